@@ -1,0 +1,301 @@
+/*
+ * prism_gpu — C ABI of the MI355X scan -> filter -> aggregate path that stands
+ * in for the DataFusion operators prism-query plans today.
+ *
+ * The reference (swgillespie/prism) has no FFI of its own: prism-query builds a
+ * DataFusion SessionContext (src/prism-query/src/main.rs:82), its TableProvider
+ * returns a ParquetExec over one file group per ingest partition
+ * (src/prism-query/src/providers/table_provider.rs:94-131), and DataFusion then
+ * runs FilterExec / AggregateExec(Partial) / RepartitionExec /
+ * AggregateExec(Final) over Arrow RecordBatches.  Each entry point below names
+ * the reference interface it replaces.  Data crosses the boundary as Arrow C
+ * Data Interface structs (arrow_c_data.h), which arrow-rs exports/imports with
+ * arrow::ffi, so a Rust `ExecutionPlan` shim needs nothing but these
+ * declarations (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *  - every function returns 0 on success or a negative prism_gpu_status; the
+ *    message is available from prism_gpu_last_error() (thread local);
+ *  - nothing throws or aborts across the boundary;
+ *  - an ArrowArray passed as "moved" is released by the library; arrays and
+ *    schemas written to `out` parameters are owned by the caller, who calls
+ *    their `release`;
+ *  - a ctx, table or plan may be used from several threads once created; a
+ *    prism_gpu_part is used by one thread at a time.
+ */
+#ifndef PRISM_GPU_H
+#define PRISM_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "arrow_c_data.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PRISM_GPU_ABI_VERSION 1u
+
+typedef struct prism_gpu_ctx prism_gpu_ctx;
+typedef struct prism_gpu_table prism_gpu_table;
+typedef struct prism_gpu_plan prism_gpu_plan;
+typedef struct prism_gpu_part prism_gpu_part;
+
+/* Error convention: stands in for datafusion::common::Result<T> on this path
+ * (src/prism-query/src/providers/table_provider.rs:85,93 map failures to
+ * DataFusionError::Internal / ::Execution).  EUNSUPPORTED from plan_create lets
+ * the caller keep DataFusion's own CPU operator for that plan. */
+typedef enum prism_gpu_status {
+  PRISM_GPU_OK = 0,
+  PRISM_GPU_EINVAL = -1,
+  PRISM_GPU_EUNSUPPORTED = -2,
+  PRISM_GPU_EOOM = -3,
+  PRISM_GPU_EHIP = -4,
+  PRISM_GPU_ERCCL = -5,
+  PRISM_GPU_EINTERNAL = -6
+} prism_gpu_status;
+
+/* Column types: the closed set of proto ColumnType
+ * (proto/common/prism/common/v1/partition.proto:26-38), same numbering, mapped
+ * to Arrow types exactly as column_type_to_datafusion does
+ * (src/prism-query/src/providers/schema_provider.rs:96-107). */
+typedef enum prism_gpu_col_type {
+  PRISM_COL_UNSPECIFIED = 0,
+  PRISM_COL_INT64 = 1,
+  PRISM_COL_UTF8 = 2,
+  PRISM_COL_TIMESTAMP = 3, /* Timestamp(Millisecond, None) */
+  PRISM_COL_INT16 = 4,
+  PRISM_COL_INT32 = 5,
+  PRISM_COL_UINT16 = 6,
+  PRISM_COL_BINARY = 7
+} prism_gpu_col_type;
+
+/* ---- plan description ---------------------------------------------------
+ * A plan is the part of DataFusion's physical plan between ParquetExec and the
+ * final RecordBatches: FilterExec predicate, AggregateExec group expressions and
+ * aggregate expressions, the aggregate mode, and an optional
+ * SortExec(fetch)/GlobalLimitExec tail.  It is passed as plain C structs. */
+
+typedef enum prism_gpu_expr_kind {
+  PRISM_EXPR_COLUMN = 1,   /* column = index into the input schema            */
+  PRISM_EXPR_LIT_I64 = 2,  /* i64 = literal, already coerced to the column type
+                              by DataFusion's type coercion                     */
+  PRISM_EXPR_LIT_STR = 3,  /* str/str_len = UTF-8 literal (not NUL terminated)  */
+  PRISM_EXPR_CMP = 4,      /* op = prism_gpu_cmp_op; lhs column, rhs literal    */
+  PRISM_EXPR_AND = 5,      /* Kleene three-valued logic, like arrow's and_kleene */
+  PRISM_EXPR_OR = 6,
+  PRISM_EXPR_NOT = 7,      /* lhs only                                          */
+  PRISM_EXPR_LIKE = 8,     /* lhs Utf8 column, rhs LIT_STR pattern; flags bit 0
+                              = NOT LIKE, bit 1 = ILIKE (ASCII case folding)    */
+  PRISM_EXPR_IS_NULL = 9,  /* lhs column                                        */
+  PRISM_EXPR_IS_NOT_NULL = 10
+} prism_gpu_expr_kind;
+
+typedef enum prism_gpu_cmp_op {
+  PRISM_CMP_EQ = 1,
+  PRISM_CMP_NEQ = 2,
+  PRISM_CMP_LT = 3,
+  PRISM_CMP_LTEQ = 4,
+  PRISM_CMP_GT = 5,
+  PRISM_CMP_GTEQ = 6
+} prism_gpu_cmp_op;
+
+#define PRISM_LIKE_NEGATED 1
+#define PRISM_LIKE_CASE_INSENSITIVE 2
+
+typedef struct prism_gpu_expr {
+  int32_t kind;   /* prism_gpu_expr_kind */
+  int32_t op;     /* prism_gpu_cmp_op for CMP */
+  int32_t lhs;    /* index of the left child in the expr array, -1 if none */
+  int32_t rhs;    /* index of the right child, -1 if none */
+  int32_t column; /* for COLUMN */
+  int32_t flags;
+  int64_t i64;    /* for LIT_I64 */
+  const char* str;
+  uint64_t str_len;
+} prism_gpu_expr;
+
+typedef enum prism_gpu_key_kind {
+  PRISM_KEY_COLUMN = 1,
+  /* date_bin(INTERVAL stride, column, origin) over Timestamp(ms); stride and
+   * origin in milliseconds.  DataFusion has no `time_bucket`; this is its
+   * spelling of a fixed-width time bucket. */
+  PRISM_KEY_DATE_BIN = 2
+} prism_gpu_key_kind;
+
+typedef struct prism_gpu_key {
+  int32_t kind;
+  int32_t column;
+  int64_t stride_ms;
+  int64_t origin_ms;
+  const char* name; /* output field name; NULL = the column's own name */
+} prism_gpu_key;
+
+typedef enum prism_gpu_agg_func {
+  PRISM_AGG_COUNT_STAR = 1, /* COUNT(*) == COUNT(UInt8(1)): counts rows       */
+  PRISM_AGG_COUNT = 2,      /* counts non-NULL values                          */
+  PRISM_AGG_SUM = 3,        /* Int* -> Int64, UInt16 -> UInt64, wrapping       */
+  PRISM_AGG_MIN = 4,        /* type preserving, NULLs ignored                  */
+  PRISM_AGG_MAX = 5,
+  PRISM_AGG_AVG = 6,        /* Float64 = f64 sum of values cast to f64 / count */
+  PRISM_AGG_COUNT_DISTINCT = 7
+} prism_gpu_agg_func;
+
+typedef struct prism_gpu_agg {
+  int32_t func;
+  int32_t column;   /* -1 for COUNT(*) */
+  const char* name; /* output field name; NULL = DataFusion's default, e.g.
+                       "COUNT(*)", "SUM(value)" */
+} prism_gpu_agg;
+
+/* AggregateMode of DataFusion's AggregateExec.  PARTIAL output = group columns
+ * followed by state columns named like DataFusion's ("COUNT(*)[count]" Int64,
+ * "SUM(x)[sum]", "MAX(x)[max]", "AVG(x)[count]" UInt64 + "AVG(x)[sum]"
+ * Float64), so an unmodified AggregateExec(Final) can consume it. */
+typedef enum prism_gpu_agg_mode {
+  PRISM_MODE_SINGLE = 0,
+  PRISM_MODE_PARTIAL = 1
+} prism_gpu_agg_mode;
+
+typedef struct prism_gpu_plan_desc {
+  uint32_t abi_version; /* PRISM_GPU_ABI_VERSION */
+  int32_t mode;         /* prism_gpu_agg_mode */
+  const prism_gpu_expr* exprs;
+  uint32_t n_exprs;
+  int32_t predicate;    /* root of the WHERE tree in exprs, -1 = no filter */
+  const prism_gpu_key* keys;
+  uint32_t n_keys;
+  const prism_gpu_agg* aggs;
+  uint32_t n_aggs;
+  /* ORDER BY <output column> [DESC] LIMIT k over the final rows (SortExec with
+   * fetch + GlobalLimitExec).  order_by indexes the OUTPUT columns (keys first,
+   * then aggregates); -1 = none.  Ties are broken arbitrarily, as in the
+   * reference.  Ignored in PARTIAL mode. */
+  int32_t order_by;
+  int32_t descending;
+  int64_t limit;        /* -1 = no limit */
+  /* Expected number of groups, 0 = unknown (the library then sizes its hash
+   * table from the scanned row count). */
+  uint64_t groups_hint;
+} prism_gpu_plan_desc;
+
+/* ---- context ------------------------------------------------------------ */
+
+/* Replaces SessionContext::new() (src/prism-query/src/main.rs:82) for this
+ * path: binds the calling process to one GPU and creates its streams, pinned
+ * staging ring and scratch pool. */
+int prism_gpu_init(int device_ordinal, prism_gpu_ctx** out);
+void prism_gpu_ctx_free(prism_gpu_ctx* ctx);
+
+/* Thread-local message for the last failing call on this thread. */
+const char* prism_gpu_last_error(void);
+
+/* ---- columnar chunk loader ----------------------------------------------
+ * Replaces what ParquetExec hands downstream (table_provider.rs:110-131):
+ * decoded Arrow columns of one partition, staged through pinned host memory
+ * into HBM and kept resident.  `schema` is the table schema the reference
+ * builds in PrismSchemaProvider::table (schema_provider.rs:73-79). */
+int prism_gpu_table_create(prism_gpu_ctx* ctx, const struct ArrowSchema* schema,
+                           prism_gpu_table** out);
+/* Appends one RecordBatch (a struct-typed ArrowArray matching the table schema;
+ * Utf8 columns may arrive dictionary encoded) to partition `partition_id`.
+ * The array is moved: the library releases it once the bytes are staged. */
+int prism_gpu_table_append(prism_gpu_table* table, uint32_t partition_id,
+                           struct ArrowArray* batch);
+int prism_gpu_table_num_rows(const prism_gpu_table* table, uint64_t* out);
+int prism_gpu_table_num_partitions(const prism_gpu_table* table, uint32_t* out);
+void prism_gpu_table_free(prism_gpu_table* table);
+
+/* Sets the dictionary of a Utf8 column whose rows are generated on the device
+ * as dictionary codes (prism_gpu_table_synth). */
+int prism_gpu_table_set_dictionary(prism_gpu_table* table, int32_t column,
+                                   const char* const* values,
+                                   const uint64_t* lengths, uint32_t n);
+
+/* Synthetic partitions generated directly in HBM by the generators of
+ * prism_synth.h (same functions on host and device, so a CPU checker can
+ * regenerate identical rows).  No counterpart in the reference: it stands in
+ * for the ClickBench / event data the reference's dev/clickbench.sh stages. */
+typedef struct prism_gpu_synth_col {
+  int32_t column; /* index in the table schema */
+  int32_t kind;   /* prism_synth_kind (prism_synth.h) */
+  int64_t p[4];   /* generator parameters */
+  const uint32_t* cdf; /* for PRISM_SYNTH_CATEGORICAL: ascending thresholds */
+  uint32_t cdf_len;
+} prism_gpu_synth_col;
+
+int prism_gpu_table_synth(prism_gpu_table* table, uint32_t partition_id,
+                          uint64_t seed, uint64_t first_row, uint64_t n_rows,
+                          uint64_t total_rows, const prism_gpu_synth_col* cols,
+                          uint32_t n_cols);
+
+/* ---- plans ---------------------------------------------------------------
+ * Replaces the physical planning DataFusion does after TableProvider::scan
+ * (table_provider.rs:73-132): FilterExec + AggregateExec (+ SortExec/Limit). */
+int prism_gpu_plan_create(prism_gpu_ctx* ctx,
+                          const struct ArrowSchema* input_schema,
+                          const prism_gpu_plan_desc* desc, prism_gpu_plan** out);
+/* ExecutionPlan::schema(): the schema of what execute/finish will return. */
+int prism_gpu_plan_output_schema(const prism_gpu_plan* plan,
+                                 struct ArrowSchema* out);
+void prism_gpu_plan_free(prism_gpu_plan* plan);
+
+/* ExecutionPlan::execute + collect over HBM-resident partitions.
+ * partition_ids == NULL or n_partitions == 0 scans every partition, as the
+ * reference does (time_range: None, table_provider.rs:90).  The result is one
+ * struct-typed ArrowArray (a record batch) in host memory. */
+int prism_gpu_execute(prism_gpu_plan* plan, prism_gpu_table* table,
+                      const uint32_t* partition_ids, size_t n_partitions,
+                      struct ArrowArray* out);
+
+/* Streaming form, one prism_gpu_part per DataFusion partition
+ * (ExecutionPlan::execute(partition, ..) polled on its own thread):
+ * push_batch moves one input RecordBatch in, finish returns the partition's
+ * output (PARTIAL state or SINGLE result). */
+int prism_gpu_partition_open(prism_gpu_plan* plan, uint32_t partition,
+                             prism_gpu_part** out);
+int prism_gpu_push_batch(prism_gpu_part* part, struct ArrowArray* batch);
+int prism_gpu_finish(prism_gpu_part* part, struct ArrowArray* out);
+void prism_gpu_part_free(prism_gpu_part* part);
+
+/* AggregateExec(Final): merges PARTIAL outputs of `plan` (from any number of
+ * partitions, GPUs or processes) into final rows, applying the plan's
+ * ORDER BY / LIMIT.  The state arrays are borrowed, not released. */
+int prism_gpu_merge(prism_gpu_plan* plan, struct ArrowArray* const* states,
+                    size_t n_states, struct ArrowArray* out);
+/* Schema of prism_gpu_merge's output (== the SINGLE-mode output schema). */
+int prism_gpu_plan_final_schema(const prism_gpu_plan* plan,
+                                struct ArrowSchema* out);
+
+/* ---- measurement ---------------------------------------------------------
+ * Per-kernel device time measured with HIP events on the stream the kernels run
+ * on, accumulated since the last reset, for roofline reporting.  Profiling is
+ * off by default (events cost a little). */
+#define PRISM_GPU_MAX_KERNEL_STATS 24
+typedef struct prism_gpu_kernel_stat {
+  char name[48];
+  uint64_t launches;
+  double total_ms;
+  uint64_t algorithmic_bytes; /* bytes the launches had to move at minimum */
+} prism_gpu_kernel_stat;
+
+typedef struct prism_gpu_stats {
+  uint64_t rows_scanned;
+  uint64_t rows_selected;
+  uint64_t groups_out;
+  uint64_t bytes_staged; /* host -> HBM */
+  double staging_ms;
+  uint32_t n_kernels;
+  prism_gpu_kernel_stat kernels[PRISM_GPU_MAX_KERNEL_STATS];
+} prism_gpu_stats;
+
+int prism_gpu_set_profiling(prism_gpu_ctx* ctx, int enabled);
+int prism_gpu_get_stats(prism_gpu_ctx* ctx, prism_gpu_stats* out);
+int prism_gpu_reset_stats(prism_gpu_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* PRISM_GPU_H */
