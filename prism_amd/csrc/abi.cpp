@@ -1,0 +1,248 @@
+// extern "C" entry points of include/prism_gpu.h: argument checking, conversion of
+// internal errors to status codes, and nothing else.
+#include <cstring>
+
+#include "engine.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+template <class F>
+int guarded(F&& f) {
+  try {
+    f();
+    return PRISM_GPU_OK;
+  } catch (const prism::Error& e) {
+    g_last_error = e.msg;
+    return e.code;
+  } catch (const std::bad_alloc&) {
+    g_last_error = "host memory exhausted";
+    return PRISM_GPU_EOOM;
+  } catch (const std::exception& e) {
+    g_last_error = std::string("internal error: ") + e.what();
+    return PRISM_GPU_EINTERNAL;
+  } catch (...) {
+    g_last_error = "unknown internal error";
+    return PRISM_GPU_EINTERNAL;
+  }
+}
+
+void require(bool ok, const char* what) {
+  if (!ok) prism::fail(PRISM_GPU_EINVAL, what);
+}
+
+std::unique_ptr<prism_gpu_table> new_table(prism_gpu_ctx* ctx, const std::vector<prism::FieldType>& fields) {
+  auto t = std::make_unique<prism_gpu_table>();
+  t->ctx = ctx;
+  t->fields = fields;
+  t->dicts.resize(fields.size());
+  return t;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* prism_gpu_last_error(void) { return g_last_error.c_str(); }
+
+int prism_gpu_init(int device_ordinal, prism_gpu_ctx** out) {
+  return guarded([&] {
+    require(out != nullptr, "out is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) prism::fail(PRISM_GPU_EHIP, "no HIP device is available; this library has no CPU fallback");
+    require(device_ordinal >= 0 && device_ordinal < n, "device ordinal out of range");
+    auto ctx = std::make_unique<prism_gpu_ctx>();
+    ctx->device = device_ordinal;
+    PRISM_HIP(hipSetDevice(device_ordinal));
+    hipDeviceProp_t prop;
+    PRISM_HIP(hipGetDeviceProperties(&prop, device_ordinal));
+    ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    PRISM_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    PRISM_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      PRISM_HIP(hipHostMalloc(&ctx->stage[i], prism_gpu_ctx::kStageBytes, hipHostMallocDefault));
+      PRISM_HIP(hipEventCreateWithFlags(&ctx->stage_done[i], hipEventDisableTiming));
+    }
+    *out = ctx.release();
+  });
+}
+
+void prism_gpu_ctx_free(prism_gpu_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  for (auto& kv : ctx->free_blocks) (void)hipFree(kv.second);
+  for (auto& kv : ctx->live_blocks) (void)hipFree(kv.first);
+  for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+  for (int i = 0; i < 2; ++i) {
+    if (ctx->stage[i]) (void)hipHostFree(ctx->stage[i]);
+    if (ctx->stage_done[i]) (void)hipEventDestroy(ctx->stage_done[i]);
+  }
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+  delete ctx;
+}
+
+int prism_gpu_table_create(prism_gpu_ctx* ctx, const struct ArrowSchema* schema, prism_gpu_table** out) {
+  return guarded([&] {
+    require(ctx && schema && out, "null argument");
+    *out = new_table(ctx, prism::parse_schema(schema)).release();
+  });
+}
+
+int prism_gpu_table_append(prism_gpu_table* table, uint32_t partition_id, struct ArrowArray* batch) {
+  return guarded([&] {
+    if (!table) {
+      if (batch && batch->release) batch->release(batch);
+      prism::fail(PRISM_GPU_EINVAL, "table is null");
+    }
+    prism::table_append(table, partition_id, batch, true);
+  });
+}
+
+int prism_gpu_table_num_rows(const prism_gpu_table* table, uint64_t* out) {
+  return guarded([&] {
+    require(table && out, "null argument");
+    uint64_t n = 0;
+    for (auto& c : table->chunks) n += c.rows;
+    *out = n;
+  });
+}
+
+int prism_gpu_table_num_partitions(const prism_gpu_table* table, uint32_t* out) {
+  return guarded([&] {
+    require(table && out, "null argument");
+    std::vector<uint32_t> ids;
+    for (auto& c : table->chunks)
+      if (std::find(ids.begin(), ids.end(), c.partition_id) == ids.end()) ids.push_back(c.partition_id);
+    *out = (uint32_t)ids.size();
+  });
+}
+
+void prism_gpu_table_free(prism_gpu_table* table) { delete table; }
+
+int prism_gpu_table_set_dictionary(prism_gpu_table* table, int32_t column, const char* const* values,
+                                   const uint64_t* lengths, uint32_t n) {
+  return guarded([&] {
+    require(table && values && lengths, "null argument");
+    require(column >= 0 && (size_t)column < table->fields.size(), "column out of range");
+    require(table->fields[column].is_string, "only string columns have a dictionary");
+    std::lock_guard<std::mutex> g(table->mu);
+    prism::ColumnDict& d = table->dicts[column];
+    require(d.values.empty(), "the column already has dictionary values");
+    for (uint32_t i = 0; i < n; ++i) {
+      uint32_t id = d.id_of(values[i], (size_t)lengths[i]);
+      if (id != i) prism::fail(PRISM_GPU_EINVAL, "dictionary values must be distinct");
+    }
+  });
+}
+
+int prism_gpu_table_synth(prism_gpu_table* table, uint32_t partition_id, uint64_t seed, uint64_t first_row,
+                          uint64_t n_rows, uint64_t total_rows, const prism_gpu_synth_col* cols, uint32_t n_cols) {
+  return guarded([&] {
+    require(table && cols, "null argument");
+    prism::table_synth(table, partition_id, seed, first_row, n_rows, total_rows, cols, n_cols);
+  });
+}
+
+int prism_gpu_plan_create(prism_gpu_ctx* ctx, const struct ArrowSchema* input_schema, const prism_gpu_plan_desc* desc,
+                          prism_gpu_plan** out) {
+  return guarded([&] {
+    require(ctx && input_schema && desc && out, "null argument");
+    *out = prism::plan_create(ctx, input_schema, desc).release();
+  });
+}
+
+int prism_gpu_plan_output_schema(const prism_gpu_plan* plan, struct ArrowSchema* out) {
+  return guarded([&] {
+    require(plan && out, "null argument");
+    prism::export_schema(plan->mode == PRISM_MODE_PARTIAL ? plan->partial_fields : plan->final_fields, out);
+  });
+}
+
+int prism_gpu_plan_final_schema(const prism_gpu_plan* plan, struct ArrowSchema* out) {
+  return guarded([&] {
+    require(plan && out, "null argument");
+    prism::export_schema(plan->final_fields, out);
+  });
+}
+
+void prism_gpu_plan_free(prism_gpu_plan* plan) { delete plan; }
+
+int prism_gpu_execute(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions,
+                      struct ArrowArray* out) {
+  return guarded([&] {
+    require(plan && table && out, "null argument");
+    prism::execute_plan(plan, table, partition_ids, n_partitions, false, out);
+  });
+}
+
+int prism_gpu_partition_open(prism_gpu_plan* plan, uint32_t partition, prism_gpu_part** out) {
+  return guarded([&] {
+    require(plan && out, "null argument");
+    auto part = std::make_unique<prism_gpu_part>();
+    part->plan = plan;
+    part->partition = partition;
+    part->table = new_table(plan->ctx, plan->fields);
+    *out = part.release();
+  });
+}
+
+int prism_gpu_push_batch(prism_gpu_part* part, struct ArrowArray* batch) {
+  return guarded([&] {
+    if (!part) {
+      if (batch && batch->release) batch->release(batch);
+      prism::fail(PRISM_GPU_EINVAL, "part is null");
+    }
+    prism::table_append(part->table.get(), part->partition, batch, true);
+  });
+}
+
+int prism_gpu_finish(prism_gpu_part* part, struct ArrowArray* out) {
+  return guarded([&] {
+    require(part && out, "null argument");
+    prism::execute_plan(part->plan, part->table.get(), nullptr, 0, false, out);
+  });
+}
+
+void prism_gpu_part_free(prism_gpu_part* part) { delete part; }
+
+int prism_gpu_merge(prism_gpu_plan* plan, struct ArrowArray* const* states, size_t n_states, struct ArrowArray* out) {
+  return guarded([&] {
+    require(plan && out && (states || n_states == 0), "null argument");
+    auto table = new_table(plan->ctx, plan->partial_fields);
+    for (size_t i = 0; i < n_states; ++i) {
+      require(states[i] != nullptr, "null state array");
+      prism::table_append(table.get(), (uint32_t)i, states[i], false);
+    }
+    prism::execute_plan(plan, table.get(), nullptr, 0, true, out);
+  });
+}
+
+int prism_gpu_set_profiling(prism_gpu_ctx* ctx, int enabled) {
+  return guarded([&] {
+    require(ctx != nullptr, "ctx is null");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    ctx->profiling = enabled != 0;
+  });
+}
+
+int prism_gpu_get_stats(prism_gpu_ctx* ctx, prism_gpu_stats* out) {
+  return guarded([&] {
+    require(ctx && out, "null argument");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    *out = ctx->stats;
+  });
+}
+
+int prism_gpu_reset_stats(prism_gpu_ctx* ctx) {
+  return guarded([&] {
+    require(ctx != nullptr, "ctx is null");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    std::memset(&ctx->stats, 0, sizeof(ctx->stats));
+  });
+}
+
+}  // extern "C"

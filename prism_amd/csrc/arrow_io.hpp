@@ -1,0 +1,56 @@
+// Arrow C Data Interface plumbing: parsing input schemas/arrays and building the
+// struct-typed arrays the library returns.  Host only.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+namespace prism {
+
+// Logical column types beyond prism_gpu_col_type that appear only in PARTIAL
+// state batches consumed by prism_gpu_merge.
+constexpr int kTypeUInt64 = 100;
+constexpr int kTypeFloat64 = 101;
+
+struct FieldType {
+  int logical = 0;      // prism_gpu_col_type or kTypeUInt64 / kTypeFloat64
+  int width = 0;        // bytes per value on the device (strings: 0)
+  bool is_unsigned = false;
+  bool is_string = false;
+  bool is_float = false;
+  bool nullable = true;
+  std::string format;   // Arrow format string of the value type
+  std::string name;
+};
+
+FieldType field_from_format(const char* format);
+// Parses a struct-typed ArrowSchema into fields (dictionary-encoded Utf8 fields
+// are reported as Utf8).
+std::vector<FieldType> parse_schema(const ArrowSchema* schema);
+
+// ---- export --------------------------------------------------------------
+
+// One output column under construction (host memory).
+struct OutColumn {
+  FieldType type;
+  std::vector<int64_t> i64;        // integer / timestamp values (any width)
+  std::vector<double> f64;
+  std::vector<std::string> str;
+  std::vector<uint8_t> valid;      // one byte per row
+  size_t rows() const { return valid.size(); }
+  void push_null();
+  void push_int(int64_t v);
+  void push_float(double v);
+  void push_str(const std::string& s);
+};
+
+OutColumn make_out_column(const std::string& name, const std::string& format, bool nullable);
+
+// Moves the columns into a freshly allocated struct ArrowArray (caller-owned).
+void export_record_batch(std::vector<OutColumn>& cols, ArrowArray* out);
+void export_schema(const std::vector<FieldType>& fields, ArrowSchema* out);
+
+}  // namespace prism

@@ -1,0 +1,175 @@
+// Per-process GPU context: device binding, streams, a size-bucketed scratch pool
+// in HBM, a pinned host staging ring, and HIP-event kernel timing.
+#pragma once
+
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+struct prism_gpu_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;       // compute
+  hipStream_t copy_stream = nullptr;  // host <-> HBM staging
+  int n_cus = 256;
+  size_t lds_per_block_max = 65536;
+
+  std::mutex mu;  // guards the pool, the staging ring and the stats
+
+  // ---- scratch pool: freed blocks are kept and reused by size class ----
+  std::multimap<size_t, void*> free_blocks;
+  std::map<void*, size_t> live_blocks;
+  size_t pool_bytes = 0;
+
+  // ---- pinned staging ring (two halves, double buffered against the copy) ----
+  static constexpr size_t kStageBytes = 64ull << 20;
+  void* stage[2] = {nullptr, nullptr};
+  hipEvent_t stage_done[2] = {nullptr, nullptr};
+  bool stage_busy[2] = {false, false};
+  int stage_next = 0;
+
+  // ---- profiling ----
+  bool profiling = false;
+  struct Pending {
+    int stat;
+    hipEvent_t a, b;
+  };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> event_pool;
+  prism_gpu_stats stats;
+
+  prism_gpu_ctx() { std::memset(&stats, 0, sizeof(stats)); }
+};
+
+namespace prism {
+
+inline void bind(prism_gpu_ctx* ctx) { PRISM_HIP(hipSetDevice(ctx->device)); }
+
+// Scratch memory for one call; returned to the pool by free_scratch.
+inline void* alloc_scratch(prism_gpu_ctx* ctx, size_t bytes) {
+  size_t cls = pow2_ceil(bytes < 256 ? 256 : bytes);
+  {
+    std::lock_guard<std::mutex> g(ctx->mu);
+    auto it = ctx->free_blocks.find(cls);
+    if (it != ctx->free_blocks.end()) {
+      void* p = it->second;
+      ctx->free_blocks.erase(it);
+      ctx->live_blocks[p] = cls;
+      return p;
+    }
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, cls);
+  if (e == hipErrorOutOfMemory) {
+    // give cached blocks back to the driver and retry once
+    std::vector<void*> drop;
+    {
+      std::lock_guard<std::mutex> g(ctx->mu);
+      for (auto& kv : ctx->free_blocks) drop.push_back(kv.second);
+      ctx->free_blocks.clear();
+    }
+    for (void* d : drop) (void)hipFree(d);
+    e = hipMalloc(&p, cls);
+  }
+  if (e != hipSuccess)
+    fail(e == hipErrorOutOfMemory ? PRISM_GPU_EOOM : PRISM_GPU_EHIP,
+         std::string("hipMalloc(") + std::to_string(cls) + ") failed: " + hipGetErrorString(e));
+  std::lock_guard<std::mutex> g(ctx->mu);
+  ctx->live_blocks[p] = cls;
+  ctx->pool_bytes += cls;
+  return p;
+}
+
+inline void free_scratch(prism_gpu_ctx* ctx, void* p) {
+  if (!p) return;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  auto it = ctx->live_blocks.find(p);
+  if (it == ctx->live_blocks.end()) return;
+  ctx->free_blocks.emplace(it->second, p);
+  ctx->live_blocks.erase(it);
+}
+
+// RAII scratch allocation.
+struct Scratch {
+  prism_gpu_ctx* ctx = nullptr;
+  void* p = nullptr;
+  Scratch() = default;
+  Scratch(prism_gpu_ctx* c, size_t bytes) : ctx(c), p(alloc_scratch(c, bytes)) {}
+  Scratch(const Scratch&) = delete;
+  Scratch& operator=(const Scratch&) = delete;
+  Scratch(Scratch&& o) noexcept : ctx(o.ctx), p(o.p) { o.p = nullptr; }
+  Scratch& operator=(Scratch&& o) noexcept {
+    if (this != &o) { reset(); ctx = o.ctx; p = o.p; o.p = nullptr; }
+    return *this;
+  }
+  ~Scratch() { reset(); }
+  void reset() { if (p) free_scratch(ctx, p); p = nullptr; }
+  template <class T> T* as() const { return (T*)p; }
+};
+
+// ---- kernel timing -------------------------------------------------------
+
+inline int stat_index(prism_gpu_ctx* ctx, const char* name) {
+  for (uint32_t i = 0; i < ctx->stats.n_kernels; ++i)
+    if (std::strncmp(ctx->stats.kernels[i].name, name, sizeof(ctx->stats.kernels[i].name)) == 0) return (int)i;
+  if (ctx->stats.n_kernels >= PRISM_GPU_MAX_KERNEL_STATS) return -1;
+  int i = (int)ctx->stats.n_kernels++;
+  std::memset(&ctx->stats.kernels[i], 0, sizeof(ctx->stats.kernels[i]));
+  std::strncpy(ctx->stats.kernels[i].name, name, sizeof(ctx->stats.kernels[i].name) - 1);
+  return i;
+}
+
+inline hipEvent_t take_event(prism_gpu_ctx* ctx) {
+  if (!ctx->event_pool.empty()) {
+    hipEvent_t e = ctx->event_pool.back();
+    ctx->event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  PRISM_HIP(hipEventCreate(&e));
+  return e;
+}
+
+// Brackets one kernel launch with events on the compute stream when profiling
+// is on; always counts the launch and its algorithmic bytes.
+struct KernelTimer {
+  prism_gpu_ctx* ctx;
+  int stat;
+  hipEvent_t a = nullptr;
+  KernelTimer(prism_gpu_ctx* c, const char* name, uint64_t algorithmic_bytes) : ctx(c) {
+    std::lock_guard<std::mutex> g(ctx->mu);
+    stat = stat_index(ctx, name);
+    if (stat >= 0) {
+      ctx->stats.kernels[stat].launches += 1;
+      ctx->stats.kernels[stat].algorithmic_bytes += algorithmic_bytes;
+    }
+    if (ctx->profiling && stat >= 0) {
+      a = take_event(ctx);
+      PRISM_HIP(hipEventRecord(a, ctx->stream));
+    }
+  }
+  ~KernelTimer() {
+    if (!a) return;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    hipEvent_t b = take_event(ctx);
+    (void)hipEventRecord(b, ctx->stream);
+    ctx->pending.push_back({stat, a, b});
+  }
+};
+
+// Call after the stream has been synchronised: folds event pairs into the stats.
+inline void collect_timings(prism_gpu_ctx* ctx) {
+  std::lock_guard<std::mutex> g(ctx->mu);
+  for (auto& p : ctx->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) ctx->stats.kernels[p.stat].total_ms += ms;
+    ctx->event_pool.push_back(p.a);
+    ctx->event_pool.push_back(p.b);
+  }
+  ctx->pending.clear();
+}
+
+}  // namespace prism

@@ -1,0 +1,62 @@
+// Device helpers shared by the kernels (wave64, gfx950).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+
+namespace prism {
+
+// Segment that owns `tile`: the last segment whose tile_base <= tile.  Wave uniform.
+__device__ __forceinline__ uint32_t find_seg(const ScanDesc& sd, uint64_t tile) {
+  uint32_t lo = 0, hi = sd.n_segs;
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (sd.segs[mid].tile_base <= tile) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;  // valid in lane 0
+}
+
+__device__ __forceinline__ long long wave_min_i64(long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { long long o = __shfl_down(v, off, 64); v = o < v ? o : v; }
+  return v;
+}
+
+__device__ __forceinline__ long long wave_max_i64(long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { long long o = __shfl_down(v, off, 64); v = o > v ? o : v; }
+  return v;
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// 64-bit finaliser (splitmix64's) used to spread packed keys over hash tables.
+__device__ __forceinline__ uint64_t hash64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+// One fixed-width value widened to int64.
+__device__ __forceinline__ long long load_value(const void* base, int width, int is_unsigned, uint64_t row) {
+  if (width == 8) return ((const long long*)base)[row];
+  if (width == 4) return is_unsigned ? (long long)((const unsigned int*)base)[row] : (long long)((const int*)base)[row];
+  return is_unsigned ? (long long)((const unsigned short*)base)[row] : (long long)((const short*)base)[row];
+}
+
+__device__ __forceinline__ bool valid_at(const uint64_t* validity, uint64_t row) {
+  return validity == nullptr || ((validity[row >> 6] >> (row & 63)) & 1ull);
+}
+
+}  // namespace prism

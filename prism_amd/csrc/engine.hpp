@@ -1,0 +1,134 @@
+// Host-side engine objects behind the opaque handles of prism_gpu.h.
+#pragma once
+
+#include <cstdint>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "arrow_io.hpp"
+#include "context.hpp"
+#include "kernels.hpp"
+
+namespace prism {
+
+// ---- resident tables --------------------------------------------------------
+
+// One column of one resident chunk (all pointers are HBM addresses).
+struct DeviceColumn {
+  void* values = nullptr;        // fixed-width values, or i32 offsets (rebased to 0) of a raw string column
+  uint64_t* validity = nullptr;  // nullptr when the chunk has no NULLs in this column
+  uint8_t* bytes = nullptr;      // raw string bytes
+  uint32_t* codes = nullptr;     // table-wide dictionary codes of a string column
+  uint64_t n_bytes = 0;
+};
+
+// A run of rows of one partition, appended in one call.
+struct Chunk {
+  uint32_t partition_id = 0;
+  uint64_t rows = 0;
+  std::vector<DeviceColumn> cols;
+  ColStats* d_stats = nullptr;      // device, one per column
+  std::vector<ColStats> stats;      // host copy, valid once stats_ready
+  bool stats_ready = false;
+};
+
+// Table-wide dictionary of a string column.  It stays alive while the column has
+// few distinct values; once it dies the column only has its raw representation.
+struct ColumnDict {
+  bool alive = true;
+  std::unordered_map<std::string, uint32_t> ids;
+  std::vector<std::string> values;
+  uint32_t id_of(const char* s, size_t n);
+};
+
+constexpr size_t kMaxDictValues = 1u << 16;
+
+}  // namespace prism
+
+struct prism_gpu_table {
+  prism_gpu_ctx* ctx = nullptr;
+  std::vector<prism::FieldType> fields;
+  std::vector<prism::Chunk> chunks;
+  std::vector<prism::ColumnDict> dicts;  // one per column (used by string columns)
+  std::mutex mu;
+  ~prism_gpu_table();
+};
+
+namespace prism {
+
+// Appends one RecordBatch.  `take` = release the array when done (moved), else borrow.
+void table_append(prism_gpu_table* t, uint32_t partition_id, ArrowArray* batch, bool take);
+void table_synth(prism_gpu_table* t, uint32_t partition_id, uint64_t seed, uint64_t first_row, uint64_t n_rows,
+                 uint64_t total_rows, const prism_gpu_synth_col* cols, uint32_t n_cols);
+void table_sync_stats(prism_gpu_table* t);
+
+// ---- plans --------------------------------------------------------------------
+
+// Predicate tree after NOT push-down: only leaves, AND and OR remain.
+struct PredNode {
+  enum Kind { CMP, LIKE, IS_NULL, IS_NOT_NULL, AND, OR } kind;
+  int column = -1;
+  int cmp_mask = 0;        // CMP: kLt | kEq | kGt
+  int64_t lit_i64 = 0;
+  std::string lit_str;     // CMP on strings, LIKE pattern
+  bool negated = false;    // NOT LIKE
+  bool case_insensitive = false;
+  int lhs = -1, rhs = -1;
+};
+
+struct KeyPlan {
+  int kind;     // prism_gpu_key_kind
+  int column;
+  int64_t stride_ms = 0, origin_ms = 0;
+  std::string name;
+};
+
+struct AggPlan {
+  int func;
+  int column;  // -1 for COUNT(*)
+  std::string name;
+};
+
+}  // namespace prism
+
+struct prism_gpu_plan {
+  prism_gpu_ctx* ctx = nullptr;
+  std::vector<prism::FieldType> fields;  // input schema
+  int mode = PRISM_MODE_SINGLE;
+  std::vector<prism::PredNode> pred;
+  int pred_root = -1;
+  std::vector<prism::KeyPlan> keys;
+  std::vector<prism::AggPlan> aggs;
+  int order_by = -1;
+  bool descending = false;
+  int64_t limit = -1;
+  uint64_t groups_hint = 0;
+  bool distinct_plan = false;
+  int distinct_col = -1;
+  std::vector<prism::FieldType> partial_fields, final_fields;
+};
+
+struct prism_gpu_part {
+  prism_gpu_plan* plan = nullptr;
+  uint32_t partition = 0;
+  std::unique_ptr<prism_gpu_table> table;
+};
+
+namespace prism {
+
+std::unique_ptr<prism_gpu_plan> plan_create(prism_gpu_ctx* ctx, const ArrowSchema* schema,
+                                            const prism_gpu_plan_desc* desc);
+
+// Runs the plan over resident chunks.  merge_input: the table holds PARTIAL state
+// batches of this plan and the result is the final rows.
+void execute_plan(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions,
+                  bool merge_input, ArrowArray* out);
+
+// Host implementation of SQL LIKE, used on dictionary values.
+std::vector<LikeToken> like_compile(const std::string& pattern);
+bool like_match_host(const std::vector<LikeToken>& tokens, const std::string& s, bool case_insensitive);
+
+}  // namespace prism

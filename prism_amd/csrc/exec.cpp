@@ -1,0 +1,849 @@
+// The executor: predicate -> selection -> aggregation -> result batch, over the
+// resident chunks of a table.  One call corresponds to what DataFusion does for
+// FilterExec + AggregateExec(Partial) [+ AggregateExec(Final) + SortExec(fetch)]
+// after prism's TableProvider::scan
+// (src/prism-query/src/providers/table_provider.rs:73-132) has produced the scan.
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+#include "engine.hpp"
+
+namespace prism {
+
+namespace {
+
+// ---- scan set ------------------------------------------------------------------
+
+struct ColUse {
+  int column;
+  bool codes;  // dictionary codes of a string column rather than its raw form
+};
+
+struct ScanSet {
+  prism_gpu_ctx* ctx = nullptr;
+  std::vector<const Chunk*> chunks;
+  std::vector<ScanSeg> segs;
+  uint64_t n_tiles = 0, rows = 0;
+  std::vector<ColUse> uses;
+  Scratch d_segs, d_cols;
+  ScanDesc desc{};
+
+  bool uploaded = false;
+  int use(int column, bool codes) {
+    for (size_t i = 0; i < uses.size(); ++i)
+      if (uses[i].column == column && uses[i].codes == codes) return (int)i;
+    if (uploaded) fail(PRISM_GPU_EINTERNAL, "column requested after the scan descriptor was uploaded");
+    uses.push_back({column, codes});
+    return (int)uses.size() - 1;
+  }
+  const ColPtr* col(int slot) const { return d_cols.as<ColPtr>() + (size_t)slot * segs.size(); }
+
+  void upload() {
+    uploaded = true;
+    if (segs.empty()) return;
+    d_segs = Scratch(ctx, segs.size() * sizeof(ScanSeg));
+    PRISM_HIP(hipMemcpyAsync(d_segs.p, segs.data(), segs.size() * sizeof(ScanSeg), hipMemcpyHostToDevice, ctx->stream));
+    std::vector<ColPtr> cp(uses.size() * segs.size());
+    for (size_t u = 0; u < uses.size(); ++u)
+      for (size_t s = 0; s < segs.size(); ++s) {
+        const DeviceColumn& dc = chunks[s]->cols[uses[u].column];
+        ColPtr& c = cp[u * segs.size() + s];
+        c.validity = dc.validity;
+        if (uses[u].codes) { c.values = dc.codes; c.bytes = nullptr; }
+        else { c.values = dc.values; c.bytes = dc.bytes; }
+        if (!c.values) fail(PRISM_GPU_EINTERNAL, "column representation missing on the device");
+      }
+    if (!cp.empty()) {
+      d_cols = Scratch(ctx, cp.size() * sizeof(ColPtr));
+      PRISM_HIP(hipMemcpyAsync(d_cols.p, cp.data(), cp.size() * sizeof(ColPtr), hipMemcpyHostToDevice, ctx->stream));
+      PRISM_HIP(hipStreamSynchronize(ctx->stream));  // cp goes out of scope
+    }
+    desc.segs = d_segs.as<ScanSeg>();
+    desc.n_segs = (uint32_t)segs.size();
+    desc.n_tiles = n_tiles;
+  }
+};
+
+struct ColInfo {  // statistics of one column over the scan set
+  long long min = 0x7fffffffffffffffll, max = -0x7fffffffffffffffll - 1;
+  unsigned long long nulls = 0;
+};
+
+ColInfo col_info(const ScanSet& ss, int column) {
+  ColInfo ci;
+  for (const Chunk* ch : ss.chunks) {
+    const ColStats& s = ch->stats[column];
+    ci.min = std::min<long long>(ci.min, s.min);
+    ci.max = std::max<long long>(ci.max, s.max);
+    ci.nulls += s.null_count;
+  }
+  return ci;
+}
+
+// ---- date_bin on the host (same arithmetic as the kernel) ---------------------------
+
+void div_magic(uint64_t d, uint64_t& magic, int& shift) {
+  if (d == 1) { magic = 0; shift = -1; return; }
+  int fl = 63 - __builtin_clzll(d);
+  if ((d & (d - 1)) == 0) { magic = 0; shift = fl - 1; return; }
+  unsigned __int128 num = (unsigned __int128)1 << (64 + fl);
+  uint64_t proposed = (uint64_t)(num / d), rem = (uint64_t)(num % d);
+  proposed += proposed;
+  uint64_t twice = rem + rem;
+  if (twice >= d || twice < rem) proposed += 1;
+  magic = proposed + 1;
+  shift = fl;
+}
+
+long long bucket_number_host(long long ts, long long stride, long long origin) {
+  long long d = (long long)((uint64_t)ts - (uint64_t)origin);
+  uint64_t a = d < 0 ? (0ull - (uint64_t)d) : (uint64_t)d;
+  long long q = (long long)(a / (uint64_t)stride);
+  if (d < 0) q = -q - (stride > 1 ? 1 : 0);
+  return q;
+}
+
+// ---- lowering of keys and aggregates ---------------------------------------------------
+
+struct KeySrc {
+  int column;
+  bool date_bin;
+  int64_t stride, origin;
+};
+
+struct KeyField {  // how to unpack one key from the packed word
+  int bit_pos = 0, bits = 0, null_bit = -1;
+  long long bias = 0;
+};
+
+struct KeyLayout {
+  std::vector<KeySpec> specs;
+  std::vector<KeyField> fields;
+  int total_bits = 0;
+};
+
+// Packs the given key sources starting at bit `cursor`.
+void layout_keys(ScanSet& ss, const prism_gpu_table* t, const std::vector<KeySrc>& keys, int& cursor, KeyLayout& L) {
+  for (const KeySrc& k : keys) {
+    const FieldType& f = t->fields[k.column];
+    if (f.is_string && !t->dicts[k.column].alive)
+      fail(PRISM_GPU_EUNSUPPORTED, "GROUP BY / DISTINCT on string column `" + f.name + "` with more than " +
+                                       std::to_string(kMaxDictValues) + " distinct values is not supported");
+    ColInfo ci = col_info(ss, k.column);
+    long long vmin = 0, vmax = 0;
+    if (ci.min <= ci.max) {
+      vmin = ci.min;
+      vmax = ci.max;
+      if (k.date_bin) { vmin = bucket_number_host(ci.min, k.stride, k.origin); vmax = bucket_number_host(ci.max, k.stride, k.origin); }
+    }
+    KeySpec s{};
+    s.col = ss.use(k.column, f.is_string);
+    s.width = f.is_string ? 4 : f.width;
+    s.is_unsigned = (f.is_string || f.is_unsigned) ? 1 : 0;
+    s.date_bin = k.date_bin ? 1 : 0;
+    s.stride = k.stride;
+    s.origin = k.origin;
+    if (k.date_bin) div_magic((uint64_t)k.stride, s.magic, s.magic_shift);
+    KeyField kf;
+    kf.bits = bits_for((uint64_t)vmax - (uint64_t)vmin);
+    kf.bias = vmin;
+    kf.bit_pos = kf.bits ? cursor : 0;
+    cursor += kf.bits;
+    if (ci.nulls) kf.null_bit = cursor++;
+    s.bias = kf.bias;
+    s.bit_pos = kf.bit_pos;
+    s.null_bit = kf.null_bit;
+    L.specs.push_back(s);
+    L.fields.push_back(kf);
+  }
+  L.total_bits = cursor;
+  if (cursor > 64)
+    fail(PRISM_GPU_EUNSUPPORTED, "GROUP BY key needs " + std::to_string(cursor) + " bits; at most 64 are supported");
+}
+
+struct SlotSrc {
+  int op;
+  int column;  // table column, -1 for kSlotAddOne
+};
+
+struct AggRule {  // how an output aggregate is read from the slots
+  int func;
+  int main_slot = -1;   // value
+  int count_slot = -1;  // > 0 <=> value is not NULL (-1: never NULL); AVG: the divisor
+};
+
+struct Lowered {
+  std::vector<SlotSrc> slots;
+  std::vector<AggRule> rules;
+  int slot(int op, int column) {
+    for (size_t i = 0; i < slots.size(); ++i)
+      if (slots[i].op == op && slots[i].column == column) return (int)i;
+    slots.push_back({op, column});
+    return (int)slots.size() - 1;
+  }
+};
+
+// Raw rows -> slots.
+Lowered lower_raw(const prism_gpu_plan* p, ScanSet& ss) {
+  Lowered L;
+  L.slot(kSlotAddOne, -1);  // slot 0: rows per group
+  for (const AggPlan& a : p->aggs) {
+    AggRule r;
+    r.func = a.func;
+    auto valid_count = [&](int column) {
+      // a column without NULLs in the scanned chunks needs no counter of its own
+      return col_info(ss, column).nulls ? L.slot(kSlotAddValid, column) : 0;
+    };
+    switch (a.func) {
+      case PRISM_AGG_COUNT_STAR: r.main_slot = 0; break;
+      case PRISM_AGG_COUNT: r.main_slot = valid_count(a.column); break;
+      case PRISM_AGG_SUM: r.main_slot = L.slot(kSlotAddI64, a.column); r.count_slot = valid_count(a.column); break;
+      case PRISM_AGG_MIN: r.main_slot = L.slot(kSlotMin, a.column); r.count_slot = valid_count(a.column); break;
+      case PRISM_AGG_MAX: r.main_slot = L.slot(kSlotMax, a.column); r.count_slot = valid_count(a.column); break;
+      case PRISM_AGG_AVG: r.main_slot = L.slot(kSlotAddF64, a.column); r.count_slot = valid_count(a.column); break;
+      default: fail(PRISM_GPU_EINTERNAL, "aggregate cannot be lowered");
+    }
+    L.rules.push_back(r);
+  }
+  return L;
+}
+
+// PARTIAL state columns -> slots (AggregateExec(Final)'s merge_batch).
+Lowered lower_merge(const prism_gpu_plan* p) {
+  Lowered L;
+  L.slot(kSlotAddOne, -1);
+  int c = (int)p->keys.size();
+  for (const AggPlan& a : p->aggs) {
+    AggRule r;
+    r.func = a.func;
+    switch (a.func) {
+      case PRISM_AGG_COUNT_STAR:
+      case PRISM_AGG_COUNT: r.main_slot = L.slot(kSlotAddI64, c); c += 1; break;
+      case PRISM_AGG_SUM: r.main_slot = L.slot(kSlotAddI64, c); r.count_slot = L.slot(kSlotAddValid, c); c += 1; break;
+      case PRISM_AGG_MIN: r.main_slot = L.slot(kSlotMin, c); r.count_slot = L.slot(kSlotAddValid, c); c += 1; break;
+      case PRISM_AGG_MAX: r.main_slot = L.slot(kSlotMax, c); r.count_slot = L.slot(kSlotAddValid, c); c += 1; break;
+      case PRISM_AGG_AVG: r.count_slot = L.slot(kSlotAddI64, c); r.main_slot = L.slot(kSlotAddF64, c + 1); c += 2; break;
+      default: fail(PRISM_GPU_EINTERNAL, "aggregate cannot be merged");
+    }
+    L.rules.push_back(r);
+  }
+  return L;
+}
+
+void fill_slots(const prism_gpu_table* t, ScanSet& ss, const Lowered& L, AggParams& ap) {
+  if (L.slots.size() > (size_t)kMaxSlots) fail(PRISM_GPU_EUNSUPPORTED, "too many aggregates in one plan");
+  std::vector<int> val_cols;
+  ap.n_slots = (int)L.slots.size();
+  for (size_t i = 0; i < L.slots.size(); ++i) {
+    ap.slots[i].op = L.slots[i].op;
+    ap.slots[i].val = -1;
+    if (L.slots[i].column < 0) continue;
+    auto it = std::find(val_cols.begin(), val_cols.end(), L.slots[i].column);
+    if (it == val_cols.end()) { val_cols.push_back(L.slots[i].column); it = val_cols.end() - 1; }
+    ap.slots[i].val = (int)(it - val_cols.begin());
+  }
+  if (val_cols.size() > (size_t)kMaxVals) fail(PRISM_GPU_EUNSUPPORTED, "too many aggregate input columns in one plan");
+  ap.n_vals = (int)val_cols.size();
+  for (size_t j = 0; j < val_cols.size(); ++j) {
+    const FieldType& f = t->fields[val_cols[j]];
+    ValSpec& v = ap.vals[j];
+    // COUNT(x) over a string column only needs its validity: either representation will do
+    v.col = ss.use(val_cols[j], f.is_string && t->dicts[val_cols[j]].alive);
+    v.width = f.is_string ? 4 : f.width;
+    v.is_unsigned = (f.is_string || f.is_unsigned) ? 1 : 0;
+    v.is_float = f.is_float ? 1 : 0;
+  }
+}
+
+long long slot_identity_host(int op) {
+  return op == kSlotMin ? 0x7fffffffffffffffll : (op == kSlotMax ? -0x7fffffffffffffffll - 1 : 0ll);
+}
+
+// ---- predicate evaluation -------------------------------------------------------------
+
+// Which representation of its column a predicate leaf reads: dictionary codes or
+// the raw values / offsets + bytes.
+bool leaf_uses_codes(const prism_gpu_table* t, const ScanSet& ss, const PredNode& n) {
+  const FieldType& f = t->fields[n.column];
+  if (!f.is_string) return false;
+  if (n.kind == PredNode::IS_NULL || n.kind == PredNode::IS_NOT_NULL) return ss.chunks[0]->cols[n.column].values == nullptr;
+  return t->dicts[n.column].alive;
+}
+
+struct Selection {
+  bool all = true;      // no predicate: every row
+  Scratch bits;         // TRUE rows, one bit per padded row id
+  uint64_t count = 0;
+};
+
+struct PredEval {
+  prism_gpu_plan* plan;
+  prism_gpu_table* table;
+  ScanSet& ss;
+  prism_gpu_ctx* ctx;
+  uint64_t n_words;
+  std::vector<Scratch> keep;  // literals etc. that must outlive the launches
+
+  Scratch new_bits(bool zero) {
+    Scratch b(ctx, n_words * 8);
+    if (zero) PRISM_HIP(hipMemsetAsync(b.p, 0, n_words * 8, ctx->stream));
+    return b;
+  }
+  const uint8_t* to_device(const void* src, size_t n) {
+    keep.emplace_back(ctx, n + 16);
+    PRISM_HIP(hipMemcpyAsync(keep.back().p, src, n, hipMemcpyHostToDevice, ctx->stream));
+    PRISM_HIP(hipStreamSynchronize(ctx->stream));
+    return keep.back().as<uint8_t>();
+  }
+
+  // String predicate through the column's dictionary: evaluated once per distinct
+  // value on the host, then a code -> bit lookup on the device.
+  Scratch lut_leaf(const PredNode& n, const ColumnDict& dict) {
+    std::vector<uint8_t> lut(dict.values.size() + 1, 0);
+    std::vector<LikeToken> toks;
+    if (n.kind == PredNode::LIKE) toks = like_compile(n.lit_str);
+    for (size_t i = 0; i < dict.values.size(); ++i) {
+      const std::string& v = dict.values[i];
+      bool t;
+      if (n.kind == PredNode::LIKE) {
+        t = like_match_host(toks, v, n.case_insensitive) != n.negated;
+      } else {
+        int c = std::memcmp(v.data(), n.lit_str.data(), std::min(v.size(), n.lit_str.size()));
+        if (c == 0) c = v.size() < n.lit_str.size() ? -1 : (v.size() > n.lit_str.size() ? 1 : 0);
+        t = (c < 0 && (n.cmp_mask & kLt)) || (c == 0 && (n.cmp_mask & kEq)) || (c > 0 && (n.cmp_mask & kGt));
+      }
+      lut[i] = t ? 1 : 0;
+    }
+    const uint8_t* d_lut = to_device(lut.data(), lut.size());
+    Scratch bits = new_bits(false);
+    KernelTimer timer(ctx, "pred_lut", ss.rows * 4);
+    launch_lut_leaf(ctx, ss.desc, ss.col(ss.use(n.column, true)), d_lut, (uint32_t)dict.values.size(), bits.as<uint64_t>());
+    return bits;
+  }
+
+  Scratch eval(int i) {
+    const PredNode& n = plan->pred[i];
+    switch (n.kind) {
+      case PredNode::AND:
+      case PredNode::OR: {
+        Scratch a = eval(n.lhs), b = eval(n.rhs);
+        if (n.kind == PredNode::AND) launch_bitmap_and(ctx, a.as<uint64_t>(), b.as<uint64_t>(), a.as<uint64_t>(), n_words);
+        else launch_bitmap_or(ctx, a.as<uint64_t>(), b.as<uint64_t>(), a.as<uint64_t>(), n_words);
+        // b returns to the pool here; the stream orders its reuse after this launch
+        return a;
+      }
+      case PredNode::IS_NULL:
+      case PredNode::IS_NOT_NULL: {
+        Scratch bits = new_bits(false);
+        launch_null_leaf(ctx, ss.desc, ss.col(ss.use(n.column, leaf_uses_codes(table, ss, n))), n.kind == PredNode::IS_NULL,
+                         bits.as<uint64_t>());
+        return bits;
+      }
+      case PredNode::CMP: {
+        const FieldType& f = table->fields[n.column];
+        if (!f.is_string) {
+          Scratch bits = new_bits(false);
+          KernelTimer timer(ctx, "pred_cmp", ss.rows * f.width);
+          launch_cmp_leaf(ctx, ss.desc, ss.col(ss.use(n.column, false)), f.width, f.is_unsigned, n.cmp_mask, n.lit_i64,
+                          bits.as<uint64_t>(), nullptr);
+          return bits;
+        }
+        const ColumnDict& dict = table->dicts[n.column];
+        if (dict.alive) return lut_leaf(n, dict);
+        const uint8_t* lit = to_device(n.lit_str.data(), n.lit_str.size());
+        Scratch bits = new_bits(false);
+        KernelTimer timer(ctx, "pred_str", 0);
+        launch_str_leaf(ctx, ss.desc, ss.col(ss.use(n.column, false)), kStrCmp, n.cmp_mask, lit, (uint32_t)n.lit_str.size(),
+                        nullptr, 0, false, false, bits.as<uint64_t>());
+        return bits;
+      }
+      case PredNode::LIKE: {
+        const ColumnDict& dict = table->dicts[n.column];
+        if (dict.alive) return lut_leaf(n, dict);
+        if (ss.chunks[0]->cols[n.column].values == nullptr)
+          fail(PRISM_GPU_EUNSUPPORTED, "LIKE on a generated dictionary column without a dictionary");
+        std::vector<LikeToken> toks = like_compile(n.lit_str);
+        int col = ss.use(n.column, false);
+        // '%needle%': any run, literal bytes, any run
+        bool contains = toks.size() >= 3 && toks.front().kind == 2 && toks.back().kind == 2 && !n.case_insensitive;
+        for (size_t k = 1; contains && k + 1 < toks.size(); ++k) contains = toks[k].kind == 0;
+        uint64_t str_bytes = 0;
+        for (const Chunk* ch : ss.chunks) str_bytes += ch->cols[n.column].n_bytes;
+        if (contains) {
+          std::string needle;
+          for (size_t k = 1; k + 1 < toks.size(); ++k) needle.push_back((char)toks[k].byte);
+          const uint8_t* d_needle = to_device(needle.data(), needle.size());
+          Scratch bits = new_bits(true);
+          {
+            KernelTimer timer(ctx, "like_contains", str_bytes + ss.rows * 4);
+            for (size_t s = 0; s < ss.segs.size(); ++s) {
+              const DeviceColumn& dc = ss.chunks[s]->cols[n.column];
+              ColPtr cp{dc.values, dc.validity, dc.bytes};
+              launch_contains_stream(ctx, cp, ss.segs[s].rows, ss.segs[s].tile_base, d_needle, (uint32_t)needle.size(),
+                                     bits.as<uint64_t>());
+            }
+          }
+          launch_mask_validity(ctx, ss.desc, ss.col(col), n.negated, bits.as<uint64_t>());
+          return bits;
+        }
+        const uint8_t* d_toks = to_device(toks.data(), toks.size() * sizeof(LikeToken));
+        Scratch bits = new_bits(false);
+        KernelTimer timer(ctx, "pred_str", str_bytes + ss.rows * 4);
+        launch_str_leaf(ctx, ss.desc, ss.col(col), kStrLike, 0, nullptr, 0, (const LikeToken*)d_toks, (uint32_t)toks.size(),
+                        n.negated, n.case_insensitive, bits.as<uint64_t>());
+        return bits;
+      }
+    }
+    fail(PRISM_GPU_EINTERNAL, "bad predicate node");
+  }
+};
+
+// ---- result assembly ---------------------------------------------------------------------
+
+struct GroupRows {
+  std::vector<uint64_t> keys;   // packed
+  std::vector<int64_t> state;   // slot-major, n groups each
+  uint64_t n = 0;
+};
+
+int64_t state_at(const GroupRows& g, int slot, uint64_t i) { return g.state[(size_t)slot * g.n + i]; }
+
+void push_key_values(const prism_gpu_table* t, const std::vector<KeySrc>& keys, const KeyLayout& L, size_t first_key,
+                     uint64_t packed, std::vector<OutColumn>& cols, size_t first_col) {
+  for (size_t i = 0; i < keys.size(); ++i) {
+    const KeyField& kf = L.fields[first_key + i];
+    OutColumn& oc = cols[first_col + i];
+    if (kf.null_bit >= 0 && ((packed >> kf.null_bit) & 1ull)) { oc.push_null(); continue; }
+    uint64_t field = kf.bits == 0 ? 0 : ((packed >> kf.bit_pos) & (kf.bits == 64 ? ~0ull : ((1ull << kf.bits) - 1ull)));
+    long long v = (long long)((uint64_t)kf.bias + field);
+    const KeySrc& k = keys[i];
+    if (k.date_bin) v = (long long)((uint64_t)k.origin + (uint64_t)v * (uint64_t)k.stride);
+    const FieldType& f = t->fields[k.column];
+    if (f.is_string) {
+      const ColumnDict& d = t->dicts[k.column];
+      if ((uint64_t)v >= d.values.size()) fail(PRISM_GPU_EINTERNAL, "dictionary code out of range in result");
+      oc.push_str(d.values[(size_t)v]);
+    } else {
+      oc.push_int(v);
+    }
+  }
+}
+
+std::vector<OutColumn> make_columns(const std::vector<FieldType>& fields) {
+  std::vector<OutColumn> cols;
+  for (auto& f : fields) cols.push_back(make_out_column(f.name, f.format, f.nullable));
+  return cols;
+}
+
+void push_aggs(const prism_gpu_plan* p, const Lowered& L, const GroupRows& g, uint64_t i, bool partial,
+               std::vector<OutColumn>& cols, size_t c) {
+  for (const AggRule& r : L.rules) {
+    int64_t main = state_at(g, r.main_slot, i);
+    int64_t cnt = r.count_slot >= 0 ? state_at(g, r.count_slot, i) : 1;
+    switch (r.func) {
+      case PRISM_AGG_COUNT_STAR:
+      case PRISM_AGG_COUNT: cols[c++].push_int(main); break;
+      case PRISM_AGG_SUM:
+      case PRISM_AGG_MIN:
+      case PRISM_AGG_MAX:
+        if (cnt > 0) cols[c].push_int(main); else cols[c].push_null();
+        ++c;
+        break;
+      case PRISM_AGG_AVG: {
+        double sum;
+        std::memcpy(&sum, &main, 8);
+        if (partial) {
+          cols[c++].push_int(cnt);
+          if (cnt > 0) cols[c].push_float(sum); else cols[c].push_null();
+          ++c;
+        } else {
+          if (cnt > 0) cols[c].push_float(sum / (double)cnt); else cols[c].push_null();
+          ++c;
+        }
+        break;
+      }
+    }
+  }
+}
+
+void sort_and_limit(const prism_gpu_plan* p, std::vector<OutColumn>& cols) {
+  if (p->order_by < 0 && p->limit < 0) return;
+  size_t n = cols.empty() ? 0 : cols[0].rows();
+  std::vector<size_t> idx(n);
+  std::iota(idx.begin(), idx.end(), 0);
+  if (p->order_by >= 0) {
+    const OutColumn& oc = cols[p->order_by];
+    const bool desc = p->descending, uns = oc.type.is_unsigned && !oc.type.is_string;
+    auto less = [&](size_t a, size_t b) {
+      bool na = !oc.valid[a], nb = !oc.valid[b];
+      if (na || nb) return desc ? (na && !nb) : (!na && nb);  // NULLS FIRST for DESC, LAST for ASC
+      int c;
+      if (oc.type.is_string) c = oc.str[a].compare(oc.str[b]);
+      else if (oc.type.is_float) c = oc.f64[a] < oc.f64[b] ? -1 : (oc.f64[a] > oc.f64[b] ? 1 : 0);
+      else if (uns) c = (uint64_t)oc.i64[a] < (uint64_t)oc.i64[b] ? -1 : ((uint64_t)oc.i64[a] > (uint64_t)oc.i64[b] ? 1 : 0);
+      else c = oc.i64[a] < oc.i64[b] ? -1 : (oc.i64[a] > oc.i64[b] ? 1 : 0);
+      return desc ? c > 0 : c < 0;
+    };
+    if (p->limit >= 0 && (size_t)p->limit < n) std::partial_sort(idx.begin(), idx.begin() + p->limit, idx.end(), less);
+    else std::stable_sort(idx.begin(), idx.end(), less);
+  }
+  if (p->limit >= 0 && (size_t)p->limit < idx.size()) idx.resize((size_t)p->limit);
+  std::vector<OutColumn> out;
+  for (auto& c : cols) {
+    OutColumn s = make_out_column(c.type.name, c.type.format, c.type.nullable);
+    for (size_t i : idx) {
+      if (!c.valid[i]) s.push_null();
+      else if (c.type.is_string) s.push_str(c.str[i]);
+      else if (c.type.is_float) s.push_float(c.f64[i]);
+      else s.push_int(c.i64[i]);
+    }
+    out.push_back(std::move(s));
+  }
+  cols.swap(out);
+}
+
+// ---- HBM group tables --------------------------------------------------------------------------
+
+constexpr int kDenseMaxBits = 22;
+
+struct GroupTable {
+  bool dense = false;
+  uint64_t capacity = 0;
+  int n_slots = 0;
+  Scratch keys, state, overflow;
+};
+
+void table_alloc(prism_gpu_ctx* ctx, GroupTable& g, bool dense, uint64_t capacity, const std::vector<int>& slot_ops) {
+  g.dense = dense;
+  g.capacity = capacity;
+  g.n_slots = (int)slot_ops.size();
+  g.state = Scratch(ctx, (capacity + 1) * 8 * slot_ops.size());
+  g.overflow = Scratch(ctx, 256);
+  PRISM_HIP(hipMemsetAsync(g.overflow.p, 0, 4, ctx->stream));
+  if (!dense) {
+    g.keys = Scratch(ctx, (capacity + 1) * 8);
+    PRISM_HIP(hipMemsetAsync(g.keys.p, 0xff, (capacity + 1) * 8, ctx->stream));
+  }
+  for (size_t s = 0; s < slot_ops.size(); ++s) {
+    int64_t* base = g.state.as<int64_t>() + s * (capacity + 1);
+    long long id = slot_identity_host(slot_ops[s]);
+    if (id == 0) PRISM_HIP(hipMemsetAsync(base, 0, (capacity + 1) * 8, ctx->stream));
+    else launch_fill_i64(ctx, base, capacity + 1, id);
+  }
+}
+
+bool table_overflowed(prism_gpu_ctx* ctx, const GroupTable& g) {
+  uint32_t flag = 0;
+  PRISM_HIP(hipMemcpyAsync(&flag, g.overflow.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  PRISM_HIP(hipStreamSynchronize(ctx->stream));
+  return flag != 0;
+}
+
+GroupRows table_read(prism_gpu_ctx* ctx, const GroupTable& g) {
+  GroupRows rows;
+  Scratch d_count(ctx, 256);
+  PRISM_HIP(hipMemsetAsync(d_count.p, 0, 8, ctx->stream));
+  launch_emit(ctx, g.dense, g.capacity, g.keys.as<uint64_t>(), g.state.as<int64_t>(), g.n_slots, nullptr, nullptr, 0,
+              d_count.as<unsigned long long>());
+  unsigned long long n = 0;
+  PRISM_HIP(hipMemcpyAsync(&n, d_count.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+  PRISM_HIP(hipStreamSynchronize(ctx->stream));
+  rows.n = n;
+  if (n == 0) return rows;
+  Scratch d_keys(ctx, n * 8), d_state(ctx, n * 8 * g.n_slots);
+  PRISM_HIP(hipMemsetAsync(d_count.p, 0, 8, ctx->stream));
+  launch_emit(ctx, g.dense, g.capacity, g.keys.as<uint64_t>(), g.state.as<int64_t>(), g.n_slots, d_keys.as<uint64_t>(),
+              d_state.as<int64_t>(), n, d_count.as<unsigned long long>());
+  rows.keys.resize(n);
+  rows.state.resize((size_t)n * g.n_slots);
+  PRISM_HIP(hipMemcpyAsync(rows.keys.data(), d_keys.p, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PRISM_HIP(hipMemcpyAsync(rows.state.data(), d_state.p, n * 8 * g.n_slots, hipMemcpyDeviceToHost, ctx->stream));
+  PRISM_HIP(hipStreamSynchronize(ctx->stream));
+  return rows;
+}
+
+int lds_slots_for(int n_slots) {
+  // about 32 KiB of LDS per workgroup, so that several workgroups share a CU
+  size_t per_entry = 8 * (1 + (size_t)n_slots);
+  int s = 256;
+  while ((size_t)s * 2 * per_entry <= 32768) s *= 2;
+  return s;
+}
+
+}  // namespace
+
+void execute_plan(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions,
+                  bool merge_input, ArrowArray* out) {
+  prism_gpu_ctx* ctx = plan->ctx;
+  bind(ctx);
+  if (table->ctx != ctx) fail(PRISM_GPU_EINVAL, "plan and table belong to different contexts");
+  const std::vector<FieldType>& expect = merge_input ? plan->partial_fields : plan->fields;
+  if (table->fields.size() != expect.size()) fail(PRISM_GPU_EINVAL, "table schema does not match the plan's input schema");
+  for (size_t i = 0; i < expect.size(); ++i)
+    if (table->fields[i].logical != expect[i].logical)
+      fail(PRISM_GPU_EINVAL, "column " + std::to_string(i) + " (`" + table->fields[i].name + "`) has a different type than the plan expects");
+  table_sync_stats(table);
+
+  // ---- which chunks ----
+  ScanSet ss;
+  ss.ctx = ctx;
+  for (const Chunk& ch : table->chunks) {
+    bool take = partition_ids == nullptr || n_partitions == 0;
+    for (size_t i = 0; !take && i < n_partitions; ++i) take = partition_ids[i] == ch.partition_id;
+    if (!take || ch.rows == 0) continue;
+    ss.chunks.push_back(&ch);
+    ss.segs.push_back({ch.rows, ss.n_tiles});
+    ss.n_tiles += ceil_div(ch.rows, kTileRows);
+    ss.rows += ch.rows;
+  }
+  if (ss.n_tiles * (uint64_t)kTileRows > 0xffffffffull)
+    fail(PRISM_GPU_EUNSUPPORTED, "more than 2^32 rows in one scan; split the scan by partition");
+  const uint64_t n_words = ss.n_tiles * kTileWords;
+  const bool partial = plan->mode == PRISM_MODE_PARTIAL && !merge_input;
+
+  // ---- lowering ----
+  std::vector<KeySrc> keys;
+  for (size_t i = 0; i < plan->keys.size(); ++i) {
+    const KeyPlan& k = plan->keys[i];
+    if (merge_input) keys.push_back({(int)i, false, 0, 0});
+    else keys.push_back({k.column, k.kind == PRISM_KEY_DATE_BIN, k.stride_ms, k.origin_ms});
+  }
+  Lowered low;
+  KeySrc distinct_src{-1, false, 0, 0};
+  if (plan->distinct_plan) {
+    low.slot(kSlotAddOne, -1);
+    distinct_src.column = merge_input ? (int)plan->keys.size() : plan->distinct_col;
+  } else {
+    low = merge_input ? lower_merge(plan) : lower_raw(plan, ss);
+  }
+
+  AggParams ap;
+  std::memset(&ap, 0, sizeof(ap));
+  KeyLayout layout;
+  int cursor = 0;
+  if (!ss.chunks.empty()) {
+    if (plan->distinct_plan) layout_keys(ss, table, {distinct_src}, cursor, layout);
+    const int x_bits = cursor;
+    layout_keys(ss, table, keys, cursor, layout);
+    (void)x_bits;
+    fill_slots(table, ss, low, ap);
+  }
+
+  // ---- predicate ----
+  Selection sel;
+  uint64_t selected = ss.rows;
+  PredEval pe{plan, table, ss, ctx, n_words, {}};
+  const bool has_pred = plan->pred_root >= 0 && !merge_input && !ss.chunks.empty();
+  // The common "COUNT(*) WHERE col <op> literal" shape needs no bitmap at all.
+  bool count_only = has_pred && plan->keys.empty() && !plan->distinct_plan && plan->aggs.size() == 1 &&
+                    plan->aggs[0].func == PRISM_AGG_COUNT_STAR && plan->pred[plan->pred_root].kind == PredNode::CMP &&
+                    !table->fields[plan->pred[plan->pred_root].column].is_string;
+  if (has_pred && count_only) ss.use(plan->pred[plan->pred_root].column, false);
+  if (has_pred && !count_only) {
+    // register every column the predicate touches before the upload
+    for (const PredNode& n : plan->pred)
+      if (n.column >= 0) ss.use(n.column, leaf_uses_codes(table, ss, n));
+  }
+  ss.upload();
+  ap.sd = ss.desc;
+  ap.cols = ss.d_cols.as<ColPtr>();
+
+  Scratch d_scalar(ctx, 256);
+  if (has_pred && count_only) {
+    const PredNode& n = plan->pred[plan->pred_root];
+    const FieldType& f = table->fields[n.column];
+    PRISM_HIP(hipMemsetAsync(d_scalar.p, 0, 8, ctx->stream));
+    {
+      KernelTimer timer(ctx, "filter_count", ss.rows * f.width);
+      launch_cmp_leaf(ctx, ss.desc, ss.col(ss.use(n.column, false)), f.width, f.is_unsigned, n.cmp_mask, n.lit_i64, nullptr,
+                      d_scalar.as<unsigned long long>());
+    }
+    unsigned long long c = 0;
+    PRISM_HIP(hipMemcpyAsync(&c, d_scalar.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PRISM_HIP(hipStreamSynchronize(ctx->stream));
+    collect_timings(ctx);
+    std::vector<OutColumn> cols = make_columns(partial ? plan->partial_fields : plan->final_fields);
+    cols[0].push_int((int64_t)c);
+    {
+      std::lock_guard<std::mutex> g(ctx->mu);
+      ctx->stats.rows_scanned += ss.rows;
+      ctx->stats.rows_selected += c;
+      ctx->stats.groups_out += 1;
+    }
+    export_record_batch(cols, out);
+    return;
+  }
+  Scratch selvec;
+  if (has_pred) {
+    sel.all = false;
+    sel.bits = pe.eval(plan->pred_root);
+    PRISM_HIP(hipMemsetAsync(d_scalar.p, 0, 8, ctx->stream));
+    launch_bitmap_count(ctx, sel.bits.as<uint64_t>(), n_words, d_scalar.as<unsigned long long>());
+    unsigned long long c = 0;
+    PRISM_HIP(hipMemcpyAsync(&c, d_scalar.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PRISM_HIP(hipStreamSynchronize(ctx->stream));
+    sel.count = selected = c;
+    ap.row_mode = kRowsBitmap;
+    ap.sel_bits = sel.bits.as<uint64_t>();
+    // Few survivors: compact them into a selection vector so that the aggregation
+    // gathers only those rows instead of streaming every column in full.
+    if (selected * 8 < ss.rows && selected > 0) {
+      Scratch tile_offsets(ctx, (ss.n_tiles + 1) * 4);
+      KernelTimer timer(ctx, "compact_selvec", n_words * 8 + selected * 4);
+      launch_compact(ctx, sel.bits.as<uint64_t>(), ss.n_tiles, tile_offsets.as<uint32_t>(), nullptr,
+                     d_scalar.as<unsigned long long>());
+      selvec = Scratch(ctx, selected * 4);
+      launch_compact(ctx, sel.bits.as<uint64_t>(), ss.n_tiles, tile_offsets.as<uint32_t>(), selvec.as<uint32_t>(), nullptr);
+      PRISM_HIP(hipStreamSynchronize(ctx->stream));  // tile_offsets is released at scope end
+      ap.row_mode = kRowsSelvec;
+      ap.selvec = selvec.as<uint32_t>();
+      ap.n_sel = selected;
+    }
+  }
+
+  std::vector<OutColumn> cols = make_columns(partial ? plan->partial_fields : plan->final_fields);
+  uint64_t groups_out = 0;
+  uint64_t value_bytes = 0;  // algorithmic bytes per row of the aggregation kernel
+  for (int j = 0; j < ap.n_vals; ++j) value_bytes += ap.vals[j].width;
+  for (auto& s : layout.specs) value_bytes += s.width;
+
+  if (ss.chunks.empty() || selected == 0) {
+    // no input rows: an ungrouped aggregate still yields one row
+    if (plan->keys.empty()) {
+      size_t c = 0;
+      if (partial && plan->distinct_plan) cols[c++].push_null();
+      else for (const AggPlan& a : plan->aggs) {
+        bool is_count = a.func == PRISM_AGG_COUNT_STAR || a.func == PRISM_AGG_COUNT || a.func == PRISM_AGG_COUNT_DISTINCT;
+        if (is_count) cols[c++].push_int(0);
+        else if (a.func == PRISM_AGG_AVG && partial) { cols[c++].push_int(0); cols[c++].push_null(); }
+        else cols[c++].push_null();
+      }
+      groups_out = 1;
+    }
+  } else if (plan->keys.empty() && !plan->distinct_plan) {
+    // ---- ungrouped aggregates ----
+    std::vector<int64_t> init(ap.n_slots);
+    for (int s = 0; s < ap.n_slots; ++s) init[s] = slot_identity_host(ap.slots[s].op);
+    Scratch d_out(ctx, 256);
+    PRISM_HIP(hipMemcpyAsync(d_out.p, init.data(), init.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    {
+      KernelTimer timer(ctx, "agg_global", (ap.row_mode == kRowsSelvec ? selected : ss.rows) * value_bytes);
+      launch_agg_global(ctx, ap, d_out.as<int64_t>());
+    }
+    GroupRows g;
+    g.n = 1;
+    g.keys.assign(1, 0);
+    g.state.resize(ap.n_slots);
+    PRISM_HIP(hipMemcpyAsync(g.state.data(), d_out.p, g.state.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PRISM_HIP(hipStreamSynchronize(ctx->stream));
+    push_aggs(plan, low, g, 0, partial, cols, 0);
+    groups_out = 1;
+  } else {
+    // ---- GROUP BY ----
+    const int total_bits = layout.total_bits;
+    std::vector<int> slot_ops;
+    for (int s = 0; s < ap.n_slots; ++s) slot_ops.push_back(ap.slots[s].op);
+    ap.n_keys = (int)layout.specs.size();
+    for (size_t i = 0; i < layout.specs.size(); ++i) ap.keys[i] = layout.specs[i];
+    ap.lds_slots = lds_slots_for(ap.n_slots);
+    uint64_t bound = selected;
+    if (total_bits < 63) bound = std::min<uint64_t>(bound, 1ull << total_bits);
+    GroupTable gt;
+    bool dense = total_bits <= kDenseMaxBits;
+    uint64_t capacity = dense ? (1ull << total_bits)
+                              : pow2_ceil(std::max<uint64_t>(1024, 2 * (plan->groups_hint ? std::min<uint64_t>(plan->groups_hint, bound)
+                                                                                         : std::min<uint64_t>(bound, 1ull << 24))));
+    const uint64_t max_capacity = pow2_ceil(std::max<uint64_t>(1024, 2 * bound));
+    for (;;) {
+      table_alloc(ctx, gt, dense, capacity, slot_ops);
+      ap.dense = dense ? 1 : 0;
+      ap.capacity = capacity;
+      ap.g_keys = gt.keys.as<uint64_t>();
+      ap.g_state = gt.state.as<int64_t>();
+      ap.overflow = gt.overflow.as<uint32_t>();
+      launch_group_by(ctx, ap, (ap.row_mode == kRowsSelvec ? selected : ss.rows) * value_bytes);
+      if (dense || !table_overflowed(ctx, gt)) break;
+      if (capacity >= max_capacity) fail(PRISM_GPU_EINTERNAL, "group table overflow at maximum capacity");
+      capacity = std::min(max_capacity, capacity * 8);  // more groups than expected: grow and redo the pass
+    }
+    if (!plan->distinct_plan) {
+      GroupRows g = table_read(ctx, gt);
+      for (uint64_t i = 0; i < g.n; ++i) {
+        push_key_values(table, keys, layout, 0, g.keys[i], cols, 0);
+        push_aggs(plan, low, g, i, partial, cols, keys.size());
+      }
+      groups_out = g.n;
+    } else if (partial) {
+      // inner GROUP BY (keys, x): one row per distinct pair
+      GroupRows g = table_read(ctx, gt);
+      for (uint64_t i = 0; i < g.n; ++i) {
+        push_key_values(table, keys, layout, 1, g.keys[i], cols, 0);
+        push_key_values(table, {distinct_src}, layout, 0, g.keys[i], cols, keys.size());
+      }
+      groups_out = g.n;
+    } else {
+      // outer GROUP BY keys: COUNT(x) over the distinct pairs
+      const KeyField& xf = layout.fields[0];
+      int x_bits = xf.bits + (xf.null_bit >= 0 ? 1 : 0);
+      int k_bits = total_bits - x_bits;
+      GroupTable q;
+      bool qdense = k_bits <= kDenseMaxBits;
+      uint64_t qcap = qdense ? (1ull << k_bits) : pow2_ceil(std::max<uint64_t>(1024, 2 * std::min<uint64_t>(selected, k_bits < 63 ? (1ull << k_bits) : selected)));
+      table_alloc(ctx, q, qdense, qcap, {kSlotAddOne, kSlotAddOne});
+      DistinctFoldParams fp{};
+      fp.set_keys = gt.dense ? nullptr : gt.keys.as<uint64_t>();
+      fp.set_capacity = gt.capacity + 1;
+      fp.set_special = gt.capacity;
+      fp.set_rowcount = gt.state.as<int64_t>();
+      fp.x_bits = x_bits;
+      fp.x_null_bit = xf.null_bit;
+      fp.dense = qdense ? 1 : 0;
+      fp.capacity = qcap;
+      fp.g_keys = q.keys.as<uint64_t>();
+      fp.g_state = q.state.as<int64_t>();
+      fp.overflow = q.overflow.as<uint32_t>();
+      GroupRows pairs;  // dense sets are folded on the host side of the emit: read them as rows
+      if (gt.dense) {
+        // a dense (k, x) set has no key array; materialise its occupied entries first
+        pairs = table_read(ctx, gt);
+        Scratch d_pairs(ctx, std::max<uint64_t>(1, pairs.n) * 8);
+        if (pairs.n) PRISM_HIP(hipMemcpyAsync(d_pairs.p, pairs.keys.data(), pairs.n * 8, hipMemcpyHostToDevice, ctx->stream));
+        fp.set_keys = d_pairs.as<uint64_t>();
+        fp.set_capacity = pairs.n;
+        fp.set_special = ~0ull;
+        if (pairs.n) launch_distinct_fold(ctx, fp);
+        PRISM_HIP(hipStreamSynchronize(ctx->stream));
+      } else {
+        launch_distinct_fold(ctx, fp);
+      }
+      if (table_overflowed(ctx, q)) fail(PRISM_GPU_EINTERNAL, "distinct group table overflow");
+      GroupRows g = table_read(ctx, q);
+      // unpack keys from the high bits: shift the layout down by x_bits
+      KeyLayout kl;
+      for (size_t i = 1; i < layout.fields.size(); ++i) {
+        KeyField f = layout.fields[i];
+        if (f.bits) f.bit_pos -= x_bits;
+        if (f.null_bit >= 0) f.null_bit -= x_bits;
+        kl.fields.push_back(f);
+      }
+      for (uint64_t i = 0; i < g.n; ++i) {
+        push_key_values(table, keys, kl, 0, g.keys[i], cols, 0);
+        for (size_t a = 0; a < plan->aggs.size(); ++a) cols[keys.size() + a].push_int(state_at(g, 1, i));
+      }
+      groups_out = g.n;
+    }
+  }
+  PRISM_HIP(hipStreamSynchronize(ctx->stream));
+  collect_timings(ctx);
+  if (!partial) sort_and_limit(plan, cols);
+  {
+    std::lock_guard<std::mutex> g(ctx->mu);
+    ctx->stats.rows_scanned += ss.rows;
+    ctx->stats.rows_selected += selected;
+    ctx->stats.groups_out += groups_out;
+  }
+  export_record_batch(cols, out);
+}
+
+}  // namespace prism

@@ -1,0 +1,190 @@
+// Device-side data descriptors and the host launch wrappers of every kernel.
+//
+// Layout recap.  A scan covers a list of segments (one per resident partition
+// chunk).  Rows are addressed by a "padded row id": tile * kTileRows + r, where a
+// tile never spans two segments.  Selection bitmaps hold one bit per padded row
+// id (64 words per tile); selection vectors hold padded row ids.
+#pragma once
+
+#include <cstdint>
+
+#include "common.hpp"
+#include "context.hpp"
+
+namespace prism {
+
+struct ScanSeg {
+  uint64_t rows;       // rows in this segment
+  uint64_t tile_base;  // first tile of this segment
+};
+
+struct ColPtr {
+  const void* values;        // fixed-width values, u32 dictionary codes, or i32 string offsets
+  const uint64_t* validity;  // Arrow validity bits, bit 0 = first row of the segment; nullptr = no NULLs
+  const uint8_t* bytes;      // string bytes (raw Utf8/Binary columns)
+};
+
+struct ScanDesc {
+  const ScanSeg* segs;  // device array
+  uint32_t n_segs;
+  uint64_t n_tiles;
+};
+
+// ---- predicates -----------------------------------------------------------
+
+enum CmpMask { kLt = 1, kEq = 2, kGt = 4 };  // which orderings satisfy the comparison
+
+// column <op> literal over a fixed-width column -> selection bits (TRUE rows) and/or
+// their count.  `bits` and `count` may each be nullptr.
+void launch_cmp_leaf(prism_gpu_ctx* ctx, const ScanDesc& sd, const ColPtr* col, int width, bool is_unsigned,
+                     int cmp_mask, int64_t literal, uint64_t* bits, unsigned long long* count);
+// bits = rows whose dictionary code c has lut[c] != 0 (and are not NULL).
+void launch_lut_leaf(prism_gpu_ctx* ctx, const ScanDesc& sd, const ColPtr* col, const uint8_t* lut, uint32_t lut_len,
+                     uint64_t* bits);
+// IS NULL / IS NOT NULL.
+void launch_null_leaf(prism_gpu_ctx* ctx, const ScanDesc& sd, const ColPtr* col, bool want_null, uint64_t* bits);
+
+// String predicates over raw (offsets + bytes) columns, one row per lane.
+enum StrPredKind { kStrCmp = 1, kStrLike = 2 };
+struct LikeToken {  // kind: 0 literal byte, 1 any one character, 2 any run
+  uint8_t kind;
+  uint8_t byte;
+};
+void launch_str_leaf(prism_gpu_ctx* ctx, const ScanDesc& sd, const ColPtr* col, int kind, int cmp_mask,
+                     const uint8_t* literal /*device*/, uint32_t literal_len, const LikeToken* tokens /*device*/,
+                     uint32_t n_tokens, bool negated, bool case_insensitive, uint64_t* bits);
+// LIKE '%needle%' as a byte-stream search over one segment's string buffer: coalesced
+// 16-byte loads, matches mapped back to rows through the offsets.  `bits` must be zeroed.
+void launch_contains_stream(prism_gpu_ctx* ctx, const ColPtr& col, uint64_t rows, uint64_t tile_base,
+                            const uint8_t* needle /*device*/, uint32_t needle_len, uint64_t* bits);
+// bits &= validity (per segment), or bits = validity & ~bits when `negate`.
+void launch_mask_validity(prism_gpu_ctx* ctx, const ScanDesc& sd, const ColPtr* col, bool negate, uint64_t* bits);
+
+void launch_bitmap_and(prism_gpu_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, uint64_t n_words);
+void launch_bitmap_or(prism_gpu_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, uint64_t n_words);
+void launch_bitmap_count(prism_gpu_ctx* ctx, const uint64_t* bits, uint64_t n_words, unsigned long long* count);
+
+// ---- selection-vector compaction -------------------------------------------
+// bits -> ascending padded row ids, in two calls: with selvec == nullptr it fills
+// tile_offsets (n_tiles + 1 u32: exclusive scan of the per-tile counts) and *total;
+// with selvec set it writes the row ids using those offsets.
+void launch_compact(prism_gpu_ctx* ctx, const uint64_t* bits, uint64_t n_tiles, uint32_t* tile_offsets,
+                    uint32_t* selvec, unsigned long long* total);
+
+// ---- aggregation -------------------------------------------------------------
+
+constexpr int kMaxKeys = 4;
+constexpr int kMaxVals = 16;
+constexpr int kMaxSlots = 24;
+
+struct KeySpec {
+  int32_t col;        // index into AggParams::cols rows
+  int32_t width;      // 2, 4, 8
+  int32_t is_unsigned;
+  int32_t date_bin;   // 1: value = bucket number of the timestamp
+  int64_t stride;     // date_bin stride (ms)
+  int64_t origin;     // date_bin origin (ms)
+  uint64_t magic;     // division by `stride` as multiply-high + shifts
+  int32_t magic_shift;
+  int32_t bit_pos;    // position of this field in the packed key
+  int64_t bias;       // field = value - bias
+  int32_t null_bit;   // bit set for a NULL key, -1 when the column has no NULLs
+  int32_t pad;
+};
+
+struct ValSpec {
+  int32_t col;
+  int32_t width;
+  int32_t is_unsigned;
+  int32_t is_float;  // values are f64 bit patterns (PARTIAL AVG sums)
+};
+
+enum SlotOp {
+  kSlotAddOne = 0,   // += 1 per row
+  kSlotAddValid = 1, // += 1 per non-NULL value
+  kSlotAddI64 = 2,   // += value (wrapping)
+  kSlotAddF64 = 3,   // += (double)value, or += value when the input is f64
+  kSlotMin = 4,
+  kSlotMax = 5
+};
+
+struct SlotSpec {
+  int32_t op;
+  int32_t val;  // index into vals, -1 for kSlotAddOne
+};
+
+enum RowMode { kRowsAll = 0, kRowsBitmap = 1, kRowsSelvec = 2 };
+
+constexpr uint64_t kEmptyKey = ~0ull;
+
+struct AggParams {
+  ScanDesc sd;
+  const ColPtr* cols;  // device: cols[c * n_segs + seg]
+  int32_t n_keys, n_vals, n_slots, row_mode;
+  KeySpec keys[kMaxKeys];
+  ValSpec vals[kMaxVals];
+  SlotSpec slots[kMaxSlots];
+  const uint64_t* sel_bits;
+  const uint32_t* selvec;
+  uint64_t n_sel;
+  // global table: dense (index = packed key) or open addressing on the packed key
+  int32_t dense;
+  int32_t lds_slots;    // power of two; 0 = no LDS pre-aggregation
+  uint64_t capacity;    // dense: number of entries; hash: power of two
+  uint64_t* g_keys;     // hash only: capacity + 1 entries (last = the all-ones key)
+  int64_t* g_state;     // n_slots arrays of (capacity + 1) entries
+  uint32_t* overflow;   // set to 1 when the hash table is full
+};
+
+// Ungrouped aggregates: out[n_slots] must hold the slot identities on entry.
+void launch_agg_global(prism_gpu_ctx* ctx, const AggParams& p, int64_t* out);
+// GROUP BY: accumulates into p.g_keys / p.g_state.
+void launch_group_by(prism_gpu_ctx* ctx, const AggParams& p, uint64_t algorithmic_bytes);
+// Second level of COUNT(DISTINCT x) GROUP BY k: every occupied entry of the
+// (k, x) set adds 1 (when its x field is not NULL) to group k of table `q`.
+struct DistinctFoldParams {
+  const uint64_t* set_keys;      // packed (k, x) keys, kEmptyKey = unused entry
+  uint64_t set_capacity;         // entries to visit
+  uint64_t set_special;          // index of the entry that stands for the all-ones key (~0 = none)
+  const int64_t* set_rowcount;   // slot 0 of the set table (tells whether the special entry is used)
+  int32_t x_bits;            // low bits holding x (including its NULL bit)
+  int32_t x_null_bit;        // -1 if x has no NULL bit
+  int32_t dense;
+  uint64_t capacity;
+  uint64_t* g_keys;
+  int64_t* g_state;          // slot 0 = existence count, slot 1 = distinct count
+  uint32_t* overflow;
+};
+void launch_distinct_fold(prism_gpu_ctx* ctx, const DistinctFoldParams& p);
+
+// Fills n entries with `value`.
+void launch_fill_i64(prism_gpu_ctx* ctx, int64_t* dst, uint64_t n, int64_t value);
+// Compacts the occupied entries of a table: out_keys[i], out_state[s * out_stride + i].
+void launch_emit(prism_gpu_ctx* ctx, bool dense, uint64_t capacity, const uint64_t* g_keys, const int64_t* g_state,
+                 int n_slots, uint64_t* out_keys, int64_t* out_state, uint64_t out_stride,
+                 unsigned long long* out_count);
+
+// ---- loader support ----------------------------------------------------------
+
+struct ColStats {
+  long long min;
+  long long max;
+  unsigned long long null_count;
+};
+// Folds min/max/null count of `rows` values into *stats (device; initialised by the caller).
+void launch_col_stats(prism_gpu_ctx* ctx, const void* values, const uint64_t* validity, int width, bool is_unsigned,
+                      uint64_t rows, ColStats* stats, hipStream_t stream);
+
+struct SynthColDev {
+  void* dst;
+  int32_t width;  // 2, 4, 8
+  int32_t kind;
+  int64_t p[4];
+  const uint32_t* cdf;  // device
+  uint32_t cdf_len;
+  uint64_t column_key;
+};
+void launch_synth(prism_gpu_ctx* ctx, const SynthColDev& col, uint64_t first_row, uint64_t n_rows,
+                  uint64_t total_rows);
+
+}  // namespace prism

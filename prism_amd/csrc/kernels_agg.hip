@@ -1,0 +1,452 @@
+// Aggregation kernels.
+//
+// GROUP BY keys are packed into one 64-bit word per row (each key column is biased
+// by its minimum and given just the bits its range needs, plus a NULL bit; a
+// date_bin key contributes its bucket number, computed with a multiply-high
+// division).  The packed key either indexes a dense table directly (small key
+// spaces) or is inserted into an open-addressing table in HBM with a 64-bit CAS.
+// In front of the HBM table every workgroup keeps an LDS-resident partial table:
+// rows update it with LDS atomics, and it is folded into the HBM table when it
+// fills up and at the end, so hot groups cost HBM one atomic per workgroup rather
+// than one per row.  Rows that find the LDS table full go straight to HBM, and a
+// workgroup whose keys do not repeat stops using LDS altogether.
+//
+// Aggregate functions are lowered by the planner to "slots": 8-byte accumulators
+// with one of six update rules (SlotOp).  Slot 0 always counts rows, which is also
+// how a dense table knows which entries exist.
+#include <algorithm>
+
+#include "device_utils.hpp"
+
+namespace prism {
+
+namespace {
+
+constexpr long long kI64Max = 0x7fffffffffffffffll;
+constexpr long long kI64Min = -kI64Max - 1;
+
+__device__ __forceinline__ long long slot_identity(int op) {
+  return op == kSlotMin ? kI64Max : (op == kSlotMax ? kI64Min : 0ll);
+}
+
+// floor(n / d) for the divisor described by (magic, shift); shift < 0 means d == 1.
+__device__ __forceinline__ uint64_t fast_div(uint64_t n, uint64_t magic, int shift) {
+  if (shift < 0) return n;
+  uint64_t q = __umul64hi(magic, n);
+  uint64_t t = ((n - q) >> 1) + q;
+  return t >> shift;
+}
+
+// Bucket number of a timestamp: DataFusion's date_bin rounds toward zero and then
+// steps one more stride down for timestamps before the origin.
+__device__ __forceinline__ long long bucket_number(long long ts, const KeySpec& k) {
+  long long d = (long long)((uint64_t)ts - (uint64_t)k.origin);
+  uint64_t a = d < 0 ? (0ull - (uint64_t)d) : (uint64_t)d;
+  long long q = (long long)fast_div(a, k.magic, k.magic_shift);
+  if (d < 0) q = -q - (k.stride > 1 ? 1 : 0);
+  return q;
+}
+
+struct RowVals {
+  long long v[kMaxVals];
+  uint32_t valid;  // bit j: value j is not NULL
+};
+
+__device__ __forceinline__ uint64_t pack_key(const AggParams& p, uint32_t seg, uint64_t row) {
+  uint64_t key = 0;
+  for (int i = 0; i < p.n_keys; ++i) {
+    const KeySpec& k = p.keys[i];
+    const ColPtr& c = p.cols[(uint64_t)k.col * p.sd.n_segs + seg];
+    if (k.null_bit >= 0 && !valid_at(c.validity, row)) { key |= 1ull << k.null_bit; continue; }
+    long long v = load_value(c.values, k.width, k.is_unsigned, row);
+    if (k.date_bin) v = bucket_number(v, k);
+    key |= ((uint64_t)v - (uint64_t)k.bias) << k.bit_pos;
+  }
+  return key;
+}
+
+__device__ __forceinline__ void load_vals(const AggParams& p, uint32_t seg, uint64_t row, RowVals& rv) {
+  rv.valid = 0;
+#pragma unroll
+  for (int j = 0; j < kMaxVals; ++j) {
+    if (j < p.n_vals) {
+      const ValSpec& vs = p.vals[j];
+      const ColPtr& c = p.cols[(uint64_t)vs.col * p.sd.n_segs + seg];
+      rv.v[j] = load_value(c.values, vs.width, vs.is_unsigned, row);
+      if (valid_at(c.validity, row)) rv.valid |= 1u << j;
+    }
+  }
+}
+
+// Contribution of one row to slot s: returns false when the row does not touch it.
+__device__ __forceinline__ bool slot_input(const AggParams& p, int s, const RowVals& rv, long long& out) {
+  const SlotSpec& sl = p.slots[s];
+  if (sl.op == kSlotAddOne) { out = 1; return true; }
+  if (!((rv.valid >> sl.val) & 1u)) return false;
+  long long v = 0;
+#pragma unroll
+  for (int j = 0; j < kMaxVals; ++j)
+    if (j == sl.val) v = rv.v[j];  // select chain: a runtime index would put rv.v in scratch memory
+  if (sl.op == kSlotAddValid) out = 1;
+  else if (sl.op == kSlotAddF64) out = p.vals[sl.val].is_float ? v : __double_as_longlong((double)v);
+  else out = v;
+  return true;
+}
+
+template <typename P>
+__device__ __forceinline__ void atomic_apply(P* addr, int op, long long x) {
+  if (op == kSlotMin) atomicMin((long long*)addr, x);
+  else if (op == kSlotMax) atomicMax((long long*)addr, x);
+  else if (op == kSlotAddF64) atomicAdd((double*)addr, __longlong_as_double(x));
+  else atomicAdd((unsigned long long*)addr, (unsigned long long)x);
+}
+
+// Entry of `key` in the HBM table, inserting it if absent; capacity (the extra
+// entry) for the all-ones key; ~0 when the table is full.
+__device__ __forceinline__ uint64_t global_entry(const AggParams& p, uint64_t key) {
+  if (p.dense) return key;
+  if (key == kEmptyKey) return p.capacity;
+  uint64_t mask = p.capacity - 1;
+  uint64_t h = hash64(key) & mask;
+  for (uint64_t probe = 0; probe < p.capacity; ++probe) {
+    unsigned long long k = p.g_keys[h];
+    if (k == key) return h;
+    if (k == kEmptyKey) {
+      unsigned long long old = atomicCAS((unsigned long long*)&p.g_keys[h], kEmptyKey, key);
+      if (old == kEmptyKey || old == key) return h;
+    }
+    h = (h + 1) & mask;
+  }
+  *p.overflow = 1u;
+  return ~0ull;
+}
+
+__device__ __forceinline__ void global_update(const AggParams& p, uint64_t key, const RowVals& rv) {
+  uint64_t e = global_entry(p, key);
+  if (e == ~0ull) return;
+  for (int s = 0; s < p.n_slots; ++s) {
+    long long x;
+    if (slot_input(p, s, rv, x)) atomic_apply(&p.g_state[(uint64_t)s * (p.capacity + 1) + e], p.slots[s].op, x);
+  }
+}
+
+struct LdsTable {
+  unsigned long long* keys;  // [S]
+  long long* state;          // [n_slots][S]
+  int S;
+};
+
+__device__ __forceinline__ int lds_entry(const LdsTable& t, uint64_t key, int* n_entries) {
+  int mask = t.S - 1;
+  int h = (int)(hash64(key) >> 20) & mask;
+  for (int probe = 0; probe < 16; ++probe) {
+    unsigned long long k = t.keys[h];
+    if (k == key) return h;
+    if (k == kEmptyKey) {
+      unsigned long long old = atomicCAS(&t.keys[h], kEmptyKey, (unsigned long long)key);
+      if (old == kEmptyKey) { atomicAdd(n_entries, 1); return h; }
+      if (old == key) return h;
+    }
+    h = (h + 1) & mask;
+  }
+  return -1;
+}
+
+__device__ __forceinline__ void process_row(const AggParams& p, const LdsTable& t, bool use_lds, int* n_entries,
+                                            uint32_t seg, uint64_t row) {
+  uint64_t key = pack_key(p, seg, row);
+  RowVals rv;
+  load_vals(p, seg, row, rv);
+  int e = (use_lds && key != kEmptyKey) ? lds_entry(t, key, n_entries) : -1;
+  if (e < 0) { global_update(p, key, rv); return; }
+  for (int s = 0; s < p.n_slots; ++s) {
+    long long x;
+    if (slot_input(p, s, rv, x)) atomic_apply(&t.state[s * t.S + e], p.slots[s].op, x);
+  }
+}
+
+__device__ __forceinline__ void lds_clear(const AggParams& p, const LdsTable& t) {
+  for (int i = threadIdx.x; i < t.S; i += blockDim.x) {
+    t.keys[i] = kEmptyKey;
+    for (int s = 0; s < p.n_slots; ++s) t.state[s * t.S + i] = slot_identity(p.slots[s].op);
+  }
+}
+
+// Folds the LDS table into the HBM table and empties it.  Block-wide; the caller
+// brackets it with barriers.
+__device__ __forceinline__ void lds_flush(const AggParams& p, const LdsTable& t) {
+  for (int i = threadIdx.x; i < t.S; i += blockDim.x) {
+    unsigned long long key = t.keys[i];
+    if (key == kEmptyKey) continue;
+    uint64_t e = global_entry(p, key);
+    for (int s = 0; s < p.n_slots; ++s) {
+      int op = p.slots[s].op;
+      long long v = t.state[s * t.S + i];
+      if (e != ~0ull && v != slot_identity(op)) atomic_apply(&p.g_state[(uint64_t)s * (p.capacity + 1) + e], op, v);
+      t.state[s * t.S + i] = slot_identity(op);
+    }
+    t.keys[i] = kEmptyKey;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_group_by(AggParams p) {
+  extern __shared__ unsigned long long lds_raw[];
+  __shared__ int n_entries;
+  __shared__ int bypass;
+  LdsTable t;
+  t.S = p.lds_slots;
+  t.keys = lds_raw;
+  t.state = (long long*)(lds_raw + t.S);
+  bool have_lds = t.S > 0;
+  if (threadIdx.x == 0) { n_entries = 0; bypass = have_lds ? 0 : 1; }
+  if (have_lds) lds_clear(p, t);
+  __syncthreads();
+
+  if (p.row_mode == kRowsSelvec) {
+    uint64_t per = ceil_div(p.n_sel, (uint64_t)gridDim.x);
+    per = ceil_div(per, (uint64_t)kBlock) * kBlock;
+    uint64_t i0 = per * blockIdx.x, i1 = i0 + per < p.n_sel ? i0 + per : p.n_sel;
+    for (uint64_t base = i0; base < i1; base += kBlock) {
+      uint64_t i = base + threadIdx.x;
+      bool use_lds = bypass == 0;
+      if (i < i1) {
+        uint64_t pid = p.selvec[i];
+        uint64_t tile = pid / kTileRows;
+        uint32_t seg = find_seg(p.sd, tile);
+        process_row(p, t, use_lds, &n_entries, seg, pid - p.sd.segs[seg].tile_base * kTileRows);
+      }
+      if (have_lds && ((base - i0) / kBlock) % 16 == 15) {  // block uniform
+        __syncthreads();
+        int n = n_entries;
+        __syncthreads();
+        if (n > t.S / 2) {
+          lds_flush(p, t);
+          if (threadIdx.x == 0) { if ((uint64_t)n * 4 > 16ull * kBlock) bypass = 1; n_entries = 0; }
+          __syncthreads();
+        }
+      }
+    }
+  } else {
+    uint64_t per = ceil_div(p.sd.n_tiles, (uint64_t)gridDim.x);
+    uint64_t t0 = per * blockIdx.x, t1 = t0 + per < p.sd.n_tiles ? t0 + per : p.sd.n_tiles;
+    uint64_t rows_since_flush = 0;
+    for (uint64_t tile = t0; tile < t1; ++tile) {
+      uint32_t seg = find_seg(p.sd, tile);
+      uint64_t seg_rows = p.sd.segs[seg].rows;
+      uint64_t tile_row0 = (tile - p.sd.segs[seg].tile_base) * kTileRows;
+      bool use_lds = bypass == 0;
+      for (uint32_t it = 0; it < kTileRows / (kBlock * 2); ++it) {
+        uint64_t in_tile = (uint64_t)it * (kBlock * 2) + (uint64_t)threadIdx.x * 2;
+        uint64_t r = tile_row0 + in_tile;
+        uint32_t sel = 3;
+        if (p.row_mode == kRowsBitmap) {
+          uint64_t pid = tile * kTileRows + in_tile;
+          sel = (uint32_t)(p.sel_bits[pid >> 6] >> (pid & 63)) & 3u;
+        }
+        if ((sel & 1u) && r < seg_rows) process_row(p, t, use_lds, &n_entries, seg, r);
+        if ((sel & 2u) && r + 1 < seg_rows) process_row(p, t, use_lds, &n_entries, seg, r + 1);
+      }
+      rows_since_flush += kTileRows;
+      if (have_lds) {
+        __syncthreads();
+        int n = n_entries;
+        __syncthreads();
+        if (n > t.S / 2) {
+          lds_flush(p, t);
+          if (threadIdx.x == 0) {
+            // keys that hardly repeat gain nothing from LDS: go straight to HBM from here on
+            if ((uint64_t)n * 4 > rows_since_flush) bypass = 1;
+            n_entries = 0;
+          }
+          rows_since_flush = 0;
+          __syncthreads();
+        }
+      }
+    }
+  }
+  if (have_lds) {
+    __syncthreads();
+    lds_flush(p, t);
+  }
+}
+
+// ---- ungrouped aggregates -------------------------------------------------------
+
+__device__ __forceinline__ long long combine(int op, long long a, long long b) {
+  if (op == kSlotMin) return a < b ? a : b;
+  if (op == kSlotMax) return a > b ? a : b;
+  if (op == kSlotAddF64) return __double_as_longlong(__longlong_as_double(a) + __longlong_as_double(b));
+  return (long long)((unsigned long long)a + (unsigned long long)b);
+}
+
+__global__ __launch_bounds__(kBlock) void k_agg_global(AggParams p, long long* out) {
+  long long acc[kMaxSlots];
+#pragma unroll
+  for (int s = 0; s < kMaxSlots; ++s) acc[s] = s < p.n_slots ? slot_identity(p.slots[s].op) : 0;
+
+  auto row = [&](uint32_t seg, uint64_t r) {
+    RowVals rv;
+    load_vals(p, seg, r, rv);
+#pragma unroll
+    for (int s = 0; s < kMaxSlots; ++s) {
+      if (s < p.n_slots) {
+        long long x;
+        if (slot_input(p, s, rv, x)) acc[s] = combine(p.slots[s].op, acc[s], x);
+      }
+    }
+  };
+
+  if (p.row_mode == kRowsSelvec) {
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < p.n_sel; i += (uint64_t)gridDim.x * kBlock) {
+      uint64_t pid = p.selvec[i];
+      uint32_t seg = find_seg(p.sd, pid / kTileRows);
+      row(seg, pid - p.sd.segs[seg].tile_base * kTileRows);
+    }
+  } else {
+    for (uint64_t tile = blockIdx.x; tile < p.sd.n_tiles; tile += gridDim.x) {
+      uint32_t seg = find_seg(p.sd, tile);
+      uint64_t seg_rows = p.sd.segs[seg].rows;
+      uint64_t tile_row0 = (tile - p.sd.segs[seg].tile_base) * kTileRows;
+      for (uint32_t it = 0; it < kTileRows / (kBlock * 2); ++it) {
+        uint64_t in_tile = (uint64_t)it * (kBlock * 2) + (uint64_t)threadIdx.x * 2;
+        uint64_t r = tile_row0 + in_tile;
+        uint32_t sel = 3;
+        if (p.row_mode == kRowsBitmap) {
+          uint64_t pid = tile * kTileRows + in_tile;
+          sel = (uint32_t)(p.sel_bits[pid >> 6] >> (pid & 63)) & 3u;
+        }
+        if ((sel & 1u) && r < seg_rows) row(seg, r);
+        if ((sel & 2u) && r + 1 < seg_rows) row(seg, r + 1);
+      }
+    }
+  }
+
+  __shared__ long long partial[kBlock / 64][kMaxSlots];
+#pragma unroll
+  for (int s = 0; s < kMaxSlots; ++s) {
+    if (s < p.n_slots) {
+      int op = p.slots[s].op;
+      long long v = acc[s];
+      if (op == kSlotMin) v = wave_min_i64(v);
+      else if (op == kSlotMax) v = wave_max_i64(v);
+      else if (op == kSlotAddF64) v = __double_as_longlong(wave_sum_f64(__longlong_as_double(v)));
+      else v = (long long)wave_sum_u64((unsigned long long)v);
+      if ((threadIdx.x & 63) == 0) partial[threadIdx.x >> 6][s] = v;
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < p.n_slots) {
+    int s = threadIdx.x, op = p.slots[s].op;
+    long long v = partial[0][s];
+    for (int w = 1; w < (int)(kBlock / 64); ++w) v = combine(op, v, partial[w][s]);
+    if (v != slot_identity(op)) atomic_apply(&out[s], op, v);
+  }
+}
+
+// ---- COUNT(DISTINCT) second level ----------------------------------------------------
+
+__global__ __launch_bounds__(kBlock) void k_distinct_fold(DistinctFoldParams q) {
+  AggParams p;  // only the table fields are used by global_entry
+  p.dense = q.dense;
+  p.capacity = q.capacity;
+  p.g_keys = q.g_keys;
+  p.overflow = q.overflow;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < q.set_capacity; i += (uint64_t)gridDim.x * kBlock) {
+    uint64_t key;
+    if (i == q.set_special) {
+      if (q.set_rowcount[i] == 0) continue;
+      key = kEmptyKey;
+    } else {
+      key = q.set_keys[i];
+      if (key == kEmptyKey) continue;
+    }
+    uint64_t k = q.x_bits >= 64 ? 0ull : key >> q.x_bits;
+    bool x_null = q.x_null_bit >= 0 && ((key >> q.x_null_bit) & 1ull);
+    uint64_t e = global_entry(p, k);
+    if (e == ~0ull) continue;
+    atomicAdd((unsigned long long*)&q.g_state[e], 1ull);
+    if (!x_null) atomicAdd((unsigned long long*)&q.g_state[(q.capacity + 1) + e], 1ull);
+  }
+}
+
+// ---- table maintenance --------------------------------------------------------------
+
+__global__ __launch_bounds__(kBlock) void k_fill_i64(long long* dst, uint64_t n, long long value) {
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) dst[i] = value;
+}
+
+// Occupied entries: dense -> row count (slot 0) non-zero; hash -> key present, and
+// the extra entry for the all-ones key when its row count is non-zero.
+__device__ __forceinline__ bool occupied(bool dense, uint64_t capacity, const uint64_t* g_keys, const long long* state0,
+                                         uint64_t i) {
+  if (dense || i == capacity) return state0[i] != 0;
+  return g_keys[i] != kEmptyKey;
+}
+
+__global__ __launch_bounds__(kBlock) void k_emit(int dense, uint64_t capacity, const uint64_t* g_keys,
+                                                const long long* g_state, int n_slots, uint64_t* out_keys,
+                                                long long* out_state, uint64_t out_stride,
+                                                unsigned long long* out_count) {
+  uint64_t n = dense ? capacity : capacity + 1;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+    if (!occupied(dense != 0, capacity, g_keys, g_state, i)) continue;
+    unsigned long long pos = atomicAdd(out_count, 1ull);
+    if (out_keys == nullptr) continue;  // counting pass
+    out_keys[pos] = dense ? i : (i == capacity ? kEmptyKey : g_keys[i]);
+    for (int s = 0; s < n_slots; ++s) out_state[(uint64_t)s * out_stride + pos] = g_state[(uint64_t)s * (capacity + 1) + i];
+  }
+}
+
+uint32_t stream_grid(prism_gpu_ctx* ctx, uint64_t items) {
+  uint64_t blocks = ceil_div(items, kBlock);
+  uint64_t cap = (uint64_t)ctx->n_cus * 8;
+  return (uint32_t)std::max<uint64_t>(1, std::min(blocks, cap));
+}
+
+}  // namespace
+
+void launch_agg_global(prism_gpu_ctx* ctx, const AggParams& p, int64_t* out) {
+  uint64_t work = p.row_mode == kRowsSelvec ? ceil_div(p.n_sel, kBlock) : p.sd.n_tiles;
+  if (work == 0) return;
+  uint32_t grid = (uint32_t)std::min<uint64_t>(work, (uint64_t)ctx->n_cus * 8);
+  k_agg_global<<<dim3(grid), dim3(kBlock), 0, ctx->stream>>>(p, (long long*)out);
+  PRISM_HIP(hipGetLastError());
+}
+
+void launch_group_by(prism_gpu_ctx* ctx, const AggParams& p, uint64_t algorithmic_bytes) {
+  uint64_t work = p.row_mode == kRowsSelvec ? ceil_div(p.n_sel, (uint64_t)kBlock * 16) : p.sd.n_tiles;
+  if (work == 0) return;
+  size_t lds = (size_t)p.lds_slots * 8 * (1 + p.n_slots);
+  // enough workgroups to fill every CU several times over, but long contiguous row
+  // ranges per workgroup so that its LDS table sees each group many times
+  uint32_t grid = (uint32_t)std::min<uint64_t>(work, (uint64_t)ctx->n_cus * 8);
+  KernelTimer timer(ctx, "group_by", algorithmic_bytes);
+  k_group_by<<<dim3(grid), dim3(kBlock), lds, ctx->stream>>>(p);
+  PRISM_HIP(hipGetLastError());
+}
+
+void launch_distinct_fold(prism_gpu_ctx* ctx, const DistinctFoldParams& p) {
+  uint32_t grid = stream_grid(ctx, p.set_capacity);
+  KernelTimer timer(ctx, "distinct_fold", p.set_capacity * 8);
+  k_distinct_fold<<<dim3(grid), dim3(kBlock), 0, ctx->stream>>>(p);
+  PRISM_HIP(hipGetLastError());
+}
+
+void launch_fill_i64(prism_gpu_ctx* ctx, int64_t* dst, uint64_t n, int64_t value) {
+  if (n == 0) return;
+  k_fill_i64<<<dim3(stream_grid(ctx, n)), dim3(kBlock), 0, ctx->stream>>>((long long*)dst, n, value);
+  PRISM_HIP(hipGetLastError());
+}
+
+void launch_emit(prism_gpu_ctx* ctx, bool dense, uint64_t capacity, const uint64_t* g_keys, const int64_t* g_state,
+                 int n_slots, uint64_t* out_keys, int64_t* out_state, uint64_t out_stride,
+                 unsigned long long* out_count) {
+  uint64_t n = dense ? capacity : capacity + 1;
+  if (n == 0) return;
+  k_emit<<<dim3(stream_grid(ctx, n)), dim3(kBlock), 0, ctx->stream>>>(dense ? 1 : 0, capacity, g_keys,
+                                                                    (const long long*)g_state, n_slots, out_keys,
+                                                                    (long long*)out_state, out_stride, out_count);
+  PRISM_HIP(hipGetLastError());
+}
+
+}  // namespace prism

@@ -1,0 +1,360 @@
+// Predicate evaluation kernels: each leaf of the WHERE tree becomes a bitmap of
+// the rows where it is TRUE (NULL rows are never TRUE, which is all FilterExec
+// needs once NOTs have been pushed down to the leaves); AND / OR are word-wise.
+//
+// Fixed-width leaves stream the column with 16-byte loads per lane, so a wave
+// instruction moves 1 KiB; result bits are packed to bytes with cross-lane
+// shuffles and stored as bytes of the little-endian bitmap words.
+#include "device_utils.hpp"
+
+namespace prism {
+
+namespace {
+
+inline uint32_t leaf_grid(prism_gpu_ctx* ctx, uint64_t n_tiles) {
+  uint64_t cap = (uint64_t)ctx->n_cus * 8;
+  return (uint32_t)(n_tiles < cap ? (n_tiles ? n_tiles : 1) : cap);
+}
+
+// Adds each block's count with one atomic.
+__device__ __forceinline__ void block_count_add(unsigned long long local, unsigned long long* count) {
+  __shared__ unsigned long long partial[kBlock / 64];
+  unsigned long long w = wave_sum_u64(local);
+  if ((threadIdx.x & 63) == 0) partial[threadIdx.x >> 6] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int i = 0; i < (int)(kBlock / 64); ++i) t += partial[i];
+    if (t) atomicAdd(count, t);
+  }
+}
+
+// Packs the V result bits of every lane into bitmap bytes.  `pid` is the padded
+// row id of the lane's first row (a multiple of V).  All lanes must call.
+template <int V>
+__device__ __forceinline__ void store_bits(uint64_t* bits, uint64_t pid, uint32_t m) {
+  uint8_t* bytes = (uint8_t*)bits;
+  if (V == 8) {
+    bytes[pid >> 3] = (uint8_t)m;
+  } else if (V == 4) {
+    uint32_t o = __shfl_down(m, 1, 64);
+    if ((threadIdx.x & 1) == 0) bytes[pid >> 3] = (uint8_t)(m | (o << 4));
+  } else {  // V == 2
+    uint32_t o1 = __shfl_down(m, 1, 64), o2 = __shfl_down(m, 2, 64), o3 = __shfl_down(m, 3, 64);
+    if ((threadIdx.x & 3) == 0) bytes[pid >> 3] = (uint8_t)(m | (o1 << 2) | (o2 << 4) | (o3 << 6));
+  }
+}
+
+template <typename T>
+struct Vec16 {
+  static constexpr int V = 16 / sizeof(T);
+  T e[V];
+};
+
+template <typename T>
+__device__ __forceinline__ Vec16<T> load16(const T* p) {
+  uint4 raw = *(const uint4*)p;
+  Vec16<T> v;
+  __builtin_memcpy(&v, &raw, 16);
+  return v;
+}
+
+// One tile of a fixed-width leaf.  FULL: the tile lies wholly inside the segment,
+// so every load is unconditional and the compiler can batch them.
+template <typename T, bool FULL, typename Pred>
+__device__ __forceinline__ unsigned long long leaf_tile(const T* vals, const uint64_t* validity, uint64_t seg_rows,
+                                                        uint64_t tile_row0, uint64_t tile, Pred pred, uint64_t* bits) {
+  constexpr int V = 16 / sizeof(T);
+  constexpr int kRowsPerIter = kBlock * V;
+  constexpr int kIters = kTileRows / kRowsPerIter;
+  unsigned long long local = 0;
+#pragma unroll
+  for (int it = 0; it < kIters; ++it) {
+    uint64_t in_tile = (uint64_t)it * kRowsPerIter + (uint64_t)threadIdx.x * V;
+    uint64_t r = tile_row0 + in_tile;
+    uint32_t m = 0;
+    if (FULL || r < seg_rows) {
+      Vec16<T> v = load16<T>(vals + r);
+#pragma unroll
+      for (int j = 0; j < V; ++j) m |= (pred(v.e[j]) ? 1u : 0u) << j;
+      if (!FULL) {
+        uint64_t left = seg_rows - r;
+        if (left < (uint64_t)V) m &= (1u << left) - 1u;
+      }
+      if (validity) m &= (uint32_t)((validity[r >> 6] >> (r & 63)) & ((1u << V) - 1u));
+    }
+    local += __popc(m);
+    if (bits) store_bits<V>(bits, tile * kTileRows + in_tile, m);
+  }
+  return local;
+}
+
+template <typename T, typename Pred>
+__device__ __forceinline__ void leaf_body(const ScanDesc& sd, const ColPtr* col, Pred pred, uint64_t* bits,
+                                          unsigned long long* count) {
+  unsigned long long local = 0;
+  for (uint64_t tile = blockIdx.x; tile < sd.n_tiles; tile += gridDim.x) {
+    uint32_t s = find_seg(sd, tile);
+    uint64_t seg_rows = sd.segs[s].rows;
+    uint64_t tile_row0 = (tile - sd.segs[s].tile_base) * kTileRows;
+    const T* vals = (const T*)col[s].values;
+    const uint64_t* validity = col[s].validity;
+    if (tile_row0 + kTileRows <= seg_rows)
+      local += leaf_tile<T, true>(vals, validity, seg_rows, tile_row0, tile, pred, bits);
+    else
+      local += leaf_tile<T, false>(vals, validity, seg_rows, tile_row0, tile, pred, bits);
+  }
+  if (count) block_count_add(local, count);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_cmp_leaf(ScanDesc sd, const ColPtr* col, int cmp_mask, long long lit,
+                                                    uint64_t* bits, unsigned long long* count) {
+  const bool want_lt = cmp_mask & kLt, want_eq = cmp_mask & kEq, want_gt = cmp_mask & kGt;
+  leaf_body<T>(
+      sd, col,
+      [=](T x) {
+        long long v = (long long)x;
+        return (v < lit && want_lt) || (v == lit && want_eq) || (v > lit && want_gt);
+      },
+      bits, count);
+}
+
+__global__ __launch_bounds__(kBlock) void k_lut_leaf(ScanDesc sd, const ColPtr* col, const uint8_t* lut,
+                                                    uint32_t lut_len, uint64_t* bits) {
+  leaf_body<uint32_t>(
+      sd, col, [=](uint32_t code) { return code < lut_len && lut[code] != 0; }, bits, nullptr);
+}
+
+// IS [NOT] NULL, and validity masking of a bitmap: word granular, 64 words per tile.
+// mode 0: bits = NULL rows; 1: bits = non-NULL rows; 2: bits &= valid; 3: bits = valid & ~bits.
+__global__ __launch_bounds__(kBlock) void k_validity(ScanDesc sd, const ColPtr* col, int mode, uint64_t* bits) {
+  uint64_t n_words = sd.n_tiles * kTileWords;
+  for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
+    uint64_t tile = w / kTileWords;
+    uint32_t s = find_seg(sd, tile);
+    uint64_t seg_rows = sd.segs[s].rows;
+    uint64_t lw = w - sd.segs[s].tile_base * kTileWords;  // word index inside the segment
+    uint64_t first = lw * 64;
+    uint64_t exist = first >= seg_rows ? 0ull : (seg_rows - first >= 64 ? ~0ull : ((1ull << (seg_rows - first)) - 1ull));
+    uint64_t valid = exist;
+    if (col[s].validity && exist) valid &= col[s].validity[lw];
+    uint64_t out;
+    if (mode == 0) out = exist & ~valid;
+    else if (mode == 1) out = valid;
+    else if (mode == 2) out = bits[w] & valid;
+    else out = valid & ~bits[w];
+    bits[w] = out;
+  }
+}
+
+// ---- raw string predicates, one row per lane ---------------------------------
+
+__device__ __forceinline__ uint8_t fold_ascii(uint8_t c, bool ci) {
+  return (ci && c >= 'A' && c <= 'Z') ? (uint8_t)(c + 32) : c;
+}
+
+__device__ __forceinline__ uint32_t utf8_step(const uint8_t* s, uint32_t i, uint32_t n) {
+  uint8_t c = s[i];
+  uint32_t l = c < 0x80 ? 1u : (c >> 5) == 6 ? 2u : (c >> 4) == 14 ? 3u : (c >> 3) == 30 ? 4u : 1u;
+  return l < n - i ? l : n - i;
+}
+
+// Glob-style matcher with one backtrack point: the same algorithm SQL LIKE needs
+// for '%' (any run) and '_' (one character).
+__device__ bool like_match(const LikeToken* t, uint32_t nt, const uint8_t* s, uint32_t n, bool ci) {
+  uint32_t si = 0, ti = 0, star_t = 0xffffffffu, star_s = 0;
+  while (si < n) {
+    if (ti < nt && t[ti].kind == 0 && fold_ascii(t[ti].byte, ci) == fold_ascii(s[si], ci)) { ++si; ++ti; }
+    else if (ti < nt && t[ti].kind == 1) { si += utf8_step(s, si, n); ++ti; }
+    else if (ti < nt && t[ti].kind == 2) { star_t = ti++; star_s = si; }
+    else if (star_t != 0xffffffffu) { ti = star_t + 1; star_s += utf8_step(s, star_s, n); si = star_s; }
+    else return false;
+  }
+  while (ti < nt && t[ti].kind == 2) ++ti;
+  return ti == nt;
+}
+
+__global__ __launch_bounds__(kBlock) void k_str_leaf(ScanDesc sd, const ColPtr* col, int kind, int cmp_mask,
+                                                    const uint8_t* lit, uint32_t lit_len, const LikeToken* tokens,
+                                                    uint32_t n_tokens, int negated, int ci, uint64_t* bits) {
+  for (uint64_t tile = blockIdx.x; tile < sd.n_tiles; tile += gridDim.x) {
+    uint32_t s = find_seg(sd, tile);
+    uint64_t seg_rows = sd.segs[s].rows;
+    uint64_t tile_row0 = (tile - sd.segs[s].tile_base) * kTileRows;
+    const int32_t* off = (const int32_t*)col[s].values;
+    const uint8_t* bytes = col[s].bytes;
+    const uint64_t* validity = col[s].validity;
+    for (uint32_t it = 0; it < kTileRows / kBlock; ++it) {
+      uint64_t r = tile_row0 + (uint64_t)it * kBlock + threadIdx.x;
+      bool t = false;
+      if (r < seg_rows && valid_at(validity, r)) {
+        uint32_t b = (uint32_t)off[r], e = (uint32_t)off[r + 1];
+        const uint8_t* p = bytes + b;
+        uint32_t n = e - b;
+        if (kind == kStrCmp) {
+          uint32_t m = n < lit_len ? n : lit_len;
+          int c = 0;
+          for (uint32_t i = 0; i < m && c == 0; ++i) c = (int)p[i] - (int)lit[i];
+          if (c == 0) c = n < lit_len ? -1 : (n > lit_len ? 1 : 0);
+          t = (c < 0 && (cmp_mask & kLt)) || (c == 0 && (cmp_mask & kEq)) || (c > 0 && (cmp_mask & kGt));
+        } else {
+          t = like_match(tokens, n_tokens, p, n, ci != 0);
+          if (negated) t = !t;
+        }
+      }
+      unsigned long long word = __ballot(t);
+      if ((threadIdx.x & 63) == 0) bits[tile * kTileWords + it * (kBlock / 64) + (threadIdx.x >> 6)] = word;
+    }
+  }
+}
+
+// ---- LIKE '%needle%' as a stream search -----------------------------------------
+//
+// Every lane owns 16 consecutive bytes of the segment's string buffer and tests the
+// 16 start positions in it against the first (up to four) needle bytes with
+// byte-aligned dword extracts; survivors are verified byte by byte, located in the
+// offsets array by binary search, and recorded with an atomic OR.  The buffer is
+// read once, fully coalesced, whatever the string lengths are.
+__global__ __launch_bounds__(kBlock) void k_contains_stream(const int32_t* off, const uint8_t* bytes, uint64_t rows,
+                                                           uint64_t total_bytes, uint64_t tile_base,
+                                                           const uint8_t* needle, uint32_t L, uint64_t* bits) {
+  const uint32_t k = L < 4 ? L : 4;
+  uint32_t first = 0;
+  for (uint32_t i = 0; i < k; ++i) first |= (uint32_t)needle[i] << (8 * i);
+  const uint32_t nmask = k == 4 ? 0xffffffffu : ((1u << (8 * k)) - 1u);
+  const uint64_t n_chunks = (total_bytes + kBlock * 16 - 1) / (kBlock * 16);
+  for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    uint64_t p = chunk * (kBlock * 16) + (uint64_t)threadIdx.x * 16;
+    if (p >= total_bytes) continue;
+    // the buffer is padded by the loader, so these 20 bytes are always readable
+    uint4 own = *(const uint4*)(bytes + p);
+    uint32_t next = *(const uint32_t*)(bytes + p + 16);
+    uint32_t d[5] = {own.x, own.y, own.z, own.w, next};
+    uint32_t cand = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      uint32_t w = __builtin_amdgcn_alignbyte(d[(j >> 2) + 1], d[j >> 2], j & 3);
+      cand |= (((w & nmask) == first) ? 1u : 0u) << j;
+    }
+    while (cand) {
+      int j = __ffs(cand) - 1;
+      cand &= cand - 1;
+      uint64_t pos = p + j;
+      if (pos + L > total_bytes) continue;
+      bool ok = true;
+      for (uint32_t i = 4; i < L && ok; ++i) ok = bytes[pos + i] == needle[i];
+      if (!ok) continue;
+      // row with off[row] <= pos < off[row + 1]
+      uint64_t lo = 0, hi = rows;
+      while (hi - lo > 1) {
+        uint64_t mid = (lo + hi) >> 1;
+        if ((uint64_t)(uint32_t)off[mid] <= pos) lo = mid; else hi = mid;
+      }
+      if (pos + L <= (uint64_t)(uint32_t)off[lo + 1] && (uint64_t)(uint32_t)off[lo] <= pos) {
+        uint64_t pid = tile_base * kTileRows + lo;
+        atomicOr((unsigned long long*)&bits[pid >> 6], 1ull << (pid & 63));
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_bitmap_binary(const uint64_t* a, const uint64_t* b, uint64_t* out,
+                                                         uint64_t n, int is_or) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    out[i] = is_or ? (a[i] | b[i]) : (a[i] & b[i]);
+}
+
+__global__ __launch_bounds__(kBlock) void k_bitmap_count(const uint64_t* bits, uint64_t n, unsigned long long* count) {
+  unsigned long long local = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    local += __popcll(bits[i]);
+  block_count_add(local, count);
+}
+
+}  // namespace
+
+void launch_cmp_leaf(prism_gpu_ctx* ctx, const ScanDesc& sd, const ColPtr* col, int width, bool is_unsigned,
+                     int cmp_mask, int64_t literal, uint64_t* bits, unsigned long long* count) {
+  if (sd.n_tiles == 0) return;
+  dim3 grid(leaf_grid(ctx, sd.n_tiles)), block(kBlock);
+  if (width == 2 && !is_unsigned) k_cmp_leaf<int16_t><<<grid, block, 0, ctx->stream>>>(sd, col, cmp_mask, literal, bits, count);
+  else if (width == 2) k_cmp_leaf<uint16_t><<<grid, block, 0, ctx->stream>>>(sd, col, cmp_mask, literal, bits, count);
+  else if (width == 4 && !is_unsigned) k_cmp_leaf<int32_t><<<grid, block, 0, ctx->stream>>>(sd, col, cmp_mask, literal, bits, count);
+  else if (width == 4) k_cmp_leaf<uint32_t><<<grid, block, 0, ctx->stream>>>(sd, col, cmp_mask, literal, bits, count);
+  else if (width == 8 && !is_unsigned) k_cmp_leaf<int64_t><<<grid, block, 0, ctx->stream>>>(sd, col, cmp_mask, literal, bits, count);
+  else fail(PRISM_GPU_EUNSUPPORTED, "comparison on this column type is not supported");
+  PRISM_HIP(hipGetLastError());
+}
+
+void launch_lut_leaf(prism_gpu_ctx* ctx, const ScanDesc& sd, const ColPtr* col, const uint8_t* lut, uint32_t lut_len,
+                     uint64_t* bits) {
+  if (sd.n_tiles == 0) return;
+  k_lut_leaf<<<dim3(leaf_grid(ctx, sd.n_tiles)), dim3(kBlock), 0, ctx->stream>>>(sd, col, lut, lut_len, bits);
+  PRISM_HIP(hipGetLastError());
+}
+
+void launch_null_leaf(prism_gpu_ctx* ctx, const ScanDesc& sd, const ColPtr* col, bool want_null, uint64_t* bits) {
+  if (sd.n_tiles == 0) return;
+  uint64_t blocks = ceil_div(sd.n_tiles * kTileWords, kBlock);
+  uint32_t grid = (uint32_t)std::min<uint64_t>(blocks, (uint64_t)ctx->n_cus * 8);
+  k_validity<<<dim3(grid), dim3(kBlock), 0, ctx->stream>>>(sd, col, want_null ? 0 : 1, bits);
+  PRISM_HIP(hipGetLastError());
+}
+
+void launch_mask_validity(prism_gpu_ctx* ctx, const ScanDesc& sd, const ColPtr* col, bool negate, uint64_t* bits) {
+  if (sd.n_tiles == 0) return;
+  uint64_t blocks = ceil_div(sd.n_tiles * kTileWords, kBlock);
+  uint32_t grid = (uint32_t)std::min<uint64_t>(blocks, (uint64_t)ctx->n_cus * 8);
+  k_validity<<<dim3(grid), dim3(kBlock), 0, ctx->stream>>>(sd, col, negate ? 3 : 2, bits);
+  PRISM_HIP(hipGetLastError());
+}
+
+void launch_str_leaf(prism_gpu_ctx* ctx, const ScanDesc& sd, const ColPtr* col, int kind, int cmp_mask,
+                     const uint8_t* literal, uint32_t literal_len, const LikeToken* tokens, uint32_t n_tokens,
+                     bool negated, bool case_insensitive, uint64_t* bits) {
+  if (sd.n_tiles == 0) return;
+  k_str_leaf<<<dim3(leaf_grid(ctx, sd.n_tiles)), dim3(kBlock), 0, ctx->stream>>>(
+      sd, col, kind, cmp_mask, literal, literal_len, tokens, n_tokens, negated ? 1 : 0, case_insensitive ? 1 : 0, bits);
+  PRISM_HIP(hipGetLastError());
+}
+
+void launch_contains_stream(prism_gpu_ctx* ctx, const ColPtr& col, uint64_t rows, uint64_t tile_base,
+                            const uint8_t* needle, uint32_t needle_len, uint64_t* bits) {
+  if (rows == 0) return;
+  // total bytes = last offset; the host knows it, but reading it here keeps the call
+  // signature small: offsets are rebased to start at 0 by the loader.
+  int32_t last = 0;
+  PRISM_HIP(hipMemcpyAsync(&last, (const int32_t*)col.values + rows, 4, hipMemcpyDeviceToHost, ctx->stream));
+  PRISM_HIP(hipStreamSynchronize(ctx->stream));
+  uint64_t total = (uint64_t)(uint32_t)last;
+  if (total == 0) return;
+  uint64_t chunks = ceil_div(total, (uint64_t)kBlock * 16);
+  uint32_t grid = (uint32_t)std::min<uint64_t>(chunks, (uint64_t)ctx->n_cus * 16);
+  k_contains_stream<<<dim3(grid), dim3(kBlock), 0, ctx->stream>>>((const int32_t*)col.values, col.bytes, rows, total,
+                                                                 tile_base, needle, needle_len, bits);
+  PRISM_HIP(hipGetLastError());
+}
+
+void launch_bitmap_and(prism_gpu_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, uint64_t n_words) {
+  if (!n_words) return;
+  uint32_t grid = (uint32_t)std::min<uint64_t>(ceil_div(n_words, kBlock), (uint64_t)ctx->n_cus * 8);
+  k_bitmap_binary<<<dim3(grid), dim3(kBlock), 0, ctx->stream>>>(a, b, out, n_words, 0);
+  PRISM_HIP(hipGetLastError());
+}
+
+void launch_bitmap_or(prism_gpu_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, uint64_t n_words) {
+  if (!n_words) return;
+  uint32_t grid = (uint32_t)std::min<uint64_t>(ceil_div(n_words, kBlock), (uint64_t)ctx->n_cus * 8);
+  k_bitmap_binary<<<dim3(grid), dim3(kBlock), 0, ctx->stream>>>(a, b, out, n_words, 1);
+  PRISM_HIP(hipGetLastError());
+}
+
+void launch_bitmap_count(prism_gpu_ctx* ctx, const uint64_t* bits, uint64_t n_words, unsigned long long* count) {
+  if (!n_words) return;
+  uint32_t grid = (uint32_t)std::min<uint64_t>(ceil_div(n_words, kBlock), (uint64_t)ctx->n_cus * 8);
+  k_bitmap_count<<<dim3(grid), dim3(kBlock), 0, ctx->stream>>>(bits, n_words, count);
+  PRISM_HIP(hipGetLastError());
+}
+
+}  // namespace prism

@@ -1,0 +1,257 @@
+"""Python driver over the C ABI of libprism_gpu.so (include/prism_gpu.h).
+
+This is the test/benchmark harness side of the boundary: it plays the role the
+Rust `ExecutionPlan` shim plays inside prism-query, moving pyarrow RecordBatches
+across the Arrow C Data Interface.  All compute happens in the HIP library; if
+the library or a GPU is missing, every call fails loudly; there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Iterable, List, Optional, Sequence
+
+import pyarrow as pa
+
+from . import _cabi as abi
+from .plan import QueryPlan, lower
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libprism_gpu.so")
+
+# every symbol include/prism_gpu.h declares
+EXPORTED_SYMBOLS = [
+    "prism_gpu_init", "prism_gpu_ctx_free", "prism_gpu_last_error",
+    "prism_gpu_table_create", "prism_gpu_table_append", "prism_gpu_table_num_rows",
+    "prism_gpu_table_num_partitions", "prism_gpu_table_free", "prism_gpu_table_set_dictionary",
+    "prism_gpu_table_synth",
+    "prism_gpu_plan_create", "prism_gpu_plan_output_schema", "prism_gpu_plan_final_schema", "prism_gpu_plan_free",
+    "prism_gpu_execute",
+    "prism_gpu_partition_open", "prism_gpu_push_batch", "prism_gpu_finish", "prism_gpu_part_free",
+    "prism_gpu_merge",
+    "prism_gpu_set_profiling", "prism_gpu_get_stats", "prism_gpu_reset_stats",
+]
+
+_LIB: Optional[C.CDLL] = None
+
+
+class PrismGpuError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"prism_gpu error {code}: {msg}")
+        self.code = code
+        self.msg = msg
+
+
+def load_library() -> C.CDLL:
+    """Loads libprism_gpu.so; raises if it has not been built (no fallback)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            f"{LIB_PATH} is missing: build it with `make -C prism_amd/csrc` (or __graft_entry__.build())")
+    L = C.CDLL(LIB_PATH)
+    P, V = C.POINTER, C.c_void_p
+    L.prism_gpu_last_error.restype = C.c_char_p
+    L.prism_gpu_init.argtypes = [C.c_int, P(V)]
+    L.prism_gpu_ctx_free.argtypes = [V]
+    L.prism_gpu_ctx_free.restype = None
+    L.prism_gpu_table_create.argtypes = [V, P(abi.ArrowSchema), P(V)]
+    L.prism_gpu_table_append.argtypes = [V, C.c_uint32, P(abi.ArrowArray)]
+    L.prism_gpu_table_num_rows.argtypes = [V, P(C.c_uint64)]
+    L.prism_gpu_table_num_partitions.argtypes = [V, P(C.c_uint32)]
+    L.prism_gpu_table_free.argtypes = [V]
+    L.prism_gpu_table_free.restype = None
+    L.prism_gpu_table_set_dictionary.argtypes = [V, C.c_int32, P(C.c_char_p), P(C.c_uint64), C.c_uint32]
+    L.prism_gpu_table_synth.argtypes = [V, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
+                                        P(abi.SynthCol), C.c_uint32]
+    L.prism_gpu_plan_create.argtypes = [V, P(abi.ArrowSchema), P(abi.PlanDesc), P(V)]
+    L.prism_gpu_plan_output_schema.argtypes = [V, P(abi.ArrowSchema)]
+    L.prism_gpu_plan_final_schema.argtypes = [V, P(abi.ArrowSchema)]
+    L.prism_gpu_plan_free.argtypes = [V]
+    L.prism_gpu_plan_free.restype = None
+    L.prism_gpu_execute.argtypes = [V, V, P(C.c_uint32), C.c_size_t, P(abi.ArrowArray)]
+    L.prism_gpu_partition_open.argtypes = [V, C.c_uint32, P(V)]
+    L.prism_gpu_push_batch.argtypes = [V, P(abi.ArrowArray)]
+    L.prism_gpu_finish.argtypes = [V, P(abi.ArrowArray)]
+    L.prism_gpu_part_free.argtypes = [V]
+    L.prism_gpu_part_free.restype = None
+    L.prism_gpu_merge.argtypes = [V, P(P(abi.ArrowArray)), C.c_size_t, P(abi.ArrowArray)]
+    L.prism_gpu_set_profiling.argtypes = [V, C.c_int]
+    L.prism_gpu_get_stats.argtypes = [V, P(abi.Stats)]
+    L.prism_gpu_reset_stats.argtypes = [V]
+    _LIB = L
+    return L
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise PrismGpuError(rc, load_library().prism_gpu_last_error().decode("utf-8", "replace"))
+
+
+class Context:
+    """prism_gpu_ctx: one per process and GPU."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        _check(self._lib.prism_gpu_init(device, C.byref(self._h)))
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.prism_gpu_ctx_free(self._h)
+            self._h = C.c_void_p()
+
+    def set_profiling(self, on: bool) -> None:
+        _check(self._lib.prism_gpu_set_profiling(self._h, 1 if on else 0))
+
+    def reset_stats(self) -> None:
+        _check(self._lib.prism_gpu_reset_stats(self._h))
+
+    def stats(self) -> dict:
+        s = abi.Stats()
+        _check(self._lib.prism_gpu_get_stats(self._h, C.byref(s)))
+        return {
+            "rows_scanned": s.rows_scanned,
+            "rows_selected": s.rows_selected,
+            "groups_out": s.groups_out,
+            "bytes_staged": s.bytes_staged,
+            "staging_ms": s.staging_ms,
+            "kernels": {
+                s.kernels[i].name.decode(): {
+                    "launches": s.kernels[i].launches,
+                    "total_ms": s.kernels[i].total_ms,
+                    "algorithmic_bytes": s.kernels[i].algorithmic_bytes,
+                }
+                for i in range(s.n_kernels)
+            },
+        }
+
+
+class Table:
+    """prism_gpu_table: HBM-resident partitions of one table."""
+
+    def __init__(self, ctx: Context, schema: pa.Schema):
+        self.ctx = ctx
+        self.schema = schema
+        self._lib = ctx._lib
+        self._h = C.c_void_p()
+        cs = abi.export_schema(schema)
+        try:
+            _check(self._lib.prism_gpu_table_create(ctx._h, C.byref(cs), C.byref(self._h)))
+        finally:
+            abi.release_schema(cs)
+
+    def append(self, partition_id: int, batch: pa.RecordBatch) -> None:
+        arr = abi.export_batch(batch)  # moved into the library
+        _check(self._lib.prism_gpu_table_append(self._h, partition_id, C.byref(arr)))
+
+    def append_table(self, table: pa.Table, n_partitions: int = 1) -> None:
+        """Splits a pyarrow Table into `n_partitions` contiguous partitions."""
+        n = table.num_rows
+        for p in range(n_partitions):
+            lo, hi = n * p // n_partitions, n * (p + 1) // n_partitions
+            for b in table.slice(lo, hi - lo).combine_chunks().to_batches():
+                self.append(p, b)
+
+    def set_dictionary(self, column: str, values: Sequence[str]) -> None:
+        enc = [v.encode("utf-8") for v in values]
+        arr = (C.c_char_p * len(enc))(*enc)
+        lens = (C.c_uint64 * len(enc))(*[len(v) for v in enc])
+        _check(self._lib.prism_gpu_table_set_dictionary(self._h, self.schema.names.index(column), arr, lens, len(enc)))
+
+    def synth(self, partition_id: int, seed: int, first_row: int, n_rows: int, total_rows: int,
+              cols: Sequence[abi.SynthCol]) -> None:
+        arr = (abi.SynthCol * len(cols))(*cols)
+        _check(self._lib.prism_gpu_table_synth(self._h, partition_id, seed, first_row, n_rows, total_rows, arr,
+                                               len(cols)))
+
+    @property
+    def num_rows(self) -> int:
+        n = C.c_uint64()
+        _check(self._lib.prism_gpu_table_num_rows(self._h, C.byref(n)))
+        return n.value
+
+    @property
+    def num_partitions(self) -> int:
+        n = C.c_uint32()
+        _check(self._lib.prism_gpu_table_num_partitions(self._h, C.byref(n)))
+        return n.value
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.prism_gpu_table_free(self._h)
+            self._h = C.c_void_p()
+
+
+class Plan:
+    """prism_gpu_plan over an input schema."""
+
+    def __init__(self, ctx: Context, schema: pa.Schema, query: QueryPlan):
+        self.ctx = ctx
+        self.schema = schema
+        self.query = query
+        self._lib = ctx._lib
+        self._lowered = lower(query, schema.names)
+        self._h = C.c_void_p()
+        cs = abi.export_schema(schema)
+        try:
+            _check(self._lib.prism_gpu_plan_create(ctx._h, C.byref(cs), self._lowered.ptr(), C.byref(self._h)))
+        finally:
+            abi.release_schema(cs)
+        self.output_schema = self._schema(self._lib.prism_gpu_plan_output_schema)
+        self.final_schema = self._schema(self._lib.prism_gpu_plan_final_schema)
+
+    def _schema(self, fn) -> pa.Schema:
+        s = abi.ArrowSchema()
+        _check(fn(self._h, C.byref(s)))
+        return abi.import_schema(s)
+
+    def execute(self, table: Table, partitions: Optional[Iterable[int]] = None) -> pa.Table:
+        out = abi.ArrowArray()
+        if partitions is None:
+            _check(self._lib.prism_gpu_execute(self._h, table._h, None, 0, C.byref(out)))
+        else:
+            ids = list(partitions)
+            arr = (C.c_uint32 * max(1, len(ids)))(*ids)
+            if not ids:
+                arr[0] = 0xFFFFFFFF  # an id no partition has: scan nothing
+            _check(self._lib.prism_gpu_execute(self._h, table._h, arr, max(1, len(ids)), C.byref(out)))
+        return pa.Table.from_batches([abi.import_batch(out, self.output_schema)])
+
+    def run_batches(self, partition: int, batches: Iterable[pa.RecordBatch]) -> pa.Table:
+        """Streaming form: partition_open / push_batch* / finish."""
+        part = C.c_void_p()
+        _check(self._lib.prism_gpu_partition_open(self._h, partition, C.byref(part)))
+        try:
+            for b in batches:
+                arr = abi.export_batch(b)
+                _check(self._lib.prism_gpu_push_batch(part, C.byref(arr)))
+            out = abi.ArrowArray()
+            _check(self._lib.prism_gpu_finish(part, C.byref(out)))
+            return pa.Table.from_batches([abi.import_batch(out, self.output_schema)])
+        finally:
+            self._lib.prism_gpu_part_free(part)
+
+    def merge(self, states: Sequence) -> pa.Table:
+        """AggregateExec(Final) over PARTIAL outputs of this plan."""
+        batches: List[pa.RecordBatch] = []
+        for s in states:
+            if isinstance(s, pa.Table):
+                batches += s.combine_chunks().to_batches()
+            else:
+                batches.append(s)
+        arrs = [abi.export_batch(b) for b in batches]
+        ptrs = (C.POINTER(abi.ArrowArray) * max(1, len(arrs)))(*[C.pointer(a) for a in arrs])
+        out = abi.ArrowArray()
+        try:
+            _check(self._lib.prism_gpu_merge(self._h, ptrs, len(arrs), C.byref(out)))
+        finally:
+            for a in arrs:
+                abi.release_array(a)  # borrowed by the library, still ours
+        return pa.Table.from_batches([abi.import_batch(out, self.final_schema)])
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.prism_gpu_plan_free(self._h)
+            self._h = C.c_void_p()
