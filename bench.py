@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rows/s scanned + aggregated on synthetic log events.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path (predicate -> selection -> GROUP BY aggregate ->
+final rows on the host) over the HBM-resident partitions of this rank.  At N = 1 the
+workload is "Synthetic log events 1B rows: time_bucket(1m) GROUP BY service with
+COUNT/SUM/MAX on one MI355X".  At N > 1 every rank holds its own 1B-row share of an
+N-times larger table (weak scaling), produces PARTIAL state, the states are
+all-gathered with RCCL and rank 0 runs the Final merge.
+
+Rank 0 prints one JSON line.  `roofline` prices the dominant kernel (group_by) by
+algorithmic bytes over its HIP-event duration; `cpu_baseline` times the CPU oracle
+(a restatement of the reference's semantics, not DataFusion itself) on a bounded
+sample of the same table on this host's cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3", "C5"])
+    ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the workload's)")
+    ap.add_argument("--partitions", type=int, default=0, help="partitions per GPU")
+    ap.add_argument("--cpu-sample-partitions", type=int, default=8,
+                    help="leading partitions of rank 0 the CPU baseline and the parity check run on")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from prism_amd import _cabi as abi
+    from prism_amd import workloads
+    from prism_amd.distributed import all_gather_tables
+    from prism_amd.engine import Context, Plan
+
+    wl = workloads.WORKLOADS[args.workload]()
+    rows = args.rows or wl.default_rows
+    parts = args.partitions or wl.default_partitions
+    total_rows = rows * world
+    first_row = rows * rank
+
+    ctx = Context(local_rank)
+    t0 = time.time()
+    table = workloads.build_gpu_table(ctx, wl, first_row, rows, total_rows, parts)
+    log(f"[rank {rank}] generated {rows:,} rows in {parts} partitions in {time.time() - t0:.1f}s")
+
+    single = Plan(ctx, wl.schema, wl.query)
+    partial = Plan(ctx, wl.schema, wl.query.with_mode(abi.MODE_PARTIAL)) if world > 1 else None
+
+    def step():
+        if world == 1:
+            return single.execute(table)
+        state = partial.execute(table)
+        states = all_gather_tables(state, device)
+        return partial.merge(states) if rank == 0 else None
+
+    # ---- parity check + CPU baseline on a bounded sample (rank 0) ----
+    cpu_baseline = None
+    k = max(1, min(args.cpu_sample_partitions, parts))
+    sample_rows = workloads.partition_bounds(rows, parts, k - 1)[1]
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import pyoracle
+        from tests.helpers import assert_tables_match, assert_topk_match
+
+        threads = max(1, int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)))
+        threads = min(threads, os.cpu_count() or 1)
+        t0 = time.time()
+        st = pyoracle.SynthTable(wl.schema, wl.make_cols(), wl.seed, first_row, sample_rows, total_rows,
+                                 n_parts=threads * 4, threads=threads)
+        log(f"[cpu] generated {sample_rows:,} sample rows in {time.time() - t0:.1f}s")
+        want, ms = st.execute(wl.query, threads=threads)
+        st.close()
+        want = workloads.decode_dictionary_columns(wl, want)
+        got = single.execute(table, range(k))
+        if wl.query.limit is not None:
+            assert_topk_match(got, want, wl.query.order_by)
+        else:
+            assert_tables_match(got, want, wl.n_keys)
+        log(f"[parity] GPU == CPU oracle on the first {k} partitions ({sample_rows:,} rows, {want.num_rows} groups)")
+        cpu_baseline = {
+            "value": sample_rows / (ms / 1e3),
+            "unit": "rows/s",
+            "cores": threads,
+            "kind": "port",
+            "sample": f"first {sample_rows} rows ({k} of {parts} partitions) of the same table, "
+                      f"CPU restatement of the reference's semantics (not DataFusion 32), {ms:.0f} ms",
+        }
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.reset_stats()
+    ctx.set_profiling(True)
+    barrier()
+    t0 = time.perf_counter()
+    result = None
+    for _ in range(args.steps):
+        result = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ctx.set_profiling(False)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        stats = ctx.stats()
+        # full-size, size-independent checks: every row lands in exactly one group
+        if args.workload in ("C2",):
+            assert sum(result.column("COUNT(*)").to_pylist()) == total_rows, "COUNT(*) does not add up to the rows scanned"
+        kname = {"C1": "filter_count", "C2": "group_by", "C3": "group_by", "C5": "group_by"}[args.workload]
+        ks = stats["kernels"].get(kname)
+        roofline = None
+        if ks and ks["launches"]:
+            avg_s = ks["total_ms"] / ks["launches"] / 1e3
+            groups = result.num_rows if wl.n_keys else 1
+            alg = rows * wl.bytes_per_row + (groups * wl.bytes_per_group if world == 1 else 0)
+            achieved = alg / avg_s / 1e9
+            roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kname,
+                        "kernel_avg_ms": avg_s * 1e3, "algorithmic_bytes_per_launch": alg}
+        ms_per_step = elapsed / args.steps * 1e3
+        line = {
+            "metric": "rows/sec scanned+aggregated (node)",
+            "value": total_rows / (elapsed / args.steps),
+            "unit": "rows/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int64",
+            "data": "synthetic",
+            "config": {"workload": f"{wl.name}: {wl.description}", "rows_per_gpu": rows, "partitions_per_gpu": parts,
+                       "total_rows": total_rows, "groups": result.num_rows,
+                       "merge": "none (single GPU)" if world == 1 else "RCCL all-gather of PARTIAL state + Final merge on rank 0"},
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+            "kernels": {n: {"launches": v["launches"], "avg_ms": v["total_ms"] / max(1, v["launches"])}
+                        for n, v in stats["kernels"].items()},
+        }
+        print(json.dumps(line), flush=True)
+
+    single.close()
+    if partial:
+        partial.close()
+    table.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
