@@ -138,7 +138,8 @@ struct LdsTable {
 
 __device__ __forceinline__ int lds_entry(const LdsTable& t, uint64_t key, int* n_entries) {
   int mask = t.S - 1;
-  int h = (int)(hash64(key) >> 20) & mask;
+  // one 32-bit multiply: the LDS table only has a few thousand entries to spread over
+  int h = (int)((((uint32_t)key ^ (uint32_t)(key >> 32)) * 0x9E3779B1u) >> 12) & mask;
   for (int probe = 0; probe < 16; ++probe) {
     unsigned long long k = t.keys[h];
     if (k == key) return h;
@@ -152,17 +153,22 @@ __device__ __forceinline__ int lds_entry(const LdsTable& t, uint64_t key, int* n
   return -1;
 }
 
-__device__ __forceinline__ void process_row(const AggParams& p, const LdsTable& t, bool use_lds, int* n_entries,
-                                            uint32_t seg, uint64_t row) {
-  uint64_t key = pack_key(p, seg, row);
-  RowVals rv;
-  load_vals(p, seg, row, rv);
+__device__ __forceinline__ void apply_row(const AggParams& p, const LdsTable& t, bool use_lds, int* n_entries,
+                                          uint64_t key, const RowVals& rv) {
   int e = (use_lds && key != kEmptyKey) ? lds_entry(t, key, n_entries) : -1;
   if (e < 0) { global_update(p, key, rv); return; }
   for (int s = 0; s < p.n_slots; ++s) {
     long long x;
     if (slot_input(p, s, rv, x)) atomic_apply(&t.state[s * t.S + e], p.slots[s].op, x);
   }
+}
+
+__device__ __forceinline__ void process_row(const AggParams& p, const LdsTable& t, bool use_lds, int* n_entries,
+                                            uint32_t seg, uint64_t row) {
+  uint64_t key = pack_key(p, seg, row);
+  RowVals rv;
+  load_vals(p, seg, row, rv);
+  apply_row(p, t, use_lds, n_entries, key, rv);
 }
 
 __device__ __forceinline__ void lds_clear(const AggParams& p, const LdsTable& t) {
@@ -267,6 +273,201 @@ __global__ __launch_bounds__(kBlock) void k_group_by(AggParams p) {
   if (have_lds) {
     __syncthreads();
     lds_flush(p, t);
+  }
+}
+
+// ---- streaming GROUP BY, specialised on the column counts ------------------------------
+//
+// Same algorithm as k_group_by for the "all rows" and "bitmap" row modes, but every
+// lane first issues the loads of kU rows of every key and value column (row per lane,
+// so a wave instruction reads one contiguous run per column) and only then starts
+// hashing: twelve or more loads are in flight per lane instead of one, which is what
+// an HBM-bound stream needs.  NK / NV are compile-time so that the loaded values
+// live in registers with constant indices.
+constexpr int kU = 4;
+
+// Pointers read from the descriptor arrays are generic; telling the compiler that
+// they point to global memory turns the column reads into global_load instructions
+// (a flat load also has to wait for LDS traffic).
+template <typename T>
+using GlobalPtr = const __attribute__((address_space(1))) T*;
+
+// Reads one value per row as a single unaligned 8-byte load at base + row * width,
+// whatever the width: no branch on the column type stands between the loads of
+// different columns, so all of them are in flight together.  The bytes beyond the
+// value belong to the next rows (or to the allocation's padding) and are shifted out
+// by extend().  Unaligned global loads are part of the amdhsa ABI.
+template <int U>
+__device__ __forceinline__ void load_rows(const void* base, int width, const uint64_t (&r)[U],
+                                          unsigned long long (&out)[U]) {
+  GlobalPtr<unsigned char> b = (GlobalPtr<unsigned char>)base;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    typedef unsigned long long __attribute__((aligned(1))) unaligned_u64;
+    out[u] = *(const __attribute__((address_space(1))) unaligned_u64*)(b + r[u] * (uint64_t)width);
+  }
+}
+
+__device__ __forceinline__ long long extend(unsigned long long raw, int width, int is_unsigned) {
+  int sh = 64 - 8 * width;
+  unsigned long long x = raw << sh;
+  return is_unsigned ? (long long)(x >> sh) : ((long long)x >> sh);
+}
+
+// Validity bits of U rows as a U-bit mask (all ones when the column has no bitmap).
+template <int U>
+__device__ __forceinline__ uint32_t load_valid(const uint64_t* validity, const uint64_t (&r)[U]) {
+  if (validity == nullptr) return (1u << U) - 1u;
+  GlobalPtr<unsigned long long> b = (GlobalPtr<unsigned long long>)validity;
+  unsigned long long w[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) w[u] = b[r[u] >> 6];
+  uint32_t m = 0;
+#pragma unroll
+  for (int u = 0; u < U; ++u) m |= (uint32_t)((w[u] >> (r[u] & 63)) & 1ull) << u;
+  return m;
+}
+
+__device__ __forceinline__ const void* uniform_ptr(const void* p) {
+  uint64_t v = (uint64_t)p;
+  uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (const void*)(((uint64_t)hi << 32) | lo);
+}
+
+template <int NK, int NV>
+__global__ __launch_bounds__(kBlock) void k_group_by_stream(AggParams p) {
+  extern __shared__ unsigned long long lds_raw[];
+  __shared__ int n_entries;
+  __shared__ int bypass;
+  LdsTable t;
+  t.S = p.lds_slots;
+  t.keys = lds_raw;
+  t.state = (long long*)(lds_raw + t.S);
+  if (threadIdx.x == 0) { n_entries = 0; bypass = 0; }
+  lds_clear(p, t);
+  __syncthreads();
+
+  constexpr int NKA = NK > 0 ? NK : 1, NVA = NV > 0 ? NV : 1;
+  const bool bitmap = p.row_mode == kRowsBitmap;
+  const uint64_t per = ceil_div(p.sd.n_tiles, (uint64_t)gridDim.x);
+  const uint64_t t0 = per * blockIdx.x, t1 = t0 + per < p.sd.n_tiles ? t0 + per : p.sd.n_tiles;
+  uint64_t rows_since_flush = 0;
+  for (uint64_t tile = t0; tile < t1; ++tile) {
+    const uint32_t seg = find_seg(p.sd, tile);
+    const uint64_t seg_rows = p.sd.segs[seg].rows;
+    const uint64_t tile_row0 = (tile - p.sd.segs[seg].tile_base) * kTileRows;
+    const bool use_lds = bypass == 0;
+    // per-tile, wave-uniform column pointers
+    const void* kval[NKA];
+    const uint64_t* kvalid[NKA];
+    const void* vval[NVA];
+    const uint64_t* vvalid[NVA];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const ColPtr& c = p.cols[(uint64_t)p.keys[k].col * p.sd.n_segs + seg];
+      kval[k] = uniform_ptr(c.values);
+      kvalid[k] = p.keys[k].null_bit >= 0 ? (const uint64_t*)uniform_ptr(c.validity) : nullptr;
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const ColPtr& c = p.cols[(uint64_t)p.vals[v].col * p.sd.n_segs + seg];
+      vval[v] = uniform_ptr(c.values);
+      vvalid[v] = (const uint64_t*)uniform_ptr(c.validity);
+    }
+
+    for (uint32_t it = 0; it < kTileRows / (kBlock * kU); ++it) {
+      uint64_t r[kU];
+      uint32_t live = 0;
+      const uint64_t in_tile0 = (uint64_t)it * kU * kBlock + threadIdx.x;
+      if (bitmap) {
+        GlobalPtr<unsigned long long> sb = (GlobalPtr<unsigned long long>)p.sel_bits;
+        unsigned long long w[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) w[u] = sb[(tile * kTileRows + in_tile0 + (uint64_t)u * kBlock) >> 6];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) live |= (uint32_t)((w[u] >> ((in_tile0 + (uint64_t)u * kBlock) & 63)) & 1ull) << u;
+      } else {
+        live = (1u << kU) - 1u;
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        uint64_t row = tile_row0 + in_tile0 + (uint64_t)u * kBlock;
+        if (row >= seg_rows) { live &= ~(1u << u); row = seg_rows - 1; }  // clamped: every lane loads
+        r[u] = row;
+      }
+      unsigned long long kraw[NKA][kU];
+      unsigned long long vraw[NVA][kU];
+      uint32_t kok[NKA], vok[NVA];
+#pragma unroll
+      for (int k = 0; k < NK; ++k) load_rows<kU>(kval[k], p.keys[k].width, r, kraw[k]);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) load_rows<kU>(vval[v], p.vals[v].width, r, vraw[v]);
+#pragma unroll
+      for (int k = 0; k < NK; ++k) kok[k] = load_valid<kU>(kvalid[k], r);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) vok[v] = load_valid<kU>(vvalid[v], r);
+
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        if (!((live >> u) & 1u)) continue;
+        uint64_t key = 0;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+          const KeySpec& ks = p.keys[k];
+          if (!((kok[k] >> u) & 1u)) { key |= 1ull << ks.null_bit; continue; }
+          long long v = extend(kraw[k][u], ks.width, ks.is_unsigned);
+          if (ks.date_bin) v = bucket_number(v, ks);
+          key |= ((uint64_t)v - (uint64_t)ks.bias) << ks.bit_pos;
+        }
+        RowVals rv;
+        rv.valid = 0;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          rv.v[v] = extend(vraw[v][u], p.vals[v].width, p.vals[v].is_unsigned);
+          rv.valid |= ((vok[v] >> u) & 1u) << v;
+        }
+        apply_row(p, t, use_lds, &n_entries, key, rv);
+      }
+    }
+    rows_since_flush += kTileRows;
+    __syncthreads();
+    int n = n_entries;
+    __syncthreads();
+    if (n > t.S / 2) {
+      lds_flush(p, t);
+      if (threadIdx.x == 0) {
+        if ((uint64_t)n * 4 > rows_since_flush) bypass = 1;
+        n_entries = 0;
+      }
+      rows_since_flush = 0;
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  lds_flush(p, t);
+}
+
+using GroupByKernel = void (*)(AggParams);
+
+template <int NK>
+GroupByKernel pick_stream_nv(int nv) {
+  switch (nv) {
+    case 0: return k_group_by_stream<NK, 0>;
+    case 1: return k_group_by_stream<NK, 1>;
+    case 2: return k_group_by_stream<NK, 2>;
+    case 3: return k_group_by_stream<NK, 3>;
+    case 4: return k_group_by_stream<NK, 4>;
+    default: return nullptr;
+  }
+}
+
+GroupByKernel pick_stream(int nk, int nv) {
+  switch (nk) {
+    case 1: return pick_stream_nv<1>(nv);
+    case 2: return pick_stream_nv<2>(nv);
+    case 3: return pick_stream_nv<3>(nv);
+    case 4: return pick_stream_nv<4>(nv);
+    default: return nullptr;
   }
 }
 
@@ -421,7 +622,9 @@ void launch_group_by(prism_gpu_ctx* ctx, const AggParams& p, uint64_t algorithmi
   // ranges per workgroup so that its LDS table sees each group many times
   uint32_t grid = (uint32_t)std::min<uint64_t>(work, (uint64_t)ctx->n_cus * 8);
   KernelTimer timer(ctx, "group_by", algorithmic_bytes);
-  k_group_by<<<dim3(grid), dim3(kBlock), lds, ctx->stream>>>(p);
+  GroupByKernel fast = (p.row_mode != kRowsSelvec && p.lds_slots > 0) ? pick_stream(p.n_keys, p.n_vals) : nullptr;
+  if (fast) fast<<<dim3(grid), dim3(kBlock), lds, ctx->stream>>>(p);
+  else k_group_by<<<dim3(grid), dim3(kBlock), lds, ctx->stream>>>(p);
   PRISM_HIP(hipGetLastError());
 }
 
