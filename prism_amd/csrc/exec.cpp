@@ -96,6 +96,19 @@ void div_magic(uint64_t d, uint64_t& magic, int& shift) {
   shift = fl;
 }
 
+void div_magic32(uint32_t d, uint32_t& magic, int& shift) {
+  if (d == 1) { magic = 0; shift = -1; return; }
+  int fl = 31 - __builtin_clz(d);
+  if ((d & (d - 1)) == 0) { magic = 0; shift = fl - 1; return; }
+  uint64_t num = 1ull << (32 + fl);
+  uint32_t proposed = (uint32_t)(num / d), rem = (uint32_t)(num % d);
+  proposed += proposed;
+  uint32_t twice = rem + rem;
+  if (twice >= d || twice < rem) proposed += 1;
+  magic = proposed + 1;
+  shift = fl;
+}
+
 long long bucket_number_host(long long ts, long long stride, long long origin) {
   long long d = (long long)((uint64_t)ts - (uint64_t)origin);
   uint64_t a = d < 0 ? (0ull - (uint64_t)d) : (uint64_t)d;
@@ -145,6 +158,16 @@ void layout_keys(ScanSet& ss, const prism_gpu_table* t, const std::vector<KeySrc
     s.stride = k.stride;
     s.origin = k.origin;
     if (k.date_bin) div_magic((uint64_t)k.stride, s.magic, s.magic_shift);
+    if (k.date_bin && ci.min <= ci.max && ci.min >= k.origin && (uint64_t)k.stride < (1ull << 32)) {
+      // every timestamp is at or after the origin: bucket numbers are plain floors, and
+      // relative to the first bucket's start they may fit 32-bit arithmetic
+      long long base = (long long)((uint64_t)k.origin + (uint64_t)vmin * (uint64_t)k.stride);
+      if ((uint64_t)ci.max - (uint64_t)base < (1ull << 32)) {
+        s.fast32 = 1;
+        s.base = base;
+        div_magic32((uint32_t)k.stride, s.magic32, s.shift32);
+      }
+    }
     KeyField kf;
     kf.bits = bits_for((uint64_t)vmax - (uint64_t)vmin);
     kf.bias = vmin;
@@ -747,6 +770,7 @@ void execute_plan(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
     ap.n_keys = (int)layout.specs.size();
     for (size_t i = 0; i < layout.specs.size(); ++i) ap.keys[i] = layout.specs[i];
     ap.lds_slots = lds_slots_for(ap.n_slots);
+    ap.key_bits = total_bits;
     uint64_t bound = selected;
     if (total_bits < 63) bound = std::min<uint64_t>(bound, 1ull << total_bits);
     GroupTable gt;

@@ -89,7 +89,13 @@ struct KeySpec {
   int32_t bit_pos;    // position of this field in the packed key
   int64_t bias;       // field = value - bias
   int32_t null_bit;   // bit set for a NULL key, -1 when the column has no NULLs
-  int32_t pad;
+  // date_bin in 32-bit arithmetic, usable when every timestamp of the scan is at or
+  // after the origin and (ts - base) and the stride fit in 32 bits, base being the
+  // start of the first bucket: field = (uint32)(ts - base) / stride, no bias needed.
+  int32_t fast32;
+  int64_t base;
+  uint32_t magic32;
+  int32_t shift32;
 };
 
 struct ValSpec {
@@ -129,12 +135,19 @@ struct AggParams {
   uint64_t n_sel;
   // global table: dense (index = packed key) or open addressing on the packed key
   int32_t dense;
+  int32_t key_bits;     // bits of the packed key in use
   int32_t lds_slots;    // power of two; 0 = no LDS pre-aggregation
   uint64_t capacity;    // dense: number of entries; hash: power of two
   uint64_t* g_keys;     // hash only: capacity + 1 entries (last = the all-ones key)
   int64_t* g_state;     // n_slots arrays of (capacity + 1) entries
   uint32_t* overflow;   // set to 1 when the hash table is full
 };
+
+// The streaming GROUP BY kernel specialised for p's shape (number of key and value
+// columns, 32- or 64-bit packed key), or nullptr when there is none; *lds_bytes
+// receives the dynamic LDS size it needs.
+using GroupByKernel = void (*)(AggParams);
+GroupByKernel pick_stream_kernel(const AggParams& p, size_t* lds_bytes);
 
 // Ungrouped aggregates: out[n_slots] must hold the slot identities on entry.
 void launch_agg_global(prism_gpu_ctx* ctx, const AggParams& p, int64_t* out);

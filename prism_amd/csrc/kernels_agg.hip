@@ -16,41 +16,11 @@
 // how a dense table knows which entries exist.
 #include <algorithm>
 
-#include "device_utils.hpp"
+#include "agg_device.hpp"
 
 namespace prism {
 
 namespace {
-
-constexpr long long kI64Max = 0x7fffffffffffffffll;
-constexpr long long kI64Min = -kI64Max - 1;
-
-__device__ __forceinline__ long long slot_identity(int op) {
-  return op == kSlotMin ? kI64Max : (op == kSlotMax ? kI64Min : 0ll);
-}
-
-// floor(n / d) for the divisor described by (magic, shift); shift < 0 means d == 1.
-__device__ __forceinline__ uint64_t fast_div(uint64_t n, uint64_t magic, int shift) {
-  if (shift < 0) return n;
-  uint64_t q = __umul64hi(magic, n);
-  uint64_t t = ((n - q) >> 1) + q;
-  return t >> shift;
-}
-
-// Bucket number of a timestamp: DataFusion's date_bin rounds toward zero and then
-// steps one more stride down for timestamps before the origin.
-__device__ __forceinline__ long long bucket_number(long long ts, const KeySpec& k) {
-  long long d = (long long)((uint64_t)ts - (uint64_t)k.origin);
-  uint64_t a = d < 0 ? (0ull - (uint64_t)d) : (uint64_t)d;
-  long long q = (long long)fast_div(a, k.magic, k.magic_shift);
-  if (d < 0) q = -q - (k.stride > 1 ? 1 : 0);
-  return q;
-}
-
-struct RowVals {
-  long long v[kMaxVals];
-  uint32_t valid;  // bit j: value j is not NULL
-};
 
 __device__ __forceinline__ uint64_t pack_key(const AggParams& p, uint32_t seg, uint64_t row) {
   uint64_t key = 0;
@@ -78,58 +48,6 @@ __device__ __forceinline__ void load_vals(const AggParams& p, uint32_t seg, uint
   }
 }
 
-// Contribution of one row to slot s: returns false when the row does not touch it.
-__device__ __forceinline__ bool slot_input(const AggParams& p, int s, const RowVals& rv, long long& out) {
-  const SlotSpec& sl = p.slots[s];
-  if (sl.op == kSlotAddOne) { out = 1; return true; }
-  if (!((rv.valid >> sl.val) & 1u)) return false;
-  long long v = 0;
-#pragma unroll
-  for (int j = 0; j < kMaxVals; ++j)
-    if (j == sl.val) v = rv.v[j];  // select chain: a runtime index would put rv.v in scratch memory
-  if (sl.op == kSlotAddValid) out = 1;
-  else if (sl.op == kSlotAddF64) out = p.vals[sl.val].is_float ? v : __double_as_longlong((double)v);
-  else out = v;
-  return true;
-}
-
-template <typename P>
-__device__ __forceinline__ void atomic_apply(P* addr, int op, long long x) {
-  if (op == kSlotMin) atomicMin((long long*)addr, x);
-  else if (op == kSlotMax) atomicMax((long long*)addr, x);
-  else if (op == kSlotAddF64) atomicAdd((double*)addr, __longlong_as_double(x));
-  else atomicAdd((unsigned long long*)addr, (unsigned long long)x);
-}
-
-// Entry of `key` in the HBM table, inserting it if absent; capacity (the extra
-// entry) for the all-ones key; ~0 when the table is full.
-__device__ __forceinline__ uint64_t global_entry(const AggParams& p, uint64_t key) {
-  if (p.dense) return key;
-  if (key == kEmptyKey) return p.capacity;
-  uint64_t mask = p.capacity - 1;
-  uint64_t h = hash64(key) & mask;
-  for (uint64_t probe = 0; probe < p.capacity; ++probe) {
-    unsigned long long k = p.g_keys[h];
-    if (k == key) return h;
-    if (k == kEmptyKey) {
-      unsigned long long old = atomicCAS((unsigned long long*)&p.g_keys[h], kEmptyKey, key);
-      if (old == kEmptyKey || old == key) return h;
-    }
-    h = (h + 1) & mask;
-  }
-  *p.overflow = 1u;
-  return ~0ull;
-}
-
-__device__ __forceinline__ void global_update(const AggParams& p, uint64_t key, const RowVals& rv) {
-  uint64_t e = global_entry(p, key);
-  if (e == ~0ull) return;
-  for (int s = 0; s < p.n_slots; ++s) {
-    long long x;
-    if (slot_input(p, s, rv, x)) atomic_apply(&p.g_state[(uint64_t)s * (p.capacity + 1) + e], p.slots[s].op, x);
-  }
-}
-
 struct LdsTable {
   unsigned long long* keys;  // [S]
   long long* state;          // [n_slots][S]
@@ -153,8 +71,9 @@ __device__ __forceinline__ int lds_entry(const LdsTable& t, uint64_t key, int* n
   return -1;
 }
 
+template <int N>
 __device__ __forceinline__ void apply_row(const AggParams& p, const LdsTable& t, bool use_lds, int* n_entries,
-                                          uint64_t key, const RowVals& rv) {
+                                          uint64_t key, const RowValsT<N>& rv) {
   int e = (use_lds && key != kEmptyKey) ? lds_entry(t, key, n_entries) : -1;
   if (e < 0) { global_update(p, key, rv); return; }
   for (int s = 0; s < p.n_slots; ++s) {
@@ -273,201 +192,6 @@ __global__ __launch_bounds__(kBlock) void k_group_by(AggParams p) {
   if (have_lds) {
     __syncthreads();
     lds_flush(p, t);
-  }
-}
-
-// ---- streaming GROUP BY, specialised on the column counts ------------------------------
-//
-// Same algorithm as k_group_by for the "all rows" and "bitmap" row modes, but every
-// lane first issues the loads of kU rows of every key and value column (row per lane,
-// so a wave instruction reads one contiguous run per column) and only then starts
-// hashing: twelve or more loads are in flight per lane instead of one, which is what
-// an HBM-bound stream needs.  NK / NV are compile-time so that the loaded values
-// live in registers with constant indices.
-constexpr int kU = 4;
-
-// Pointers read from the descriptor arrays are generic; telling the compiler that
-// they point to global memory turns the column reads into global_load instructions
-// (a flat load also has to wait for LDS traffic).
-template <typename T>
-using GlobalPtr = const __attribute__((address_space(1))) T*;
-
-// Reads one value per row as a single unaligned 8-byte load at base + row * width,
-// whatever the width: no branch on the column type stands between the loads of
-// different columns, so all of them are in flight together.  The bytes beyond the
-// value belong to the next rows (or to the allocation's padding) and are shifted out
-// by extend().  Unaligned global loads are part of the amdhsa ABI.
-template <int U>
-__device__ __forceinline__ void load_rows(const void* base, int width, const uint64_t (&r)[U],
-                                          unsigned long long (&out)[U]) {
-  GlobalPtr<unsigned char> b = (GlobalPtr<unsigned char>)base;
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    typedef unsigned long long __attribute__((aligned(1))) unaligned_u64;
-    out[u] = *(const __attribute__((address_space(1))) unaligned_u64*)(b + r[u] * (uint64_t)width);
-  }
-}
-
-__device__ __forceinline__ long long extend(unsigned long long raw, int width, int is_unsigned) {
-  int sh = 64 - 8 * width;
-  unsigned long long x = raw << sh;
-  return is_unsigned ? (long long)(x >> sh) : ((long long)x >> sh);
-}
-
-// Validity bits of U rows as a U-bit mask (all ones when the column has no bitmap).
-template <int U>
-__device__ __forceinline__ uint32_t load_valid(const uint64_t* validity, const uint64_t (&r)[U]) {
-  if (validity == nullptr) return (1u << U) - 1u;
-  GlobalPtr<unsigned long long> b = (GlobalPtr<unsigned long long>)validity;
-  unsigned long long w[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) w[u] = b[r[u] >> 6];
-  uint32_t m = 0;
-#pragma unroll
-  for (int u = 0; u < U; ++u) m |= (uint32_t)((w[u] >> (r[u] & 63)) & 1ull) << u;
-  return m;
-}
-
-__device__ __forceinline__ const void* uniform_ptr(const void* p) {
-  uint64_t v = (uint64_t)p;
-  uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-  return (const void*)(((uint64_t)hi << 32) | lo);
-}
-
-template <int NK, int NV>
-__global__ __launch_bounds__(kBlock) void k_group_by_stream(AggParams p) {
-  extern __shared__ unsigned long long lds_raw[];
-  __shared__ int n_entries;
-  __shared__ int bypass;
-  LdsTable t;
-  t.S = p.lds_slots;
-  t.keys = lds_raw;
-  t.state = (long long*)(lds_raw + t.S);
-  if (threadIdx.x == 0) { n_entries = 0; bypass = 0; }
-  lds_clear(p, t);
-  __syncthreads();
-
-  constexpr int NKA = NK > 0 ? NK : 1, NVA = NV > 0 ? NV : 1;
-  const bool bitmap = p.row_mode == kRowsBitmap;
-  const uint64_t per = ceil_div(p.sd.n_tiles, (uint64_t)gridDim.x);
-  const uint64_t t0 = per * blockIdx.x, t1 = t0 + per < p.sd.n_tiles ? t0 + per : p.sd.n_tiles;
-  uint64_t rows_since_flush = 0;
-  for (uint64_t tile = t0; tile < t1; ++tile) {
-    const uint32_t seg = find_seg(p.sd, tile);
-    const uint64_t seg_rows = p.sd.segs[seg].rows;
-    const uint64_t tile_row0 = (tile - p.sd.segs[seg].tile_base) * kTileRows;
-    const bool use_lds = bypass == 0;
-    // per-tile, wave-uniform column pointers
-    const void* kval[NKA];
-    const uint64_t* kvalid[NKA];
-    const void* vval[NVA];
-    const uint64_t* vvalid[NVA];
-#pragma unroll
-    for (int k = 0; k < NK; ++k) {
-      const ColPtr& c = p.cols[(uint64_t)p.keys[k].col * p.sd.n_segs + seg];
-      kval[k] = uniform_ptr(c.values);
-      kvalid[k] = p.keys[k].null_bit >= 0 ? (const uint64_t*)uniform_ptr(c.validity) : nullptr;
-    }
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      const ColPtr& c = p.cols[(uint64_t)p.vals[v].col * p.sd.n_segs + seg];
-      vval[v] = uniform_ptr(c.values);
-      vvalid[v] = (const uint64_t*)uniform_ptr(c.validity);
-    }
-
-    for (uint32_t it = 0; it < kTileRows / (kBlock * kU); ++it) {
-      uint64_t r[kU];
-      uint32_t live = 0;
-      const uint64_t in_tile0 = (uint64_t)it * kU * kBlock + threadIdx.x;
-      if (bitmap) {
-        GlobalPtr<unsigned long long> sb = (GlobalPtr<unsigned long long>)p.sel_bits;
-        unsigned long long w[kU];
-#pragma unroll
-        for (int u = 0; u < kU; ++u) w[u] = sb[(tile * kTileRows + in_tile0 + (uint64_t)u * kBlock) >> 6];
-#pragma unroll
-        for (int u = 0; u < kU; ++u) live |= (uint32_t)((w[u] >> ((in_tile0 + (uint64_t)u * kBlock) & 63)) & 1ull) << u;
-      } else {
-        live = (1u << kU) - 1u;
-      }
-#pragma unroll
-      for (int u = 0; u < kU; ++u) {
-        uint64_t row = tile_row0 + in_tile0 + (uint64_t)u * kBlock;
-        if (row >= seg_rows) { live &= ~(1u << u); row = seg_rows - 1; }  // clamped: every lane loads
-        r[u] = row;
-      }
-      unsigned long long kraw[NKA][kU];
-      unsigned long long vraw[NVA][kU];
-      uint32_t kok[NKA], vok[NVA];
-#pragma unroll
-      for (int k = 0; k < NK; ++k) load_rows<kU>(kval[k], p.keys[k].width, r, kraw[k]);
-#pragma unroll
-      for (int v = 0; v < NV; ++v) load_rows<kU>(vval[v], p.vals[v].width, r, vraw[v]);
-#pragma unroll
-      for (int k = 0; k < NK; ++k) kok[k] = load_valid<kU>(kvalid[k], r);
-#pragma unroll
-      for (int v = 0; v < NV; ++v) vok[v] = load_valid<kU>(vvalid[v], r);
-
-#pragma unroll
-      for (int u = 0; u < kU; ++u) {
-        if (!((live >> u) & 1u)) continue;
-        uint64_t key = 0;
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
-          const KeySpec& ks = p.keys[k];
-          if (!((kok[k] >> u) & 1u)) { key |= 1ull << ks.null_bit; continue; }
-          long long v = extend(kraw[k][u], ks.width, ks.is_unsigned);
-          if (ks.date_bin) v = bucket_number(v, ks);
-          key |= ((uint64_t)v - (uint64_t)ks.bias) << ks.bit_pos;
-        }
-        RowVals rv;
-        rv.valid = 0;
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-          rv.v[v] = extend(vraw[v][u], p.vals[v].width, p.vals[v].is_unsigned);
-          rv.valid |= ((vok[v] >> u) & 1u) << v;
-        }
-        apply_row(p, t, use_lds, &n_entries, key, rv);
-      }
-    }
-    rows_since_flush += kTileRows;
-    __syncthreads();
-    int n = n_entries;
-    __syncthreads();
-    if (n > t.S / 2) {
-      lds_flush(p, t);
-      if (threadIdx.x == 0) {
-        if ((uint64_t)n * 4 > rows_since_flush) bypass = 1;
-        n_entries = 0;
-      }
-      rows_since_flush = 0;
-      __syncthreads();
-    }
-  }
-  __syncthreads();
-  lds_flush(p, t);
-}
-
-using GroupByKernel = void (*)(AggParams);
-
-template <int NK>
-GroupByKernel pick_stream_nv(int nv) {
-  switch (nv) {
-    case 0: return k_group_by_stream<NK, 0>;
-    case 1: return k_group_by_stream<NK, 1>;
-    case 2: return k_group_by_stream<NK, 2>;
-    case 3: return k_group_by_stream<NK, 3>;
-    case 4: return k_group_by_stream<NK, 4>;
-    default: return nullptr;
-  }
-}
-
-GroupByKernel pick_stream(int nk, int nv) {
-  switch (nk) {
-    case 1: return pick_stream_nv<1>(nv);
-    case 2: return pick_stream_nv<2>(nv);
-    case 3: return pick_stream_nv<3>(nv);
-    case 4: return pick_stream_nv<4>(nv);
-    default: return nullptr;
   }
 }
 
@@ -620,11 +344,18 @@ void launch_group_by(prism_gpu_ctx* ctx, const AggParams& p, uint64_t algorithmi
   size_t lds = (size_t)p.lds_slots * 8 * (1 + p.n_slots);
   // enough workgroups to fill every CU several times over, but long contiguous row
   // ranges per workgroup so that its LDS table sees each group many times
-  uint32_t grid = (uint32_t)std::min<uint64_t>(work, (uint64_t)ctx->n_cus * 8);
+  size_t fast_lds = 0;
+  GroupByKernel fast = (p.row_mode != kRowsSelvec && p.lds_slots > 0) ? pick_stream_kernel(p, &fast_lds) : nullptr;
+  GroupByKernel kernel = fast ? fast : k_group_by;
+  if (fast) lds = fast_lds;
+  // One round of workgroups: exactly as many as are resident at once, each walking a
+  // contiguous run of tiles, so that no CU idles while a second, partial round runs.
+  int per_cu = 0;
+  PRISM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)kBlock, lds));
+  if (per_cu < 1) per_cu = 1;
+  uint32_t grid = (uint32_t)std::min<uint64_t>(work, (uint64_t)ctx->n_cus * (uint64_t)per_cu);
   KernelTimer timer(ctx, "group_by", algorithmic_bytes);
-  GroupByKernel fast = (p.row_mode != kRowsSelvec && p.lds_slots > 0) ? pick_stream(p.n_keys, p.n_vals) : nullptr;
-  if (fast) fast<<<dim3(grid), dim3(kBlock), lds, ctx->stream>>>(p);
-  else k_group_by<<<dim3(grid), dim3(kBlock), lds, ctx->stream>>>(p);
+  kernel<<<dim3(grid), dim3(kBlock), lds, ctx->stream>>>(p);
   PRISM_HIP(hipGetLastError());
 }
 

@@ -84,7 +84,9 @@ def c1() -> Workload:
 
 def c2(n_services: int = 64) -> Workload:
     schema = pa.schema([("timestamp", pa.timestamp("ms")), ("service", pa.string()), ("value", pa.int64())])
-    cdf = zipf_cdf(n_services, 1.1)
+    import os
+
+    cdf = zipf_cdf(n_services, float(os.environ.get("PRISM_C2_ZIPF", "1.1")))  # env override: experiments only
     return Workload(
         "C2", "SELECT date_bin(INTERVAL '1 minute', timestamp), service, COUNT(*), SUM(value), MAX(value) "
               "FROM events GROUP BY 1, 2", schema,
