@@ -96,8 +96,10 @@ void div_magic(uint64_t d, uint64_t& magic, int& shift) {
   shift = fl;
 }
 
-void div_magic32(uint32_t d, uint32_t& magic, int& shift) {
-  if (d == 1) { magic = 0; shift = -1; return; }
+// n / d == (((n - q) >> pre) + q) >> shift with q = mulhi(magic, n), for every 32-bit n.
+void div_magic32(uint32_t d, uint32_t& magic, int& pre, int& shift) {
+  pre = 1;
+  if (d == 1) { magic = 0; pre = 0; shift = 0; return; }
   int fl = 31 - __builtin_clz(d);
   if ((d & (d - 1)) == 0) { magic = 0; shift = fl - 1; return; }
   uint64_t num = 1ull << (32 + fl);
@@ -165,8 +167,13 @@ void layout_keys(ScanSet& ss, const prism_gpu_table* t, const std::vector<KeySrc
       if ((uint64_t)ci.max - (uint64_t)base < (1ull << 32)) {
         s.fast32 = 1;
         s.base = base;
-        div_magic32((uint32_t)k.stride, s.magic32, s.shift32);
+        div_magic32((uint32_t)k.stride, s.magic32, s.pre32, s.shift32);
       }
+    }
+    if (!k.date_bin && (uint64_t)vmax - (uint64_t)vmin < (1ull << 31)) {
+      s.fast32 = 1;  // plain column: divisor 1
+      s.base = vmin;
+      div_magic32(1, s.magic32, s.pre32, s.shift32);
     }
     KeyField kf;
     kf.bits = bits_for((uint64_t)vmax - (uint64_t)vmin);

@@ -89,13 +89,16 @@ struct KeySpec {
   int32_t bit_pos;    // position of this field in the packed key
   int64_t bias;       // field = value - bias
   int32_t null_bit;   // bit set for a NULL key, -1 when the column has no NULLs
-  // date_bin in 32-bit arithmetic, usable when every timestamp of the scan is at or
-  // after the origin and (ts - base) and the stride fit in 32 bits, base being the
-  // start of the first bucket: field = (uint32)(ts - base) / stride, no bias needed.
+  // 32-bit form of the field, field = (uint32)(value - base) / divisor, usable when the
+  // packed key fits 31 bits: plain columns (base = bias, divisor 1) and date_bin when
+  // every timestamp of the scan is at or after the origin and (ts - base) and the
+  // stride fit in 32 bits, base being the start of the first bucket.
   int32_t fast32;
   int64_t base;
   uint32_t magic32;
+  int32_t pre32;
   int32_t shift32;
+  int32_t pad;
 };
 
 struct ValSpec {

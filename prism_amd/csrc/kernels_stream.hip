@@ -166,25 +166,28 @@ __device__ __forceinline__ void issue(const AggParams& p, uint64_t j, SegCursor<
   b.live = live;
 }
 
-// Value of a fixed-width column from the 8 bytes loaded at its address.
-__device__ __forceinline__ long long widen(unsigned long long raw, int width, int is_unsigned) {
-  if (width == 8) return (long long)raw;
-  uint32_t lo = (uint32_t)raw;
-  if (width == 4) return is_unsigned ? (long long)lo : (long long)(int)lo;
-  return is_unsigned ? (long long)(lo & 0xffffu) : (long long)(short)lo;
-}
-
-// Low 32 bits of the same value (enough when only differences below 2^32 matter).
+// Low 32 bits of a fixed-width value from the 8 bytes loaded at its address, without
+// branching on the width: shift the value to the top of the dword and back down,
+// arithmetically for signed types.
 __device__ __forceinline__ uint32_t widen_lo(unsigned long long raw, int width, int is_unsigned) {
-  uint32_t lo = (uint32_t)raw;
-  if (width >= 4) return lo;
-  return is_unsigned ? (lo & 0xffffu) : (uint32_t)(int)(short)lo;
+  const int sh = width >= 4 ? 0 : 16;
+  const uint32_t x = (uint32_t)raw << sh;
+  return is_unsigned ? (x >> sh) : (uint32_t)((int)x >> sh);
 }
 
-__device__ __forceinline__ uint32_t fast_div32(uint32_t n, uint32_t magic, int shift) {
-  if (shift < 0) return n;
+// The full value, also branch free.
+__device__ __forceinline__ long long widen(unsigned long long raw, int width, int is_unsigned) {
+  const uint32_t lo = widen_lo(raw, width, is_unsigned);
+  const uint32_t ext = is_unsigned ? 0u : (uint32_t)((int)lo >> 31);
+  const uint32_t hi = width == 8 ? (uint32_t)(raw >> 32) : ext;
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
+// n / d for a divisor described by (magic, pre, shift), including d == 1
+// (magic 0, pre 0, shift 0), without a branch.
+__device__ __forceinline__ uint32_t fast_div32(uint32_t n, uint32_t magic, int pre, int shift) {
   uint32_t q = __umulhi(magic, n);
-  uint32_t t = ((n - q) >> 1) + q;
+  uint32_t t = ((n - q) >> pre) + q;
   return t >> shift;
 }
 
@@ -202,18 +205,15 @@ __device__ __forceinline__ void convert(const AggParams& p, const RowBatch<NK, N
       const int bit_pos = ks.bit_pos, null_bit = ks.null_bit;
       const KeyT<K32> null_field = null_bit >= 0 ? ((KeyT<K32>)1 << null_bit) : (KeyT<K32>)0;
       KeyT<K32> field;
-      if (K32) {
-        if (ks.fast32) {
-          field = fast_div32(widen_lo(b.kraw[k][u], ks.width, ks.is_unsigned) - (uint32_t)ks.base, ks.magic32, ks.shift32);
-        } else if (ks.date_bin) {
-          field = (uint32_t)((uint64_t)bucket_number(widen(b.kraw[k][u], ks.width, ks.is_unsigned), ks) - (uint64_t)ks.bias);
-        } else {
-          field = widen_lo(b.kraw[k][u], ks.width, ks.is_unsigned) - (uint32_t)ks.bias;
-        }
+      if (K32 && ks.fast32) {
+        // plain columns and 32-bit date_bin alike: (value - base) / divisor, divisor 1 for
+        // a plain column
+        field = fast_div32(widen_lo(b.kraw[k][u], ks.width, ks.is_unsigned) - (uint32_t)ks.base, ks.magic32, ks.pre32,
+                           ks.shift32);
       } else {
         long long v = widen(b.kraw[k][u], ks.width, ks.is_unsigned);
         if (ks.date_bin) v = bucket_number(v, ks);
-        field = (uint64_t)v - (uint64_t)ks.bias;
+        field = (KeyT<K32>)((uint64_t)v - (uint64_t)ks.bias);
       }
       field <<= bit_pos;
       key |= ((b.kok[k] >> u) & 1u) ? field : null_field;
@@ -248,12 +248,61 @@ __device__ __forceinline__ int lds_entry(const Lds<K32>& t, KeyT<K32> key, int* 
   return -1;
 }
 
+// Applies the kU rows of a lane.  Slot-major: the LDS entries of all rows are looked
+// up first (independent probe chains, so their LDS latencies overlap), then every slot
+// is decoded once and applied to all rows, so the per-slot dispatch is paid per step,
+// not per row.  Rows that found the LDS table full fall through to the HBM table.
 template <int NK, int NV, bool K32>
 __device__ __forceinline__ void consume(const AggParams& p, const Lds<K32>& t, bool use_lds, int* n_entries,
                                         const PackedRows<NK, NV, K32>& b) {
+  int e[kU];  // LDS entry, -1 = go to HBM, -2 = row not live
 #pragma unroll
   for (int u = 0; u < kU; ++u) {
-    if (!((b.live >> u) & 1u)) continue;
+    e[u] = -2;
+    if ((b.live >> u) & 1u) {
+      // a 64-bit key equal to the empty marker only lives in the HBM table's extra entry
+      const bool lds_ok = use_lds && (K32 || b.key[u] != (KeyT<K32>)kEmptyKey);
+      e[u] = lds_ok ? lds_entry<K32>(t, b.key[u], n_entries) : -1;
+    }
+  }
+  for (int s = 0; s < p.n_slots; ++s) {
+    const int op = p.slots[s].op, val = p.slots[s].val;
+    long long* base = t.state + s * t.S;
+    if (op == kSlotAddOne) {
+#pragma unroll
+      for (int u = 0; u < kU; ++u)
+        if (e[u] >= 0) atomicAdd((unsigned long long*)&base[e[u]], 1ull);
+      continue;
+    }
+    // the slot's input column, picked by a select chain (a runtime index would put the
+    // values in scratch memory)
+    uint32_t ok = 0;
+    long long x[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) x[u] = 0;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      if (v == val) {
+        ok = b.vok[v];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) x[u] = b.val[v][u];
+      }
+    }
+    const bool is_float = val >= 0 && p.vals[val].is_float;
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      if (e[u] < 0 || !((ok >> u) & 1u)) continue;
+      long long* addr = &base[e[u]];
+      if (op == kSlotAddValid) atomicAdd((unsigned long long*)addr, 1ull);
+      else if (op == kSlotAddI64) atomicAdd((unsigned long long*)addr, (unsigned long long)x[u]);
+      else if (op == kSlotMax) atomicMax(addr, x[u]);
+      else if (op == kSlotMin) atomicMin(addr, x[u]);
+      else atomicAdd((double*)addr, is_float ? __longlong_as_double(x[u]) : (double)x[u]);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < kU; ++u) {
+    if (e[u] != -1) continue;
     RowValsT<NV> rv;
     rv.valid = 0;
 #pragma unroll
@@ -261,14 +310,7 @@ __device__ __forceinline__ void consume(const AggParams& p, const Lds<K32>& t, b
       rv.v[v] = b.val[v][u];
       rv.valid |= ((b.vok[v] >> u) & 1u) << v;
     }
-    const KeyT<K32> key = b.key[u];
-    // a 64-bit key equal to the empty marker only lives in the HBM table's extra entry
-    int e = (use_lds && (K32 || key != (KeyT<K32>)kEmptyKey)) ? lds_entry<K32>(t, key, n_entries) : -1;
-    if (e < 0) { global_update(p, (uint64_t)key, rv); continue; }
-    for (int s = 0; s < p.n_slots; ++s) {
-      long long x;
-      if (slot_input(p, s, rv, x)) atomic_apply(&t.state[s * t.S + e], p.slots[s].op, x);
-    }
+    global_update(p, (uint64_t)b.key[u], rv);
   }
 }
 
