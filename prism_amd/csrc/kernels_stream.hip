@@ -41,12 +41,17 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
 template <bool K32>
 using KeyT = std::conditional_t<K32, uint32_t, uint64_t>;
 
+// The workgroup's LDS table.  It is split into 2^rep_log2 replicas of S >> rep_log2
+// entries each; a lane uses the replica picked by its lane number.  Rows of a hot
+// group that meet in one wave instruction then update different addresses instead of
+// serialising on one (LDS atomics to the same address are applied one lane at a
+// time), at the price of holding each group up to 2^rep_log2 times.
 template <bool K32>
 struct Lds {
   long long* state;   // [n_slots][S]
   KeyT<K32>* keys;    // [S]
   int S;
-  int hash_shift;     // 32 - log2(S)
+  int rep_log2;
 };
 
 template <int NK, int NV>
@@ -205,9 +210,9 @@ __device__ __forceinline__ void convert(const AggParams& p, const RowBatch<NK, N
       const int bit_pos = ks.bit_pos, null_bit = ks.null_bit;
       const KeyT<K32> null_field = null_bit >= 0 ? ((KeyT<K32>)1 << null_bit) : (KeyT<K32>)0;
       KeyT<K32> field;
-      if (K32 && ks.fast32) {
-        // plain columns and 32-bit date_bin alike: (value - base) / divisor, divisor 1 for
-        // a plain column
+      if (K32) {
+        // every key of a K32 plan has the 32-bit form: (value - base) / divisor, with
+        // divisor 1 for a plain column and the stride for date_bin
         field = fast_div32(widen_lo(b.kraw[k][u], ks.width, ks.is_unsigned) - (uint32_t)ks.base, ks.magic32, ks.pre32,
                            ks.shift32);
       } else {
@@ -230,18 +235,23 @@ __device__ __forceinline__ void convert(const AggParams& p, const RowBatch<NK, N
 template <bool K32>
 __device__ __forceinline__ int lds_entry(const Lds<K32>& t, KeyT<K32> key, int* n_entries) {
   const KeyT<K32> empty = (KeyT<K32>)~(KeyT<K32>)0;
-  const int mask = t.S - 1;
+  const int sub = t.S >> t.rep_log2;  // entries per replica
+  const int mask = sub - 1;
+  // replicas are interleaved (entry = slot * replicas + replica) so that the copies of
+  // one group sit in neighbouring banks rather than in the same one
+  const int rep = (int)(threadIdx.x & ((1u << t.rep_log2) - 1u));
   uint32_t mixed = K32 ? (uint32_t)key : ((uint32_t)key ^ (uint32_t)((uint64_t)key >> 32));
-  int h = (int)((mixed * 0x9E3779B1u) >> t.hash_shift) & mask;
+  int h = (int)((mixed * 0x9E3779B1u) >> 12) & mask;
   for (int probe = 0; probe < kLdsProbes; ++probe) {
-    KeyT<K32> k = t.keys[h];
-    if (k == key) return h;
+    const int e = (h << t.rep_log2) + rep;
+    KeyT<K32> k = t.keys[e];
+    if (k == key) return e;
     if (k == empty) {
       KeyT<K32> old;
-      if (K32) old = (KeyT<K32>)atomicCAS((unsigned int*)&t.keys[h], 0xffffffffu, (unsigned int)key);
-      else old = (KeyT<K32>)atomicCAS((unsigned long long*)&t.keys[h], ~0ull, (unsigned long long)key);
-      if (old == empty) { atomicAdd(n_entries, 1); return h; }
-      if (old == key) return h;
+      if (K32) old = (KeyT<K32>)atomicCAS((unsigned int*)&t.keys[e], 0xffffffffu, (unsigned int)key);
+      else old = (KeyT<K32>)atomicCAS((unsigned long long*)&t.keys[e], ~0ull, (unsigned long long)key);
+      if (old == empty) { atomicAdd(n_entries, 1); return e; }
+      if (old == key) return e;
     }
     h = (h + 1) & mask;
   }
@@ -346,9 +356,10 @@ __global__ __launch_bounds__(kBlock) void k_group_by_stream(AggParams p) {
   extern __shared__ unsigned long long lds_raw[];
   __shared__ int n_entries;
   __shared__ int bypass;
+  constexpr int kInitialRepLog2 = 0;
   Lds<K32> t;
   t.S = p.lds_slots;
-  t.hash_shift = 32 - (31 - __builtin_clz((unsigned)t.S));
+  t.rep_log2 = kInitialRepLog2;
   t.state = (long long*)lds_raw;
   t.keys = (KeyT<K32>*)(lds_raw + (size_t)p.n_slots * t.S);
   if (threadIdx.x == 0) { n_entries = 0; bypass = 0; }
@@ -383,10 +394,14 @@ __global__ __launch_bounds__(kBlock) void k_group_by_stream(AggParams p) {
       __syncthreads();
       if (n > t.S / 2) {
         lds_flush<K32>(p, t);
-        if (threadIdx.x == 0) {
-          if ((uint64_t)n * 4 > rows_since_flush) bypass = 1;
-          n_entries = 0;
+        // The table filled up: keep fewer copies of each group from here on, and give up
+        // on LDS altogether if even a single copy sees hardly any repeats.
+        if (t.rep_log2 > 0) {
+          t.rep_log2 -= 1;
+        } else if (threadIdx.x == 0 && (uint64_t)n * 4 > rows_since_flush) {
+          bypass = 1;
         }
+        if (threadIdx.x == 0) n_entries = 0;
         rows_since_flush = 0;
         __syncthreads();
         use_lds = bypass == 0;
@@ -423,7 +438,8 @@ GroupByKernel pick_nk(int nk, int nv) {
 }  // namespace
 
 GroupByKernel pick_stream_kernel(const AggParams& p, size_t* lds_bytes) {
-  const bool k32 = p.key_bits <= 31;
+  bool k32 = p.key_bits <= 31;
+  for (int k = 0; k < p.n_keys; ++k) k32 = k32 && p.keys[k].fast32 != 0;
   *lds_bytes = (size_t)p.lds_slots * (8 * (size_t)p.n_slots + (k32 ? 4 : 8));
   return k32 ? pick_nk<true>(p.n_keys, p.n_vals) : pick_nk<false>(p.n_keys, p.n_vals);
 }
