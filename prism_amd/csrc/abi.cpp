@@ -80,6 +80,7 @@ void prism_gpu_ctx_free(prism_gpu_ctx* ctx) {
     if (ctx->stage[i]) (void)hipHostFree(ctx->stage[i]);
     if (ctx->stage_done[i]) (void)hipEventDestroy(ctx->stage_done[i]);
   }
+  if (ctx->result_pinned) (void)hipHostFree(ctx->result_pinned);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   delete ctx;

@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <type_traits>
 
 namespace prism {
 
@@ -41,9 +42,25 @@ std::vector<FieldType> parse_schema(const ArrowSchema* schema) {
   return out;
 }
 
+void OutColumn::gather(const std::vector<size_t>& idx) {
+  auto take = [&](auto& v) {
+    if (v.empty()) return;
+    typename std::remove_reference<decltype(v)>::type out;
+    out.reserve(idx.size());
+    for (size_t i : idx) out.push_back(std::move(v[i]));
+    v.swap(out);
+  };
+  take(i64);
+  take(f64);
+  take(str);
+  take(codes);
+  take(valid);
+}
+
 void OutColumn::push_null() {
   valid.push_back(0);
-  if (type.is_string) str.emplace_back();
+  if (type.is_string && dict) codes.push_back(0);
+  else if (type.is_string) str.emplace_back();
   else if (type.is_float) f64.push_back(0.0);
   else i64.push_back(0);
 }
@@ -68,9 +85,9 @@ struct BatchOwner {
   std::vector<ArrowArray*> child_ptrs;
   const void* struct_buffers[1] = {nullptr};
 
-  uint8_t* block(size_t bytes) {
+  uint8_t* block(size_t bytes, bool zero = true) {
     blocks.emplace_back(new uint8_t[bytes + 64]);
-    std::memset(blocks.back().get(), 0, bytes + 64);
+    if (zero) std::memset(blocks.back().get(), 0, bytes + 64);
     return blocks.back().get();
   }
 };
@@ -105,34 +122,40 @@ void export_record_batch(std::vector<OutColumn>& cols, ArrowArray* out) {
     ArrowArray& a = owner->children[c];
     std::memset(&a, 0, sizeof(a));
     int64_t nulls = 0;
-    uint8_t* bits = owner->block((n + 7) / 8);
-    for (size_t i = 0; i < n; ++i) {
-      if (col.valid[i]) bits[i >> 3] |= (uint8_t)(1u << (i & 7));
-      else ++nulls;
+    uint8_t* bits = nullptr;
+    if (n && std::memchr(col.valid.data(), 0, n) != nullptr) {  // bitmap only when there is a NULL
+      bits = owner->block((n + 7) / 8);
+      for (size_t i = 0; i < n; ++i) {
+        if (col.valid[i]) bits[i >> 3] |= (uint8_t)(1u << (i & 7));
+        else ++nulls;
+      }
     }
     auto& bl = owner->buffer_lists[c];
     bl.push_back(nulls ? bits : nullptr);
     if (col.type.is_string) {
       size_t total = 0;
-      for (auto& s : col.str) total += s.size();
+      for (size_t i = 0; i < n; ++i) total += col.valid[i] ? col.str_at(i).size() : 0;
       if (total > 0x7fffffffull) fail(PRISM_GPU_EUNSUPPORTED, "string output exceeds 2 GiB");
       int32_t* off = (int32_t*)owner->block((n + 1) * 4);
       uint8_t* data = owner->block(total);
       size_t pos = 0;
       for (size_t i = 0; i < n; ++i) {
-        std::memcpy(data + pos, col.str[i].data(), col.str[i].size());
-        pos += col.str[i].size();
+        if (col.valid[i]) {
+          const std::string& v = col.str_at(i);
+          std::memcpy(data + pos, v.data(), v.size());
+          pos += v.size();
+        }
         off[i + 1] = (int32_t)pos;
       }
       bl.push_back(off);
       bl.push_back(data);
     } else if (col.type.is_float) {
       double* v = (double*)owner->block(n * 8);
-      for (size_t i = 0; i < n; ++i) v[i] = col.f64[i];
+      if (n) std::memcpy(v, col.f64.data(), n * 8);
       bl.push_back(v);
     } else if (col.type.width == 8) {
       int64_t* v = (int64_t*)owner->block(n * 8);
-      for (size_t i = 0; i < n; ++i) v[i] = col.i64[i];
+      if (n) std::memcpy(v, col.i64.data(), n * 8);
       bl.push_back(v);
     } else if (col.type.width == 4) {
       int32_t* v = (int32_t*)owner->block(n * 4);

@@ -39,12 +39,19 @@ struct OutColumn {
   std::vector<int64_t> i64;        // integer / timestamp values (any width)
   std::vector<double> f64;
   std::vector<std::string> str;
+  // dictionary-coded strings: when `dict` is set the values are (*dict)[codes[i]] and
+  // `str` is unused (large GROUP BY results never materialise one std::string per row)
+  const std::vector<std::string>* dict = nullptr;
+  std::vector<uint32_t> codes;
   std::vector<uint8_t> valid;      // one byte per row
   size_t rows() const { return valid.size(); }
   void push_null();
   void push_int(int64_t v);
   void push_float(double v);
   void push_str(const std::string& s);
+  const std::string& str_at(size_t i) const { return dict ? (*dict)[codes[i]] : str[i]; }
+  // Keeps rows idx[0], idx[1], ... in that order.
+  void gather(const std::vector<size_t>& idx);
 };
 
 OutColumn make_out_column(const std::string& name, const std::string& format, bool nullable);

@@ -2,6 +2,7 @@
 // in HBM, a pinned host staging ring, and HIP-event kernel timing.
 #pragma once
 
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -30,6 +31,11 @@ struct prism_gpu_ctx {
   hipEvent_t stage_done[2] = {nullptr, nullptr};
   bool stage_busy[2] = {false, false};
   int stage_next = 0;
+
+  // ---- pinned landing buffer for results read back from HBM ----
+  std::mutex result_mu;
+  void* result_pinned = nullptr;
+  size_t result_pinned_bytes = 0;
 
   // ---- profiling ----
   bool profiling = false;
@@ -157,6 +163,21 @@ struct KernelTimer {
     hipEvent_t b = take_event(ctx);
     (void)hipEventRecord(b, ctx->stream);
     ctx->pending.push_back({stat, a, b});
+  }
+};
+
+// Wall-clock time of a host-side phase, reported beside the kernels under a "host:"
+// name (always measured: it costs two clock reads).
+struct HostTimer {
+  prism_gpu_ctx* ctx;
+  const char* name;
+  std::chrono::steady_clock::time_point t0;
+  HostTimer(prism_gpu_ctx* c, const char* n) : ctx(c), name(n), t0(std::chrono::steady_clock::now()) {}
+  ~HostTimer() {
+    double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    std::lock_guard<std::mutex> g(ctx->mu);
+    int i = stat_index(ctx, name);
+    if (i >= 0) { ctx->stats.kernels[i].launches += 1; ctx->stats.kernels[i].total_ms += ms; }
   }
 };
 

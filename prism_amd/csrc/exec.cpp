@@ -439,23 +439,38 @@ struct GroupRows {
 
 int64_t state_at(const GroupRows& g, int slot, uint64_t i) { return g.state[(size_t)slot * g.n + i]; }
 
-void push_key_values(const prism_gpu_table* t, const std::vector<KeySrc>& keys, const KeyLayout& L, size_t first_key,
-                     uint64_t packed, std::vector<OutColumn>& cols, size_t first_col) {
+// Appends the key columns of n groups, column by column (tight loops, no per-row
+// allocation: string keys stay dictionary codes until the Arrow buffers are written).
+void append_key_columns(const prism_gpu_table* t, const std::vector<KeySrc>& keys, const KeyLayout& L, size_t first_key,
+                        const uint64_t* packed, size_t n, std::vector<OutColumn>& cols, size_t first_col) {
   for (size_t i = 0; i < keys.size(); ++i) {
     const KeyField& kf = L.fields[first_key + i];
-    OutColumn& oc = cols[first_col + i];
-    if (kf.null_bit >= 0 && ((packed >> kf.null_bit) & 1ull)) { oc.push_null(); continue; }
-    uint64_t field = kf.bits == 0 ? 0 : ((packed >> kf.bit_pos) & (kf.bits == 64 ? ~0ull : ((1ull << kf.bits) - 1ull)));
-    long long v = (long long)((uint64_t)kf.bias + field);
     const KeySrc& k = keys[i];
-    if (k.date_bin) v = (long long)((uint64_t)k.origin + (uint64_t)v * (uint64_t)k.stride);
     const FieldType& f = t->fields[k.column];
+    OutColumn& oc = cols[first_col + i];
+    const size_t base = oc.rows();
+    const uint64_t mask = kf.bits == 0 ? 0ull : (kf.bits == 64 ? ~0ull : ((1ull << kf.bits) - 1ull));
+    oc.valid.resize(base + n, 1);
+    if (kf.null_bit >= 0)
+      for (size_t r = 0; r < n; ++r) oc.valid[base + r] = ((packed[r] >> kf.null_bit) & 1ull) ? 0 : 1;
     if (f.is_string) {
       const ColumnDict& d = t->dicts[k.column];
-      if ((uint64_t)v >= d.values.size()) fail(PRISM_GPU_EINTERNAL, "dictionary code out of range in result");
-      oc.push_str(d.values[(size_t)v]);
+      if (base == 0) oc.dict = &d.values;
+      if (oc.dict != &d.values) fail(PRISM_GPU_EINTERNAL, "string key column built from two dictionaries");
+      oc.codes.resize(base + n);
+      for (size_t r = 0; r < n; ++r) {
+        uint64_t code = (uint64_t)kf.bias + ((packed[r] >> kf.bit_pos) & mask);
+        if (!oc.valid[base + r]) code = 0;
+        if (code >= d.values.size() && oc.valid[base + r]) fail(PRISM_GPU_EINTERNAL, "dictionary code out of range in result");
+        oc.codes[base + r] = (uint32_t)code;
+      }
     } else {
-      oc.push_int(v);
+      oc.i64.resize(base + n);
+      for (size_t r = 0; r < n; ++r) {
+        long long v = (long long)((uint64_t)kf.bias + ((packed[r] >> kf.bit_pos) & mask));
+        if (k.date_bin) v = (long long)((uint64_t)k.origin + (uint64_t)v * (uint64_t)k.stride);
+        oc.i64[base + r] = oc.valid[base + r] ? v : 0;
+      }
     }
   }
 }
@@ -466,33 +481,46 @@ std::vector<OutColumn> make_columns(const std::vector<FieldType>& fields) {
   return cols;
 }
 
-void push_aggs(const prism_gpu_plan* p, const Lowered& L, const GroupRows& g, uint64_t i, bool partial,
-               std::vector<OutColumn>& cols, size_t c) {
+// Appends the aggregate columns of all groups of g, column by column.
+void append_agg_columns(const Lowered& L, const GroupRows& g, bool partial, std::vector<OutColumn>& cols, size_t c) {
+  const size_t n = (size_t)g.n;
   for (const AggRule& r : L.rules) {
-    int64_t main = state_at(g, r.main_slot, i);
-    int64_t cnt = r.count_slot >= 0 ? state_at(g, r.count_slot, i) : 1;
+    const int64_t* main = g.state.data() + (size_t)r.main_slot * n;
+    const int64_t* cnt = r.count_slot >= 0 ? g.state.data() + (size_t)r.count_slot * n : nullptr;
+    auto append_ints = [&](OutColumn& oc, const int64_t* v, bool nullable) {
+      const size_t base = oc.rows();
+      oc.i64.insert(oc.i64.end(), v, v + n);
+      oc.valid.resize(base + n, 1);
+      if (nullable && cnt)
+        for (size_t i = 0; i < n; ++i) oc.valid[base + i] = cnt[i] > 0;
+    };
+    auto append_floats = [&](OutColumn& oc, bool divide) {
+      const size_t base = oc.rows();
+      oc.f64.resize(base + n);
+      oc.valid.resize(base + n, 1);
+      for (size_t i = 0; i < n; ++i) {
+        double sum;
+        std::memcpy(&sum, &main[i], 8);
+        const int64_t k = cnt ? cnt[i] : 1;
+        oc.valid[base + i] = k > 0;
+        oc.f64[base + i] = k > 0 ? (divide ? sum / (double)k : sum) : 0.0;
+      }
+    };
     switch (r.func) {
       case PRISM_AGG_COUNT_STAR:
-      case PRISM_AGG_COUNT: cols[c++].push_int(main); break;
+      case PRISM_AGG_COUNT: append_ints(cols[c++], main, false); break;
       case PRISM_AGG_SUM:
       case PRISM_AGG_MIN:
-      case PRISM_AGG_MAX:
-        if (cnt > 0) cols[c].push_int(main); else cols[c].push_null();
-        ++c;
-        break;
-      case PRISM_AGG_AVG: {
-        double sum;
-        std::memcpy(&sum, &main, 8);
+      case PRISM_AGG_MAX: append_ints(cols[c++], main, true); break;
+      case PRISM_AGG_AVG:
         if (partial) {
-          cols[c++].push_int(cnt);
-          if (cnt > 0) cols[c].push_float(sum); else cols[c].push_null();
-          ++c;
+          if (cnt) append_ints(cols[c++], cnt, false);
+          else { OutColumn& oc = cols[c++]; oc.i64.resize(oc.i64.size() + n, 1); oc.valid.resize(oc.valid.size() + n, 1); }
+          append_floats(cols[c++], false);
         } else {
-          if (cnt > 0) cols[c].push_float(sum / (double)cnt); else cols[c].push_null();
-          ++c;
+          append_floats(cols[c++], true);
         }
         break;
-      }
     }
   }
 }
@@ -509,7 +537,7 @@ void sort_and_limit(const prism_gpu_plan* p, std::vector<OutColumn>& cols) {
       bool na = !oc.valid[a], nb = !oc.valid[b];
       if (na || nb) return desc ? (na && !nb) : (!na && nb);  // NULLS FIRST for DESC, LAST for ASC
       int c;
-      if (oc.type.is_string) c = oc.str[a].compare(oc.str[b]);
+      if (oc.type.is_string) c = oc.str_at(a).compare(oc.str_at(b));
       else if (oc.type.is_float) c = oc.f64[a] < oc.f64[b] ? -1 : (oc.f64[a] > oc.f64[b] ? 1 : 0);
       else if (uns) c = (uint64_t)oc.i64[a] < (uint64_t)oc.i64[b] ? -1 : ((uint64_t)oc.i64[a] > (uint64_t)oc.i64[b] ? 1 : 0);
       else c = oc.i64[a] < oc.i64[b] ? -1 : (oc.i64[a] > oc.i64[b] ? 1 : 0);
@@ -519,18 +547,7 @@ void sort_and_limit(const prism_gpu_plan* p, std::vector<OutColumn>& cols) {
     else std::stable_sort(idx.begin(), idx.end(), less);
   }
   if (p->limit >= 0 && (size_t)p->limit < idx.size()) idx.resize((size_t)p->limit);
-  std::vector<OutColumn> out;
-  for (auto& c : cols) {
-    OutColumn s = make_out_column(c.type.name, c.type.format, c.type.nullable);
-    for (size_t i : idx) {
-      if (!c.valid[i]) s.push_null();
-      else if (c.type.is_string) s.push_str(c.str[i]);
-      else if (c.type.is_float) s.push_float(c.f64[i]);
-      else s.push_int(c.i64[i]);
-    }
-    out.push_back(std::move(s));
-  }
-  cols.swap(out);
+  for (auto& c : cols) c.gather(idx);
 }
 
 // ---- HBM group tables --------------------------------------------------------------------------
@@ -587,9 +604,29 @@ GroupRows table_read(prism_gpu_ctx* ctx, const GroupTable& g) {
               d_state.as<int64_t>(), n, d_count.as<unsigned long long>());
   rows.keys.resize(n);
   rows.state.resize((size_t)n * g.n_slots);
-  PRISM_HIP(hipMemcpyAsync(rows.keys.data(), d_keys.p, n * 8, hipMemcpyDeviceToHost, ctx->stream));
-  PRISM_HIP(hipMemcpyAsync(rows.state.data(), d_state.p, n * 8 * g.n_slots, hipMemcpyDeviceToHost, ctx->stream));
-  PRISM_HIP(hipStreamSynchronize(ctx->stream));
+  // HBM -> pinned host memory at full PCIe rate, then a plain copy into the vectors
+  const size_t key_bytes = n * 8, state_bytes = n * 8 * (size_t)g.n_slots;
+  if (key_bytes + state_bytes <= (256ull << 20)) {
+    std::lock_guard<std::mutex> lock(ctx->result_mu);
+    if (ctx->result_pinned_bytes < key_bytes + state_bytes) {
+      if (ctx->result_pinned) (void)hipHostFree(ctx->result_pinned);
+      ctx->result_pinned = nullptr;
+      ctx->result_pinned_bytes = 0;
+      size_t want = pow2_ceil(key_bytes + state_bytes);
+      PRISM_HIP(hipHostMalloc(&ctx->result_pinned, want, hipHostMallocDefault));
+      ctx->result_pinned_bytes = want;
+    }
+    uint8_t* pin = (uint8_t*)ctx->result_pinned;
+    PRISM_HIP(hipMemcpyAsync(pin, d_keys.p, key_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PRISM_HIP(hipMemcpyAsync(pin + key_bytes, d_state.p, state_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PRISM_HIP(hipStreamSynchronize(ctx->stream));
+    std::memcpy(rows.keys.data(), pin, key_bytes);
+    std::memcpy(rows.state.data(), pin + key_bytes, state_bytes);
+  } else {
+    PRISM_HIP(hipMemcpyAsync(rows.keys.data(), d_keys.p, key_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PRISM_HIP(hipMemcpyAsync(rows.state.data(), d_state.p, state_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PRISM_HIP(hipStreamSynchronize(ctx->stream));
+  }
   return rows;
 }
 
@@ -607,6 +644,7 @@ void execute_plan(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
                   bool merge_input, ArrowArray* out) {
   prism_gpu_ctx* ctx = plan->ctx;
   bind(ctx);
+  HostTimer whole(ctx, "host:execute");
   if (table->ctx != ctx) fail(PRISM_GPU_EINVAL, "plan and table belong to different contexts");
   const std::vector<FieldType>& expect = merge_input ? plan->partial_fields : plan->fields;
   if (table->fields.size() != expect.size()) fail(PRISM_GPU_EINVAL, "table schema does not match the plan's input schema");
@@ -767,7 +805,7 @@ void execute_plan(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
     g.state.resize(ap.n_slots);
     PRISM_HIP(hipMemcpyAsync(g.state.data(), d_out.p, g.state.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
     PRISM_HIP(hipStreamSynchronize(ctx->stream));
-    push_aggs(plan, low, g, 0, partial, cols, 0);
+    append_agg_columns(low, g, partial, cols, 0);
     groups_out = 1;
   } else {
     // ---- GROUP BY ----
@@ -787,7 +825,10 @@ void execute_plan(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
                                                                                          : std::min<uint64_t>(bound, 1ull << 24))));
     const uint64_t max_capacity = pow2_ceil(std::max<uint64_t>(1024, 2 * bound));
     for (;;) {
-      table_alloc(ctx, gt, dense, capacity, slot_ops);
+      {
+        HostTimer ht(ctx, "host:table_alloc");
+        table_alloc(ctx, gt, dense, capacity, slot_ops);
+      }
       ap.dense = dense ? 1 : 0;
       ap.capacity = capacity;
       ap.g_keys = gt.keys.as<uint64_t>();
@@ -799,19 +840,20 @@ void execute_plan(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       capacity = std::min(max_capacity, capacity * 8);  // more groups than expected: grow and redo the pass
     }
     if (!plan->distinct_plan) {
-      GroupRows g = table_read(ctx, gt);
-      for (uint64_t i = 0; i < g.n; ++i) {
-        push_key_values(table, keys, layout, 0, g.keys[i], cols, 0);
-        push_aggs(plan, low, g, i, partial, cols, keys.size());
+      GroupRows g;
+      {
+        HostTimer ht(ctx, "host:read_groups");
+        g = table_read(ctx, gt);
       }
+      HostTimer ht(ctx, "host:assemble");
+      append_key_columns(table, keys, layout, 0, g.keys.data(), (size_t)g.n, cols, 0);
+      append_agg_columns(low, g, partial, cols, keys.size());
       groups_out = g.n;
     } else if (partial) {
       // inner GROUP BY (keys, x): one row per distinct pair
       GroupRows g = table_read(ctx, gt);
-      for (uint64_t i = 0; i < g.n; ++i) {
-        push_key_values(table, keys, layout, 1, g.keys[i], cols, 0);
-        push_key_values(table, {distinct_src}, layout, 0, g.keys[i], cols, keys.size());
-      }
+      append_key_columns(table, keys, layout, 1, g.keys.data(), (size_t)g.n, cols, 0);
+      append_key_columns(table, {distinct_src}, layout, 0, g.keys.data(), (size_t)g.n, cols, keys.size());
       groups_out = g.n;
     } else {
       // outer GROUP BY keys: COUNT(x) over the distinct pairs
@@ -858,9 +900,12 @@ void execute_plan(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
         if (f.null_bit >= 0) f.null_bit -= x_bits;
         kl.fields.push_back(f);
       }
-      for (uint64_t i = 0; i < g.n; ++i) {
-        push_key_values(table, keys, kl, 0, g.keys[i], cols, 0);
-        for (size_t a = 0; a < plan->aggs.size(); ++a) cols[keys.size() + a].push_int(state_at(g, 1, i));
+      append_key_columns(table, keys, kl, 0, g.keys.data(), (size_t)g.n, cols, 0);
+      for (size_t a = 0; a < plan->aggs.size(); ++a) {
+        OutColumn& oc = cols[keys.size() + a];
+        const int64_t* v = g.state.data() + (size_t)g.n;  // slot 1 = distinct count
+        oc.i64.insert(oc.i64.end(), v, v + g.n);
+        oc.valid.resize(oc.valid.size() + g.n, 1);
       }
       groups_out = g.n;
     }
@@ -874,6 +919,7 @@ void execute_plan(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
     ctx->stats.rows_selected += selected;
     ctx->stats.groups_out += groups_out;
   }
+  HostTimer ht(ctx, "host:export");
   export_record_batch(cols, out);
 }
 
