@@ -156,8 +156,15 @@ def main() -> int:
             groups = result.num_rows if wl.n_keys else 1
             alg = rows * wl.bytes_per_row + (groups * wl.bytes_per_group if world == 1 else 0)
             achieved = alg / avg_s / 1e9
+            traffic = None
+            try:  # HBM bytes per launch from the committed PMC profile of this exact configuration
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r1", f"{wl.name.lower()}_1b_traffic.json")))
+                if tj["config"]["rows_per_gpu"] == rows and tj["config"]["partitions_per_gpu"] == parts and world == 1:
+                    traffic = tj["hbm_bytes_per_launch"]
+            except (OSError, KeyError, ValueError):
+                pass
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kname,
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
                         "kernel_avg_ms": avg_s * 1e3, "algorithmic_bytes_per_launch": alg}
         ms_per_step = elapsed / args.steps * 1e3
         line = {
