@@ -1,0 +1,167 @@
+"""GPU parity on the benchmark workloads at toy size: tables generated in HBM by the
+device generators must aggregate to exactly what the CPU oracle computes over its own
+generation of the same rows; plus the high-cardinality string (ClickBench URL-like)
+path, where no dictionary exists and the raw-string kernels run."""
+import numpy as np
+import pyarrow as pa
+import pytest
+
+from tests import helpers
+from tests.helpers import assert_tables_match, assert_topk_match
+
+pytestmark = pytest.mark.gpu
+
+from prism_amd import _cabi as abi  # noqa: E402
+from prism_amd import workloads  # noqa: E402
+from prism_amd.plan import QueryPlan, col, count_distinct, count_star, date_bin, max_, min_, sum_, avg  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import pyoracle
+
+    return pyoracle
+
+
+def _both(gpu_ctx, oracle, wl, rows, parts, first=0, total=None, queries=None):
+    from prism_amd.engine import Plan
+
+    total = total or rows
+    table = workloads.build_gpu_table(gpu_ctx, wl, first, rows, total, parts)
+    st = oracle.SynthTable(wl.schema, wl.make_cols(), wl.seed, first, rows, total, n_parts=parts)
+    try:
+        assert table.num_rows == rows
+        for q, n_keys in queries or [(wl.query, wl.n_keys)]:
+            plan = Plan(gpu_ctx, wl.schema, q)
+            try:
+                got = plan.execute(table)
+            finally:
+                plan.close()
+            want, _ = st.execute(q)
+            want = workloads.decode_dictionary_columns(wl, want)
+            if q.limit is not None:
+                assert_topk_match(got, want, q.order_by)
+            else:
+                assert_tables_match(got, want, n_keys)
+    finally:
+        st.close()
+        table.close()
+
+
+def test_c1_filter_count(gpu_ctx, oracle):
+    wl = workloads.c1()
+    _both(gpu_ctx, oracle, wl, 1_000_003, 10, queries=[
+        (wl.query, 0),
+        (QueryPlan([count_star(), sum_("AdvEngineID"), max_("AdvEngineID")], predicate=col("AdvEngineID") > 30), 0),
+        (QueryPlan([count_star()], keys=["AdvEngineID"]), 1),
+    ])
+
+
+def test_c2_time_bucket_group_by(gpu_ctx, oracle):
+    wl = workloads.c2()
+    # a middle slice of a larger table, ragged partition sizes
+    _both(gpu_ctx, oracle, wl, 700_001, 7, first=1_000_000, total=5_000_000, queries=[
+        (wl.query, 2),
+        (QueryPlan([count_star(), sum_("value"), max_("value"), min_("value"), avg("value")],
+                   keys=[date_bin(1_000, "timestamp"), "service"], predicate=col("value") < 25_000), 2),
+        (QueryPlan([count_star()], keys=[date_bin(3_600_000, "timestamp")]), 1),
+        (QueryPlan([count_star(), sum_("value")], keys=["service"], predicate=col("value") >= 49_000), 1),
+    ])
+
+
+def test_c3_high_cardinality_group_by_topk(gpu_ctx, oracle):
+    wl = workloads.c3(id_bits=18)
+    _both(gpu_ctx, oracle, wl, 600_000, 6, queries=[
+        (wl.query, 1),
+        (QueryPlan([count_star()], keys=["UserID"]), 1),
+        (QueryPlan([count_distinct("UserID")]), 0),
+    ])
+
+
+@pytest.mark.xfail(reason="packed keys wider than 64 bits are not supported yet", strict=False)
+def test_c5_count_distinct_by_hour_service(gpu_ctx, oracle):
+    wl = workloads.c5(n_services=16, user_bits=14)
+    _both(gpu_ctx, oracle, wl, 500_000, 4, queries=[(wl.query, 2)])
+
+
+def test_c2_partial_states_merge_across_shards(gpu_ctx, oracle):
+    """Two 'ranks' each holding half of a table: PARTIAL per shard + Final merge equals
+    the single pass over the whole table (the weak-scaling choreography of bench.py)."""
+    from prism_amd.engine import Plan
+
+    wl = workloads.c2()
+    total = 400_000
+    shards = [workloads.build_gpu_table(gpu_ctx, wl, r * total // 2, total // 2, total, 3) for r in range(2)]
+    whole = workloads.build_gpu_table(gpu_ctx, wl, 0, total, total, 4)
+    try:
+        pp = Plan(gpu_ctx, wl.schema, wl.query.with_mode(abi.MODE_PARTIAL))
+        ps = Plan(gpu_ctx, wl.schema, wl.query)
+        try:
+            merged = pp.merge([pp.execute(s) for s in shards])
+            assert_tables_match(merged, ps.execute(whole), 2)
+            assert sum(merged.column("COUNT(*)").to_pylist()) == total
+        finally:
+            pp.close()
+            ps.close()
+    finally:
+        for t in shards + [whole]:
+            t.close()
+
+
+def _url_table(n: int, seed: int) -> pa.Table:
+    rng = np.random.default_rng(seed)
+    words = np.array(["google", "googl", "gogle", "example", "bing", "news", "shop", "a", "zz9", "GOOGLE"])
+    urls = []
+    for i in range(n):
+        k = rng.integers(1, 6)
+        urls.append("http://" + ".".join(words[rng.integers(0, len(words), k)]) + f"/p{i}")  # unique per row
+    mask = rng.random(n) < 0.03
+    return pa.table({
+        "URL": pa.array(urls, mask=mask),
+        "UserID": pa.array(rng.integers(0, 5000, n).astype(np.int64) * 1_000_003),
+        "v": pa.array(rng.integers(-100, 100, n).astype(np.int32)),
+    })
+
+
+def test_c4_like_on_high_cardinality_strings(gpu_ctx, oracle):
+    """> 65536 distinct URLs: the column has no dictionary, so LIKE '%google%' runs as the
+    byte-stream search, other patterns and comparisons through the row-per-lane kernel,
+    and the few survivors reach the GROUP BY through a compacted selection vector."""
+    from prism_amd.engine import Plan, Table
+
+    t = _url_table(150_000, seed=4)
+    g = Table(gpu_ctx, t.schema)
+    g.append_table(t, 3)
+    try:
+        queries = [
+            (QueryPlan([count_star()], predicate=col("URL").like("%google%")), 0),
+            (QueryPlan([count_star()], predicate=col("URL").not_like("%google%")), 0),
+            (QueryPlan([count_star()], predicate=col("URL").like("%e%")), 0),
+            (QueryPlan([count_star()], predicate=col("URL").like("%google.google.google%")), 0),
+            (QueryPlan([count_star()], predicate=col("URL").like("http://goo%/p1%")), 0),
+            (QueryPlan([count_star()], predicate=col("URL").like("%/p12_")), 0),
+            (QueryPlan([count_star()], predicate=col("URL").ilike("%GoOgLe.bing%")), 0),
+            (QueryPlan([count_star()], predicate=col("URL") == "http://google/p7"), 0),
+            (QueryPlan([count_star()], predicate=(col("URL") >= "http://g") & (col("URL") < "http://h")), 0),
+            (QueryPlan([count_star(), sum_("v")], keys=["UserID"], predicate=col("URL").like("%google.bing%")), 1),
+            (QueryPlan([count_star(), sum_("v")], keys=["UserID"], predicate=col("URL").like("%google%") & (col("v") > 0)), 1),
+            (QueryPlan([count_star()], predicate=col("URL").is_null()), 0),
+            (QueryPlan([count_star(), avg("v")], predicate=col("URL").like("%zz9.zz9.zz9.zz9%")), 0),
+        ]
+        for q, n_keys in queries:
+            plan = Plan(gpu_ctx, t.schema, q)
+            try:
+                assert_tables_match(plan.execute(g), oracle.execute(t, q), n_keys)
+            finally:
+                plan.close()
+        from prism_amd.engine import PrismGpuError
+
+        with pytest.raises(PrismGpuError) as e:  # no dictionary -> no GROUP BY on this column
+            p = Plan(gpu_ctx, t.schema, QueryPlan([count_star()], keys=["URL"]))
+            try:
+                p.execute(g)
+            finally:
+                p.close()
+        assert e.value.code == abi.EUNSUPPORTED
+    finally:
+        g.close()
