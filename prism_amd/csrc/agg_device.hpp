@@ -69,7 +69,8 @@ __device__ __forceinline__ uint64_t global_entry(const AggParams& p, uint64_t ke
   if (key == kEmptyKey) return p.capacity;
   uint64_t mask = p.capacity - 1;
   uint64_t h = hash64(key) & mask;
-  for (uint64_t probe = 0; probe < p.capacity; ++probe) {
+  const uint64_t max_probes = p.capacity < 4096 ? p.capacity : 4096;  // far beyond any chain at load <= 0.5
+  for (uint64_t probe = 0; probe < max_probes; ++probe) {
     unsigned long long k = p.g_keys[h];
     if (k == key) return h;
     if (k == kEmptyKey) {
@@ -80,6 +81,43 @@ __device__ __forceinline__ uint64_t global_entry(const AggParams& p, uint64_t ke
   }
   *p.overflow = 1u;
   return ~0ull;
+}
+
+// Two-word keys.  The low word claims the entry with a CAS; the winner then publishes
+// the high word, which starts as all ones ("not written yet"; the planner keeps both
+// words below all ones).  A lane that finds its low word in an entry whose high word
+// is still unwritten simply runs the same probe again: the winner's store sits earlier
+// in the loop body than that re-read, so lanes of one wave cannot wait on each other
+// forever, and device-scope loads and stores make it visible across CUs.
+__device__ __forceinline__ uint64_t global_entry2(const AggParams& p, uint64_t lo, uint64_t hi) {
+  const uint64_t mask = p.capacity - 1;
+  uint64_t h = hash64(lo ^ hash64(hi)) & mask;
+  const uint64_t max_probes = p.capacity < 4096 ? p.capacity : 4096;
+  uint64_t probes = 0, result = ~0ull;
+  bool done = false;
+  while (!done) {
+    bool retry = false;
+    unsigned long long k = __hip_atomic_load((unsigned long long*)&p.g_keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k == kEmptyKey) {
+      unsigned long long old = atomicCAS((unsigned long long*)&p.g_keys[h], kEmptyKey, lo);
+      if (old == kEmptyKey) {
+        __hip_atomic_store((unsigned long long*)&p.g_keys_hi[h], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        result = h;
+        done = true;
+      }
+      k = old;
+    }
+    if (!done && k == lo) {
+      unsigned long long kh = __hip_atomic_load((unsigned long long*)&p.g_keys_hi[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (kh == hi) { result = h; done = true; }
+      else if (kh == kEmptyKey) retry = true;
+    }
+    if (!done && !retry) {
+      h = (h + 1) & mask;
+      if (++probes >= max_probes) { *p.overflow = 1u; done = true; }
+    }
+  }
+  return result;
 }
 
 template <int N>

@@ -127,19 +127,28 @@ struct KeySrc {
   int64_t stride, origin;
 };
 
-struct KeyField {  // how to unpack one key from the packed word
-  int bit_pos = 0, bits = 0, null_bit = -1;
+struct KeyField {  // how to unpack one key from the packed key
+  int word = 0, bit_pos = 0, bits = 0, null_bit = -1;
   long long bias = 0;
 };
 
 struct KeyLayout {
   std::vector<KeySpec> specs;
   std::vector<KeyField> fields;
-  int total_bits = 0;
+  int total_bits = 0;   // bits in use when the key is one word
+  int words = 1;        // 1 or 2
+  int word_bits[2] = {0, 0};
 };
 
-// Packs the given key sources starting at bit `cursor`.
-void layout_keys(ScanSet& ss, const prism_gpu_table* t, const std::vector<KeySrc>& keys, int& cursor, KeyLayout& L) {
+// Where the next key field goes: the packed key is one or two 64-bit words and a field
+// never straddles them.
+struct KeyCursor {
+  int bit[2] = {0, 0};   // bits used in each word
+  bool closed0 = false;  // nothing more may go into word 0
+};
+
+// Packs the given key sources from `cur` on.
+void layout_keys(ScanSet& ss, const prism_gpu_table* t, const std::vector<KeySrc>& keys, KeyCursor& cur, KeyLayout& L) {
   for (const KeySrc& k : keys) {
     const FieldType& f = t->fields[k.column];
     if (f.is_string && !t->dicts[k.column].alive)
@@ -178,18 +187,44 @@ void layout_keys(ScanSet& ss, const prism_gpu_table* t, const std::vector<KeySrc
     KeyField kf;
     kf.bits = bits_for((uint64_t)vmax - (uint64_t)vmin);
     kf.bias = vmin;
-    kf.bit_pos = kf.bits ? cursor : 0;
-    cursor += kf.bits;
-    if (ci.nulls) kf.null_bit = cursor++;
+    const int need = kf.bits + (ci.nulls ? 1 : 0);
+    // first fit: word 0 while the field fits there (64 bits when it is the only word in
+    // use, 63 once a second word exists), else word 1
+    int w;
+    if (!cur.closed0 && cur.bit[0] + need <= (cur.bit[1] ? 63 : 64)) w = 0;
+    else if (cur.bit[1] + need <= 63 && cur.bit[0] <= 63) w = 1;
+    else fail(PRISM_GPU_EUNSUPPORTED, "GROUP BY key does not fit two 63-bit words");
+    kf.word = w;
+    kf.bit_pos = kf.bits ? cur.bit[w] : 0;
+    cur.bit[w] += kf.bits;
+    if (ci.nulls) kf.null_bit = cur.bit[w]++;
     s.bias = kf.bias;
     s.bit_pos = kf.bit_pos;
     s.null_bit = kf.null_bit;
+    s.word = kf.word;
     L.specs.push_back(s);
     L.fields.push_back(kf);
   }
-  L.total_bits = cursor;
-  if (cursor > 64)
-    fail(PRISM_GPU_EUNSUPPORTED, "GROUP BY key needs " + std::to_string(cursor) + " bits; at most 64 are supported");
+  L.word_bits[0] = cur.bit[0];
+  L.word_bits[1] = cur.bit[1];
+  L.words = (cur.bit[1] > 0 || cur.closed0) ? 2 : 1;
+  L.total_bits = L.words == 1 ? cur.bit[0] : 128;
+}
+
+// Bits the keys would take in one word (fields plus NULL bits).
+int key_bits_needed(ScanSet& ss, const prism_gpu_table* t, const std::vector<KeySrc>& keys) {
+  int bits = 0;
+  for (const KeySrc& k : keys) {
+    ColInfo ci = col_info(ss, k.column);
+    long long vmin = 0, vmax = 0;
+    if (ci.min <= ci.max) {
+      vmin = ci.min;
+      vmax = ci.max;
+      if (k.date_bin) { vmin = bucket_number_host(ci.min, k.stride, k.origin); vmax = bucket_number_host(ci.max, k.stride, k.origin); }
+    }
+    bits += bits_for((uint64_t)vmax - (uint64_t)vmin) + (ci.nulls ? 1 : 0);
+  }
+  return bits;
 }
 
 struct SlotSrc {
@@ -432,7 +467,8 @@ struct PredEval {
 // ---- result assembly ---------------------------------------------------------------------
 
 struct GroupRows {
-  std::vector<uint64_t> keys;   // packed
+  std::vector<uint64_t> keys;   // packed (low word)
+  std::vector<uint64_t> keys_hi;  // high word of two-word keys, else empty
   std::vector<int64_t> state;   // slot-major, n groups each
   uint64_t n = 0;
 };
@@ -442,9 +478,11 @@ int64_t state_at(const GroupRows& g, int slot, uint64_t i) { return g.state[(siz
 // Appends the key columns of n groups, column by column (tight loops, no per-row
 // allocation: string keys stay dictionary codes until the Arrow buffers are written).
 void append_key_columns(const prism_gpu_table* t, const std::vector<KeySrc>& keys, const KeyLayout& L, size_t first_key,
-                        const uint64_t* packed, size_t n, std::vector<OutColumn>& cols, size_t first_col) {
+                        const GroupRows& g, std::vector<OutColumn>& cols, size_t first_col) {
+  const size_t n = (size_t)g.n;
   for (size_t i = 0; i < keys.size(); ++i) {
     const KeyField& kf = L.fields[first_key + i];
+    const uint64_t* packed = kf.word ? g.keys_hi.data() : g.keys.data();
     const KeySrc& k = keys[i];
     const FieldType& f = t->fields[k.column];
     OutColumn& oc = cols[first_col + i];
@@ -558,11 +596,19 @@ struct GroupTable {
   bool dense = false;
   uint64_t capacity = 0;
   int n_slots = 0;
-  Scratch keys, state, overflow;
+  int key_words = 1;
+  Scratch keys, keys_hi, state, overflow;
 };
 
-void table_alloc(prism_gpu_ctx* ctx, GroupTable& g, bool dense, uint64_t capacity, const std::vector<int>& slot_ops) {
+void table_alloc(prism_gpu_ctx* ctx, GroupTable& g, bool dense, uint64_t capacity, const std::vector<int>& slot_ops,
+                 int key_words = 1) {
   g.dense = dense;
+  g.key_words = key_words;
+  g.keys_hi = Scratch();
+  if (key_words == 2) {
+    g.keys_hi = Scratch(ctx, (capacity + 1) * 8);
+    PRISM_HIP(hipMemsetAsync(g.keys_hi.p, 0xff, (capacity + 1) * 8, ctx->stream));
+  }
   g.capacity = capacity;
   g.n_slots = (int)slot_ops.size();
   g.state = Scratch(ctx, (capacity + 1) * 8 * slot_ops.size());
@@ -591,17 +637,23 @@ GroupRows table_read(prism_gpu_ctx* ctx, const GroupTable& g) {
   GroupRows rows;
   Scratch d_count(ctx, 256);
   PRISM_HIP(hipMemsetAsync(d_count.p, 0, 8, ctx->stream));
-  launch_emit(ctx, g.dense, g.capacity, g.keys.as<uint64_t>(), g.state.as<int64_t>(), g.n_slots, nullptr, nullptr, 0,
-              d_count.as<unsigned long long>());
+  launch_emit(ctx, g.dense, g.capacity, g.keys.as<uint64_t>(), g.keys_hi.as<uint64_t>(), g.state.as<int64_t>(),
+              g.n_slots, nullptr, nullptr, nullptr, 0, d_count.as<unsigned long long>());
   unsigned long long n = 0;
   PRISM_HIP(hipMemcpyAsync(&n, d_count.p, 8, hipMemcpyDeviceToHost, ctx->stream));
   PRISM_HIP(hipStreamSynchronize(ctx->stream));
   rows.n = n;
   if (n == 0) return rows;
-  Scratch d_keys(ctx, n * 8), d_state(ctx, n * 8 * g.n_slots);
+  Scratch d_keys(ctx, n * 8), d_state(ctx, n * 8 * g.n_slots), d_keys_hi;
+  if (g.key_words == 2) d_keys_hi = Scratch(ctx, n * 8);
   PRISM_HIP(hipMemsetAsync(d_count.p, 0, 8, ctx->stream));
-  launch_emit(ctx, g.dense, g.capacity, g.keys.as<uint64_t>(), g.state.as<int64_t>(), g.n_slots, d_keys.as<uint64_t>(),
-              d_state.as<int64_t>(), n, d_count.as<unsigned long long>());
+  launch_emit(ctx, g.dense, g.capacity, g.keys.as<uint64_t>(), g.keys_hi.as<uint64_t>(), g.state.as<int64_t>(),
+              g.n_slots, d_keys.as<uint64_t>(), d_keys_hi.as<uint64_t>(), d_state.as<int64_t>(), n,
+              d_count.as<unsigned long long>());
+  if (g.key_words == 2) {
+    rows.keys_hi.resize(n);
+    PRISM_HIP(hipMemcpyAsync(rows.keys_hi.data(), d_keys_hi.p, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  }
   rows.keys.resize(n);
   rows.state.resize((size_t)n * g.n_slots);
   // HBM -> pinned host memory at full PCIe rate, then a plain copy into the vectors
@@ -689,12 +741,14 @@ void execute_plan(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
   AggParams ap;
   std::memset(&ap, 0, sizeof(ap));
   KeyLayout layout;
-  int cursor = 0;
+  KeyCursor cursor;
   if (!ss.chunks.empty()) {
-    if (plan->distinct_plan) layout_keys(ss, table, {distinct_src}, cursor, layout);
-    const int x_bits = cursor;
+    if (plan->distinct_plan) {
+      layout_keys(ss, table, {distinct_src}, cursor, layout);
+      // (x, keys) beyond one word: x alone in the low word, the group key in the high one
+      if (cursor.bit[0] + key_bits_needed(ss, table, keys) > 64) cursor.closed0 = true;
+    }
     layout_keys(ss, table, keys, cursor, layout);
-    (void)x_bits;
     fill_slots(table, ss, low, ap);
   }
 
@@ -816,6 +870,7 @@ void execute_plan(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
     for (size_t i = 0; i < layout.specs.size(); ++i) ap.keys[i] = layout.specs[i];
     ap.lds_slots = lds_slots_for(ap.n_slots);
     ap.key_bits = total_bits;
+    ap.key_words = layout.words;
     uint64_t bound = selected;
     if (total_bits < 63) bound = std::min<uint64_t>(bound, 1ull << total_bits);
     GroupTable gt;
@@ -827,11 +882,12 @@ void execute_plan(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
     for (;;) {
       {
         HostTimer ht(ctx, "host:table_alloc");
-        table_alloc(ctx, gt, dense, capacity, slot_ops);
+        table_alloc(ctx, gt, dense, capacity, slot_ops, layout.words);
       }
       ap.dense = dense ? 1 : 0;
       ap.capacity = capacity;
       ap.g_keys = gt.keys.as<uint64_t>();
+      ap.g_keys_hi = gt.keys_hi.as<uint64_t>();
       ap.g_state = gt.state.as<int64_t>();
       ap.overflow = gt.overflow.as<uint32_t>();
       launch_group_by(ctx, ap, (ap.row_mode == kRowsSelvec ? selected : ss.rows) * value_bytes);
@@ -846,26 +902,28 @@ void execute_plan(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
         g = table_read(ctx, gt);
       }
       HostTimer ht(ctx, "host:assemble");
-      append_key_columns(table, keys, layout, 0, g.keys.data(), (size_t)g.n, cols, 0);
+      append_key_columns(table, keys, layout, 0, g, cols, 0);
       append_agg_columns(low, g, partial, cols, keys.size());
       groups_out = g.n;
     } else if (partial) {
       // inner GROUP BY (keys, x): one row per distinct pair
       GroupRows g = table_read(ctx, gt);
-      append_key_columns(table, keys, layout, 1, g.keys.data(), (size_t)g.n, cols, 0);
-      append_key_columns(table, {distinct_src}, layout, 0, g.keys.data(), (size_t)g.n, cols, keys.size());
+      append_key_columns(table, keys, layout, 1, g, cols, 0);
+      append_key_columns(table, {distinct_src}, layout, 0, g, cols, keys.size());
       groups_out = g.n;
     } else {
       // outer GROUP BY keys: COUNT(x) over the distinct pairs
       const KeyField& xf = layout.fields[0];
-      int x_bits = xf.bits + (xf.null_bit >= 0 ? 1 : 0);
-      int k_bits = total_bits - x_bits;
+      const bool two_words = layout.words == 2;
+      int x_bits = two_words ? 0 : xf.bits + (xf.null_bit >= 0 ? 1 : 0);
+      int k_bits = two_words ? layout.word_bits[1] : total_bits - x_bits;
       GroupTable q;
       bool qdense = k_bits <= kDenseMaxBits;
       uint64_t qcap = qdense ? (1ull << k_bits) : pow2_ceil(std::max<uint64_t>(1024, 2 * std::min<uint64_t>(selected, k_bits < 63 ? (1ull << k_bits) : selected)));
       table_alloc(ctx, q, qdense, qcap, {kSlotAddOne, kSlotAddOne});
       DistinctFoldParams fp{};
       fp.set_keys = gt.dense ? nullptr : gt.keys.as<uint64_t>();
+      fp.set_keys_hi = two_words ? gt.keys_hi.as<uint64_t>() : nullptr;
       fp.set_capacity = gt.capacity + 1;
       fp.set_special = gt.capacity;
       fp.set_rowcount = gt.state.as<int64_t>();
@@ -896,11 +954,12 @@ void execute_plan(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       KeyLayout kl;
       for (size_t i = 1; i < layout.fields.size(); ++i) {
         KeyField f = layout.fields[i];
+        f.word = 0;  // the outer table's key is the group key alone, in one word
         if (f.bits) f.bit_pos -= x_bits;
         if (f.null_bit >= 0) f.null_bit -= x_bits;
         kl.fields.push_back(f);
       }
-      append_key_columns(table, keys, kl, 0, g.keys.data(), (size_t)g.n, cols, 0);
+      append_key_columns(table, keys, kl, 0, g, cols, 0);
       for (size_t a = 0; a < plan->aggs.size(); ++a) {
         OutColumn& oc = cols[keys.size() + a];
         const int64_t* v = g.state.data() + (size_t)g.n;  // slot 1 = distinct count

@@ -98,7 +98,7 @@ struct KeySpec {
   uint32_t magic32;
   int32_t pre32;
   int32_t shift32;
-  int32_t pad;
+  int32_t word;       // which 64-bit word of the packed key holds this field (0 or 1)
 };
 
 struct ValSpec {
@@ -142,6 +142,8 @@ struct AggParams {
   int32_t lds_slots;    // power of two; 0 = no LDS pre-aggregation
   uint64_t capacity;    // dense: number of entries; hash: power of two
   uint64_t* g_keys;     // hash only: capacity + 1 entries (last = the all-ones key)
+  uint64_t* g_keys_hi;  // second key word of every entry when key_words == 2
+  int32_t key_words;    // 1, or 2 for packed keys of 65..127 bits (hash table only, no LDS stage)
   int64_t* g_state;     // n_slots arrays of (capacity + 1) entries
   uint32_t* overflow;   // set to 1 when the hash table is full
 };
@@ -160,6 +162,7 @@ void launch_group_by(prism_gpu_ctx* ctx, const AggParams& p, uint64_t algorithmi
 // (k, x) set adds 1 (when its x field is not NULL) to group k of table `q`.
 struct DistinctFoldParams {
   const uint64_t* set_keys;      // packed (k, x) keys, kEmptyKey = unused entry
+  const uint64_t* set_keys_hi;   // non-null: two-word keys, x in the low word and k in the high word
   uint64_t set_capacity;         // entries to visit
   uint64_t set_special;          // index of the entry that stands for the all-ones key (~0 = none)
   const int64_t* set_rowcount;   // slot 0 of the set table (tells whether the special entry is used)
@@ -176,9 +179,10 @@ void launch_distinct_fold(prism_gpu_ctx* ctx, const DistinctFoldParams& p);
 // Fills n entries with `value`.
 void launch_fill_i64(prism_gpu_ctx* ctx, int64_t* dst, uint64_t n, int64_t value);
 // Compacts the occupied entries of a table: out_keys[i], out_state[s * out_stride + i].
-void launch_emit(prism_gpu_ctx* ctx, bool dense, uint64_t capacity, const uint64_t* g_keys, const int64_t* g_state,
-                 int n_slots, uint64_t* out_keys, int64_t* out_state, uint64_t out_stride,
-                 unsigned long long* out_count);
+// g_keys_hi / out_keys_hi are non-null for two-word keys.
+void launch_emit(prism_gpu_ctx* ctx, bool dense, uint64_t capacity, const uint64_t* g_keys, const uint64_t* g_keys_hi,
+                 const int64_t* g_state, int n_slots, uint64_t* out_keys, uint64_t* out_keys_hi, int64_t* out_state,
+                 uint64_t out_stride, unsigned long long* out_count);
 
 // ---- loader support ----------------------------------------------------------
 

@@ -195,6 +195,66 @@ __global__ __launch_bounds__(kBlock) void k_group_by(AggParams p) {
   }
 }
 
+// ---- GROUP BY with packed keys wider than 64 bits ------------------------------------
+//
+// Two key words, straight into the HBM table (such keys come from high-cardinality
+// columns, where an LDS stage would see no repeats anyway).
+__device__ __forceinline__ void pack_key2(const AggParams& p, uint32_t seg, uint64_t row, uint64_t& lo, uint64_t& hi) {
+  lo = 0;
+  hi = 0;
+  for (int i = 0; i < p.n_keys; ++i) {
+    const KeySpec& k = p.keys[i];
+    const ColPtr& c = p.cols[(uint64_t)k.col * p.sd.n_segs + seg];
+    uint64_t field;
+    if (k.null_bit >= 0 && !valid_at(c.validity, row)) {
+      field = 1ull << k.null_bit;
+    } else {
+      long long v = load_value(c.values, k.width, k.is_unsigned, row);
+      if (k.date_bin) v = bucket_number(v, k);
+      field = ((uint64_t)v - (uint64_t)k.bias) << k.bit_pos;
+    }
+    if (k.word) hi |= field; else lo |= field;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_group_by_wide(AggParams p) {
+  auto row = [&](uint32_t seg, uint64_t r) {
+    uint64_t lo, hi;
+    pack_key2(p, seg, r, lo, hi);
+    RowVals rv;
+    load_vals(p, seg, r, rv);
+    uint64_t e = global_entry2(p, lo, hi);
+    if (e == ~0ull) return;
+    for (int s = 0; s < p.n_slots; ++s) {
+      long long x;
+      if (slot_input(p, s, rv, x)) atomic_apply(&p.g_state[(uint64_t)s * (p.capacity + 1) + e], p.slots[s].op, x);
+    }
+  };
+  if (p.row_mode == kRowsSelvec) {
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < p.n_sel; i += (uint64_t)gridDim.x * kBlock) {
+      uint64_t pid = p.selvec[i];
+      uint32_t seg = find_seg(p.sd, pid / kTileRows);
+      row(seg, pid - p.sd.segs[seg].tile_base * kTileRows);
+    }
+    return;
+  }
+  for (uint64_t tile = blockIdx.x; tile < p.sd.n_tiles; tile += gridDim.x) {
+    uint32_t seg = find_seg(p.sd, tile);
+    uint64_t seg_rows = p.sd.segs[seg].rows;
+    uint64_t tile_row0 = (tile - p.sd.segs[seg].tile_base) * kTileRows;
+    for (uint32_t it = 0; it < kTileRows / kBlock; ++it) {
+      uint64_t in_tile = (uint64_t)it * kBlock + threadIdx.x;
+      uint64_t r = tile_row0 + in_tile;
+      bool sel = r < seg_rows;
+      if (sel && p.row_mode == kRowsBitmap) {
+        uint64_t pid = tile * kTileRows + in_tile;
+        sel = (p.sel_bits[pid >> 6] >> (pid & 63)) & 1ull;
+      }
+      if (sel) row(seg, r);
+    }
+  }
+}
+
 // ---- ungrouped aggregates -------------------------------------------------------
 
 __device__ __forceinline__ long long combine(int op, long long a, long long b) {
@@ -277,6 +337,16 @@ __global__ __launch_bounds__(kBlock) void k_distinct_fold(DistinctFoldParams q) 
   p.g_keys = q.g_keys;
   p.overflow = q.overflow;
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < q.set_capacity; i += (uint64_t)gridDim.x * kBlock) {
+    if (q.set_keys_hi) {  // two words: x in the low word, the group key in the high word
+      uint64_t lo = q.set_keys[i];
+      if (lo == kEmptyKey) continue;
+      bool x_null = q.x_null_bit >= 0 && ((lo >> q.x_null_bit) & 1ull);
+      uint64_t e = global_entry(p, q.set_keys_hi[i]);
+      if (e == ~0ull) continue;
+      atomicAdd((unsigned long long*)&q.g_state[e], 1ull);
+      if (!x_null) atomicAdd((unsigned long long*)&q.g_state[(q.capacity + 1) + e], 1ull);
+      continue;
+    }
     uint64_t key;
     if (i == q.set_special) {
       if (q.set_rowcount[i] == 0) continue;
@@ -309,15 +379,16 @@ __device__ __forceinline__ bool occupied(bool dense, uint64_t capacity, const ui
 }
 
 __global__ __launch_bounds__(kBlock) void k_emit(int dense, uint64_t capacity, const uint64_t* g_keys,
-                                                const long long* g_state, int n_slots, uint64_t* out_keys,
-                                                long long* out_state, uint64_t out_stride,
-                                                unsigned long long* out_count) {
+                                                const uint64_t* g_keys_hi, const long long* g_state, int n_slots,
+                                                uint64_t* out_keys, uint64_t* out_keys_hi, long long* out_state,
+                                                uint64_t out_stride, unsigned long long* out_count) {
   uint64_t n = dense ? capacity : capacity + 1;
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
     if (!occupied(dense != 0, capacity, g_keys, g_state, i)) continue;
     unsigned long long pos = atomicAdd(out_count, 1ull);
     if (out_keys == nullptr) continue;  // counting pass
     out_keys[pos] = dense ? i : (i == capacity ? kEmptyKey : g_keys[i]);
+    if (out_keys_hi) out_keys_hi[pos] = i == capacity ? 0ull : g_keys_hi[i];
     for (int s = 0; s < n_slots; ++s) out_state[(uint64_t)s * out_stride + pos] = g_state[(uint64_t)s * (capacity + 1) + i];
   }
 }
@@ -346,7 +417,8 @@ void launch_group_by(prism_gpu_ctx* ctx, const AggParams& p, uint64_t algorithmi
   // ranges per workgroup so that its LDS table sees each group many times
   size_t fast_lds = 0;
   GroupByKernel fast = (p.row_mode != kRowsSelvec && p.lds_slots > 0) ? pick_stream_kernel(p, &fast_lds) : nullptr;
-  GroupByKernel kernel = fast ? fast : k_group_by;
+  if (p.key_words == 2) { fast = nullptr; lds = 0; }
+  GroupByKernel kernel = p.key_words == 2 ? k_group_by_wide : (fast ? fast : k_group_by);
   if (fast) lds = fast_lds;
   // One round of workgroups: exactly as many as are resident at once, each walking a
   // contiguous run of tiles, so that no CU idles while a second, partial round runs.
@@ -372,14 +444,15 @@ void launch_fill_i64(prism_gpu_ctx* ctx, int64_t* dst, uint64_t n, int64_t value
   PRISM_HIP(hipGetLastError());
 }
 
-void launch_emit(prism_gpu_ctx* ctx, bool dense, uint64_t capacity, const uint64_t* g_keys, const int64_t* g_state,
-                 int n_slots, uint64_t* out_keys, int64_t* out_state, uint64_t out_stride,
-                 unsigned long long* out_count) {
+void launch_emit(prism_gpu_ctx* ctx, bool dense, uint64_t capacity, const uint64_t* g_keys, const uint64_t* g_keys_hi,
+                 const int64_t* g_state, int n_slots, uint64_t* out_keys, uint64_t* out_keys_hi, int64_t* out_state,
+                 uint64_t out_stride, unsigned long long* out_count) {
   uint64_t n = dense ? capacity : capacity + 1;
   if (n == 0) return;
-  k_emit<<<dim3(stream_grid(ctx, n)), dim3(kBlock), 0, ctx->stream>>>(dense ? 1 : 0, capacity, g_keys,
+  k_emit<<<dim3(stream_grid(ctx, n)), dim3(kBlock), 0, ctx->stream>>>(dense ? 1 : 0, capacity, g_keys, g_keys_hi,
                                                                     (const long long*)g_state, n_slots, out_keys,
-                                                                    (long long*)out_state, out_stride, out_count);
+                                                                    out_keys_hi, (long long*)out_state, out_stride,
+                                                                    out_count);
   PRISM_HIP(hipGetLastError());
 }
 

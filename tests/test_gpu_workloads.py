@@ -78,7 +78,6 @@ def test_c3_high_cardinality_group_by_topk(gpu_ctx, oracle):
     ])
 
 
-@pytest.mark.xfail(reason="packed keys wider than 64 bits are not supported yet", strict=False)
 def test_c5_count_distinct_by_hour_service(gpu_ctx, oracle):
     wl = workloads.c5(n_services=16, user_bits=14)
     _both(gpu_ctx, oracle, wl, 500_000, 4, queries=[(wl.query, 2)])
@@ -163,5 +162,44 @@ def test_c4_like_on_high_cardinality_strings(gpu_ctx, oracle):
             finally:
                 p.close()
         assert e.value.code == abi.EUNSUPPORTED
+    finally:
+        g.close()
+
+
+def test_keys_wider_than_64_bits(gpu_ctx, oracle):
+    """GROUP BY over columns whose ranges need more than 64 bits together: two-word keys
+    in the HBM table (also the shape of C5: a 63-bit id next to the group key)."""
+    from prism_amd.engine import Plan, Table
+
+    rng = np.random.default_rng(8)
+    n = 60_000
+    a = rng.integers(0, 300, n).astype(np.int64) * (2**62 // 300) - 2**61
+    b = rng.integers(0, 200, n).astype(np.int64) * (2**40 // 200)
+    t = pa.table({"a": pa.array(a, mask=rng.random(n) < 0.02), "b": pa.array(b), "c": pa.array(rng.integers(0, 9, n).astype(np.int32)),
+                  "v": pa.array(rng.integers(-5, 5, n).astype(np.int64))})
+    g = Table(gpu_ctx, t.schema)
+    g.append_table(t, 2)
+    try:
+        for q, nk in [(QueryPlan([count_star(), sum_("v"), min_("v")], keys=["a", "b"]), 2),
+                      (QueryPlan([count_star(), avg("v")], keys=["c", "a", "b"], predicate=col("v") != 0), 3),
+                      (QueryPlan([count_distinct("a")], keys=["c"]), 1),
+                      (QueryPlan([count_distinct("b")], keys=["a"]), 1),
+                      (QueryPlan([count_star()], keys=["a", "b"], order_by=2, descending=True, limit=7), 2)]:
+            plan = Plan(gpu_ctx, t.schema, q)
+            try:
+                got, want = plan.execute(g), oracle.execute(t, q)
+                if q.limit is not None:
+                    assert_topk_match(got, want, q.order_by)
+                else:
+                    assert_tables_match(got, want, nk)
+                if q.limit is None and not any(a.func == abi.AGG_COUNT_DISTINCT for a in q.aggs):
+                    pp = Plan(gpu_ctx, t.schema, q.with_mode(abi.MODE_PARTIAL))
+                    try:
+                        states = [pp.execute(g, [p]) for p in range(2)]
+                        assert_tables_match(pp.merge(states), want, nk)
+                    finally:
+                        pp.close()
+            finally:
+                plan.close()
     finally:
         g.close()
