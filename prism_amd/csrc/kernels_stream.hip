@@ -232,8 +232,10 @@ __device__ __forceinline__ void convert(const AggParams& p, const RowBatch<NK, N
   out.live = b.live;
 }
 
+// Entry of `key` in the LDS table, or -1.  `insert` false: look-up only, a few probes
+// (the table is frozen: it keeps the groups it has, everything else goes to HBM).
 template <bool K32>
-__device__ __forceinline__ int lds_entry(const Lds<K32>& t, KeyT<K32> key, int* n_entries) {
+__device__ __forceinline__ int lds_entry(const Lds<K32>& t, KeyT<K32> key, int* n_entries, bool insert) {
   const KeyT<K32> empty = (KeyT<K32>)~(KeyT<K32>)0;
   const int sub = t.S >> t.rep_log2;  // entries per replica
   const int mask = sub - 1;
@@ -242,11 +244,13 @@ __device__ __forceinline__ int lds_entry(const Lds<K32>& t, KeyT<K32> key, int* 
   const int rep = (int)(threadIdx.x & ((1u << t.rep_log2) - 1u));
   uint32_t mixed = K32 ? (uint32_t)key : ((uint32_t)key ^ (uint32_t)((uint64_t)key >> 32));
   int h = (int)((mixed * 0x9E3779B1u) >> 12) & mask;
-  for (int probe = 0; probe < kLdsProbes; ++probe) {
+  const int max_probes = insert ? kLdsProbes : 4;
+  for (int probe = 0; probe < max_probes; ++probe) {
     const int e = (h << t.rep_log2) + rep;
     KeyT<K32> k = t.keys[e];
     if (k == key) return e;
     if (k == empty) {
+      if (!insert) return -1;
       KeyT<K32> old;
       if (K32) old = (KeyT<K32>)atomicCAS((unsigned int*)&t.keys[e], 0xffffffffu, (unsigned int)key);
       else old = (KeyT<K32>)atomicCAS((unsigned long long*)&t.keys[e], ~0ull, (unsigned long long)key);
@@ -263,7 +267,7 @@ __device__ __forceinline__ int lds_entry(const Lds<K32>& t, KeyT<K32> key, int* 
 // is decoded once and applied to all rows, so the per-slot dispatch is paid per step,
 // not per row.  Rows that found the LDS table full fall through to the HBM table.
 template <int NK, int NV, bool K32>
-__device__ __forceinline__ void consume(const AggParams& p, const Lds<K32>& t, bool use_lds, int* n_entries,
+__device__ __forceinline__ void consume(const AggParams& p, const Lds<K32>& t, bool insert, int* n_entries,
                                         const PackedRows<NK, NV, K32>& b) {
   int e[kU];  // LDS entry, -1 = go to HBM, -2 = row not live
 #pragma unroll
@@ -271,8 +275,8 @@ __device__ __forceinline__ void consume(const AggParams& p, const Lds<K32>& t, b
     e[u] = -2;
     if ((b.live >> u) & 1u) {
       // a 64-bit key equal to the empty marker only lives in the HBM table's extra entry
-      const bool lds_ok = use_lds && (K32 || b.key[u] != (KeyT<K32>)kEmptyKey);
-      e[u] = lds_ok ? lds_entry<K32>(t, b.key[u], n_entries) : -1;
+      const bool lds_ok = K32 || b.key[u] != (KeyT<K32>)kEmptyKey;
+      e[u] = lds_ok ? lds_entry<K32>(t, b.key[u], n_entries, insert) : -1;
     }
   }
   for (int s = 0; s < p.n_slots; ++s) {
@@ -355,14 +359,13 @@ template <int NK, int NV, bool K32>
 __global__ __launch_bounds__(kBlock) void k_group_by_stream(AggParams p) {
   extern __shared__ unsigned long long lds_raw[];
   __shared__ int n_entries;
-  __shared__ int bypass;
   constexpr int kInitialRepLog2 = 0;
   Lds<K32> t;
   t.S = p.lds_slots;
   t.rep_log2 = kInitialRepLog2;
   t.state = (long long*)lds_raw;
   t.keys = (KeyT<K32>*)(lds_raw + (size_t)p.n_slots * t.S);
-  if (threadIdx.x == 0) { n_entries = 0; bypass = 0; }
+  if (threadIdx.x == 0) n_entries = 0;
   lds_clear<K32>(p, t);
   __syncthreads();
 
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(kBlock) void k_group_by_stream(AggParams p) {
   const uint64_t t0 = per * blockIdx.x, t1 = t0 + per < p.sd.n_tiles ? t0 + per : p.sd.n_tiles;
   const uint64_t j0 = t0 * kStepsPerTile, j1 = t1 * kStepsPerTile;
   uint64_t rows_since_flush = 0;
-  bool use_lds = true;
+  bool insert = true;  // false once the table is frozen
 
   SegCursor<NK, NV> cur;
   RowBatch<NK, NV> raw;
@@ -384,27 +387,28 @@ __global__ __launch_bounds__(kBlock) void k_group_by_stream(AggParams p) {
     __builtin_amdgcn_sched_barrier(0);
     if (j + 1 < j1) issue(p, j + 1, cur, raw);
     __builtin_amdgcn_sched_barrier(0);
-    consume<NK, NV, K32>(p, t, use_lds, &n_entries, rows);
-    if ((j + 1) % kStepsPerTile == 0) {
-      // Block-wide bookkeeping at the end of a tile: fold the LDS table into HBM when it
-      // is getting full, and stop using LDS if the keys hardly repeat.
+    consume<NK, NV, K32>(p, t, insert, &n_entries, rows);
+    if (insert && (j + 1) % kStepsPerTile == 0) {
+      // Block-wide bookkeeping at the end of a tile, when the LDS table is half full.
+      // Keys that repeat a lot: fold the table into HBM and start over (with fewer
+      // copies per group if replicas were in use).  Keys that hardly repeat (high
+      // cardinality): freeze the table instead.  It then keeps the groups it has, which
+      // are the frequent ones (they show up first), so the hot groups still cost HBM no
+      // per-row atomics on one address, and every other row goes straight to HBM.
       rows_since_flush += kTileRows;
       __syncthreads();
-      int n = n_entries;
+      const int n = n_entries;
       __syncthreads();
       if (n > t.S / 2) {
-        lds_flush<K32>(p, t);
-        // The table filled up: keep fewer copies of each group from here on, and give up
-        // on LDS altogether if even a single copy sees hardly any repeats.
-        if (t.rep_log2 > 0) {
-          t.rep_log2 -= 1;
-        } else if (threadIdx.x == 0 && (uint64_t)n * 4 > rows_since_flush) {
-          bypass = 1;
+        if (t.rep_log2 == 0 && (uint64_t)n * 4 > rows_since_flush) {
+          insert = false;
+        } else {
+          lds_flush<K32>(p, t);
+          if (t.rep_log2 > 0) t.rep_log2 -= 1;
+          if (threadIdx.x == 0) n_entries = 0;
+          rows_since_flush = 0;
+          __syncthreads();
         }
-        if (threadIdx.x == 0) n_entries = 0;
-        rows_since_flush = 0;
-        __syncthreads();
-        use_lds = bypass == 0;
       }
     }
   }
