@@ -633,12 +633,15 @@ bool table_overflowed(prism_gpu_ctx* ctx, const GroupTable& g) {
   return flag != 0;
 }
 
-GroupRows table_read(prism_gpu_ctx* ctx, const GroupTable& g) {
+// Reads the occupied entries of a table; with `order`, only those whose rank reaches the
+// threshold launch_topk_threshold left in d_threshold.
+GroupRows table_read(prism_gpu_ctx* ctx, const GroupTable& g, const TopKOrder* order = nullptr,
+                     const TopKState* d_threshold = nullptr) {
   GroupRows rows;
   Scratch d_count(ctx, 256);
   PRISM_HIP(hipMemsetAsync(d_count.p, 0, 8, ctx->stream));
   launch_emit(ctx, g.dense, g.capacity, g.keys.as<uint64_t>(), g.keys_hi.as<uint64_t>(), g.state.as<int64_t>(),
-              g.n_slots, nullptr, nullptr, nullptr, 0, d_count.as<unsigned long long>());
+              g.n_slots, nullptr, nullptr, nullptr, 0, d_count.as<unsigned long long>(), order, d_threshold);
   unsigned long long n = 0;
   PRISM_HIP(hipMemcpyAsync(&n, d_count.p, 8, hipMemcpyDeviceToHost, ctx->stream));
   PRISM_HIP(hipStreamSynchronize(ctx->stream));
@@ -649,7 +652,7 @@ GroupRows table_read(prism_gpu_ctx* ctx, const GroupTable& g) {
   PRISM_HIP(hipMemsetAsync(d_count.p, 0, 8, ctx->stream));
   launch_emit(ctx, g.dense, g.capacity, g.keys.as<uint64_t>(), g.keys_hi.as<uint64_t>(), g.state.as<int64_t>(),
               g.n_slots, d_keys.as<uint64_t>(), d_keys_hi.as<uint64_t>(), d_state.as<int64_t>(), n,
-              d_count.as<unsigned long long>());
+              d_count.as<unsigned long long>(), order, d_threshold);
   if (g.key_words == 2) {
     rows.keys_hi.resize(n);
     PRISM_HIP(hipMemcpyAsync(rows.keys_hi.data(), d_keys_hi.p, n * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -680,6 +683,40 @@ GroupRows table_read(prism_gpu_ctx* ctx, const GroupTable& g) {
     PRISM_HIP(hipStreamSynchronize(ctx->stream));
   }
   return rows;
+}
+
+// Tables with fewer entries than this are read whole; sorting them on the host is cheap.
+constexpr uint64_t kTopKMinEntries = 4096;
+
+// Whether ORDER BY ... LIMIT of this plan can be decided on the device, and how.
+bool topk_order(const prism_gpu_plan* p, const prism_gpu_table* t, const std::vector<KeySrc>& keys, const KeyLayout& layout,
+                const Lowered& low, const std::vector<OutColumn>& cols, TopKOrder& o) {
+  if (p->order_by < 0 || p->limit < 0 || p->limit > (1 << 20)) return false;
+  std::memset(&o, 0, sizeof(o));
+  o.descending = p->descending ? 1 : 0;
+  const size_t c = (size_t)p->order_by;
+  if (c < keys.size()) {
+    if (t->fields[keys[c].column].is_string) return false;  // dictionary codes do not sort like their strings
+    const KeyField& f = layout.fields[c];
+    o.kind = kOrdKeyField;
+    o.word = f.word;
+    o.bit_pos = f.bit_pos;
+    o.bits = f.bits;
+    o.null_bit = f.null_bit;
+    return true;
+  }
+  if (c - keys.size() >= low.rules.size()) return false;
+  const AggRule& r = low.rules[c - keys.size()];
+  o.main_slot = r.main_slot;
+  o.count_slot = r.count_slot;
+  o.is_unsigned = cols[c].type.is_unsigned ? 1 : 0;
+  if (r.func == PRISM_AGG_AVG) {
+    if (r.count_slot < 0) return false;
+    o.kind = kOrdAvg;
+  } else {
+    o.kind = kOrdI64;
+  }
+  return true;
 }
 
 int lds_slots_for(int n_slots) {
@@ -899,7 +936,17 @@ void execute_plan(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       GroupRows g;
       {
         HostTimer ht(ctx, "host:read_groups");
-        g = table_read(ctx, gt);
+        TopKOrder order;
+        const uint64_t entries = gt.dense ? gt.capacity : gt.capacity + 1;
+        if (!partial && entries >= kTopKMinEntries && topk_order(plan, table, keys, layout, low, cols, order)) {
+          Scratch d_topk(ctx, sizeof(TopKState));
+          launch_topk_threshold(ctx, gt.dense, gt.capacity, gt.keys.as<uint64_t>(), gt.keys_hi.as<uint64_t>(),
+                                gt.state.as<int64_t>(), order, (uint64_t)std::max<int64_t>(1, plan->limit),
+                                d_topk.as<TopKState>());
+          g = table_read(ctx, gt, &order, d_topk.as<TopKState>());
+        } else {
+          g = table_read(ctx, gt);
+        }
       }
       HostTimer ht(ctx, "host:assemble");
       append_key_columns(table, keys, layout, 0, g, cols, 0);

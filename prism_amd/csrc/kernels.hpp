@@ -176,13 +176,40 @@ struct DistinctFoldParams {
 };
 void launch_distinct_fold(prism_gpu_ctx* ctx, const DistinctFoldParams& p);
 
+// ORDER BY <one output column> [DESC] LIMIT k, decided on the device so that only the
+// leading groups travel to the host.  Every occupied entry gets a 64-bit rank, larger =
+// earlier in the requested order (NULLS FIRST when descending, NULLS LAST when
+// ascending, as in sort_and_limit); a radix select finds a threshold rank that at least
+// k entries reach, and launch_emit then compacts only those.  Entries that tie with the
+// threshold all pass, so the host still sorts the survivors and cuts at k.
+enum TopKKind { kOrdI64 = 0, kOrdAvg = 1, kOrdKeyField = 2 };
+struct TopKOrder {
+  int kind;
+  int main_slot, count_slot;  // kOrdI64 / kOrdAvg: value slot; count slot (> 0 <=> not NULL, -1: never NULL)
+  int is_unsigned;            // kOrdI64: compare as unsigned
+  int descending;
+  int word, bit_pos, bits, null_bit;  // kOrdKeyField: where the field sits in the packed key
+};
+constexpr int kTopKBins = 2048;
+struct TopKState {
+  uint64_t prefix, mask;  // ranks still in play: (rank & mask) == prefix
+  uint64_t k_rem;         // how many of those are wanted
+  uint32_t done, pad;
+  uint32_t hist[kTopKBins];
+};
+// Leaves the threshold in d_state->prefix.  d_state is overwritten.
+void launch_topk_threshold(prism_gpu_ctx* ctx, bool dense, uint64_t capacity, const uint64_t* g_keys,
+                           const uint64_t* g_keys_hi, const int64_t* g_state, const TopKOrder& order, uint64_t k,
+                           TopKState* d_state);
+
 // Fills n entries with `value`.
 void launch_fill_i64(prism_gpu_ctx* ctx, int64_t* dst, uint64_t n, int64_t value);
 // Compacts the occupied entries of a table: out_keys[i], out_state[s * out_stride + i].
 // g_keys_hi / out_keys_hi are non-null for two-word keys.
 void launch_emit(prism_gpu_ctx* ctx, bool dense, uint64_t capacity, const uint64_t* g_keys, const uint64_t* g_keys_hi,
                  const int64_t* g_state, int n_slots, uint64_t* out_keys, uint64_t* out_keys_hi, int64_t* out_state,
-                 uint64_t out_stride, unsigned long long* out_count);
+                 uint64_t out_stride, unsigned long long* out_count, const TopKOrder* order = nullptr,
+                 const TopKState* d_threshold = nullptr);
 
 // ---- loader support ----------------------------------------------------------
 

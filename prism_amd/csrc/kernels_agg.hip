@@ -378,15 +378,121 @@ __device__ __forceinline__ bool occupied(bool dense, uint64_t capacity, const ui
   return g_keys[i] != kEmptyKey;
 }
 
+// Rank of entry i under `o`: larger = earlier in the requested order.
+__device__ __forceinline__ uint64_t topk_rank(const TopKOrder& o, bool dense, uint64_t capacity, const uint64_t* g_keys,
+                                              const uint64_t* g_keys_hi, const long long* g_state, uint64_t i) {
+  bool valid = true;
+  uint64_t u;
+  if (o.kind == kOrdKeyField) {
+    uint64_t key;
+    if (o.word == 1) key = i == capacity ? 0ull : g_keys_hi[i];
+    else key = dense ? i : (i == capacity ? kEmptyKey : g_keys[i]);
+    if (o.null_bit >= 0) valid = ((key >> o.null_bit) & 1ull) == 0;
+    u = o.bits ? ((key >> o.bit_pos) & (~0ull >> (64 - o.bits))) : 0ull;
+  } else {
+    const long long main = g_state[(uint64_t)o.main_slot * (capacity + 1) + i];
+    const long long cnt = o.count_slot >= 0 ? g_state[(uint64_t)o.count_slot * (capacity + 1) + i] : 1;
+    valid = cnt > 0;
+    if (o.kind == kOrdI64) {
+      u = o.is_unsigned ? (uint64_t)main : ((uint64_t)main ^ (1ull << 63));
+    } else {
+      double v = valid ? __longlong_as_double(main) / (double)cnt : 0.0;
+      if (v == 0.0) v = 0.0;  // -0.0 ranks with +0.0
+      const uint64_t b = (uint64_t)__double_as_longlong(v);
+      u = (b >> 63) ? ~b : (b | (1ull << 63));
+    }
+  }
+  if (o.descending) return valid ? u : ~0ull;
+  return valid ? ~u : 0ull;
+}
+
+// One radix-select pass: histogram of the `bits` rank bits at `shift` over the entries
+// whose higher bits match the prefix found so far.
+__global__ __launch_bounds__(kBlock) void k_topk_hist(TopKOrder o, int dense, uint64_t capacity, const uint64_t* g_keys,
+                                                     const uint64_t* g_keys_hi, const long long* g_state,
+                                                     TopKState* st, int shift, int bits) {
+  __shared__ uint32_t h[kTopKBins];
+  if (st->done) return;
+  for (int b = threadIdx.x; b < kTopKBins; b += kBlock) h[b] = 0;
+  __syncthreads();
+  const uint64_t prefix = st->prefix, mask = st->mask;
+  const uint64_t n = dense ? capacity : capacity + 1;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+    if (g_state[i] == 0) continue;  // slot 0 counts the rows of the group
+    const uint64_t r = topk_rank(o, dense != 0, capacity, g_keys, g_keys_hi, g_state, i);
+    if ((r & mask) != prefix) continue;
+    atomicAdd(&h[(r >> shift) & ((1u << bits) - 1)], 1u);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < kTopKBins; b += kBlock)
+    if (h[b]) atomicAdd(&st->hist[b], h[b]);
+}
+
+// Picks the bin that holds the k_rem-th largest rank, narrows the prefix to it and
+// clears the histogram for the next pass.  One workgroup.
+__global__ __launch_bounds__(kBlock) void k_topk_pick(TopKState* st, int shift, int bits) {
+  constexpr int kPer = kTopKBins / kBlock;
+  __shared__ uint64_t part[kBlock];
+  __shared__ uint64_t before[kBlock];  // entries in the bins above this thread's bins
+  __shared__ uint64_t total;
+  const bool done = st->done != 0;
+  const uint64_t k = st->k_rem;
+  const int t = threadIdx.x;
+  // thread t owns bins [top - kPer + 1, top], walked from the top down
+  const int top = kTopKBins - 1 - t * kPer;
+  uint32_t c[kPer];
+  uint64_t sum = 0;
+  for (int j = 0; j < kPer; ++j) { c[j] = st->hist[top - j]; sum += c[j]; }
+  part[t] = sum;
+  __syncthreads();
+  if (t == 0) {
+    uint64_t run = 0;
+    for (int i = 0; i < kBlock; ++i) { before[i] = run; run += part[i]; }
+    total = run;
+  }
+  __syncthreads();
+  if (!done) {
+    if (total < k) {
+      // fewer entries than wanted: everything passes
+      if (t == 0) { st->prefix = 0; st->mask = 0; st->done = 1; }
+    } else if (before[t] < k && k <= before[t] + sum) {
+      uint64_t acc = before[t];
+      for (int j = 0; j < kPer; ++j) {
+        if (acc + c[j] >= k) {
+          st->prefix |= (uint64_t)(top - j) << shift;
+          st->mask |= (uint64_t)((1u << bits) - 1) << shift;
+          st->k_rem = k - acc;
+          // few entries share the bin: pass them all and let the host sort them out
+          if (c[j] <= 1024) st->done = 1;
+          break;
+        }
+        acc += c[j];
+      }
+    }
+  }
+  for (int j = 0; j < kPer; ++j) st->hist[top - j] = 0;
+}
+
 __global__ __launch_bounds__(kBlock) void k_emit(int dense, uint64_t capacity, const uint64_t* g_keys,
                                                 const uint64_t* g_keys_hi, const long long* g_state, int n_slots,
                                                 uint64_t* out_keys, uint64_t* out_keys_hi, long long* out_state,
-                                                uint64_t out_stride, unsigned long long* out_count) {
-  uint64_t n = dense ? capacity : capacity + 1;
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
-    if (!occupied(dense != 0, capacity, g_keys, g_state, i)) continue;
-    unsigned long long pos = atomicAdd(out_count, 1ull);
-    if (out_keys == nullptr) continue;  // counting pass
+                                                uint64_t out_stride, unsigned long long* out_count, int filtered,
+                                                TopKOrder order, const TopKState* threshold) {
+  const uint64_t n = dense ? capacity : capacity + 1;
+  const uint64_t min_rank = filtered ? threshold->prefix : 0ull;
+  const int lane = threadIdx.x & 63;
+  for (uint64_t base = (uint64_t)blockIdx.x * kBlock; base < n; base += (uint64_t)gridDim.x * kBlock) {
+    const uint64_t i = base + threadIdx.x;
+    bool take = i < n && occupied(dense != 0, capacity, g_keys, g_state, i);
+    if (take && filtered) take = topk_rank(order, dense != 0, capacity, g_keys, g_keys_hi, g_state, i) >= min_rank;
+    // one counter update per wave
+    const uint64_t m = __ballot(take);
+    if (m == 0) continue;
+    unsigned long long first = 0;
+    if (lane == __ffsll((long long)m) - 1) first = atomicAdd(out_count, (unsigned long long)__popcll(m));
+    first = __shfl(first, __ffsll((long long)m) - 1);
+    if (!take || out_keys == nullptr) continue;  // counting pass
+    const unsigned long long pos = first + __popcll(m & ((1ull << lane) - 1));
     out_keys[pos] = dense ? i : (i == capacity ? kEmptyKey : g_keys[i]);
     if (out_keys_hi) out_keys_hi[pos] = i == capacity ? 0ull : g_keys_hi[i];
     for (int s = 0; s < n_slots; ++s) out_state[(uint64_t)s * out_stride + pos] = g_state[(uint64_t)s * (capacity + 1) + i];
@@ -446,13 +552,35 @@ void launch_fill_i64(prism_gpu_ctx* ctx, int64_t* dst, uint64_t n, int64_t value
 
 void launch_emit(prism_gpu_ctx* ctx, bool dense, uint64_t capacity, const uint64_t* g_keys, const uint64_t* g_keys_hi,
                  const int64_t* g_state, int n_slots, uint64_t* out_keys, uint64_t* out_keys_hi, int64_t* out_state,
-                 uint64_t out_stride, unsigned long long* out_count) {
+                 uint64_t out_stride, unsigned long long* out_count, const TopKOrder* order,
+                 const TopKState* d_threshold) {
   uint64_t n = dense ? capacity : capacity + 1;
   if (n == 0) return;
+  TopKOrder o{};
+  if (order) o = *order;
   k_emit<<<dim3(stream_grid(ctx, n)), dim3(kBlock), 0, ctx->stream>>>(dense ? 1 : 0, capacity, g_keys, g_keys_hi,
                                                                     (const long long*)g_state, n_slots, out_keys,
                                                                     out_keys_hi, (long long*)out_state, out_stride,
-                                                                    out_count);
+                                                                    out_count, order ? 1 : 0, o, d_threshold);
+  PRISM_HIP(hipGetLastError());
+}
+
+void launch_topk_threshold(prism_gpu_ctx* ctx, bool dense, uint64_t capacity, const uint64_t* g_keys,
+                           const uint64_t* g_keys_hi, const int64_t* g_state, const TopKOrder& order, uint64_t k,
+                           TopKState* d_state) {
+  const uint64_t n = dense ? capacity : capacity + 1;
+  PRISM_HIP(hipMemsetAsync(d_state, 0, sizeof(TopKState), ctx->stream));
+  PRISM_HIP(hipMemcpyAsync(&d_state->k_rem, &k, 8, hipMemcpyHostToDevice, ctx->stream));
+  KernelTimer timer(ctx, "topk_select", n * 16);
+  // 64 rank bits, most significant first: five passes of 11 bits and one of 9
+  for (int hi = 64; hi > 0;) {
+    const int bits = hi >= 11 ? 11 : hi;
+    const int shift = hi - bits;
+    k_topk_hist<<<dim3(stream_grid(ctx, n)), dim3(kBlock), 0, ctx->stream>>>(order, dense ? 1 : 0, capacity, g_keys, g_keys_hi,
+                                                                           (const long long*)g_state, d_state, shift, bits);
+    k_topk_pick<<<dim3(1), dim3(kBlock), 0, ctx->stream>>>(d_state, shift, bits);
+    hi = shift;
+  }
   PRISM_HIP(hipGetLastError());
 }
 
