@@ -152,7 +152,9 @@ struct AggParams {
 // columns, 32- or 64-bit packed key), or nullptr when there is none; *lds_bytes
 // receives the dynamic LDS size it needs.
 using GroupByKernel = void (*)(AggParams);
-GroupByKernel pick_stream_kernel(const AggParams& p, size_t* lds_bytes);
+// The streaming kernel for this plan shape (nullptr: none), with the workgroup size, the
+// LDS table size (entries) and the dynamic LDS bytes to launch it with.
+GroupByKernel pick_stream_kernel(const AggParams& p, size_t* lds_bytes, uint32_t* block, int* lds_slots);
 
 // Ungrouped aggregates: out[n_slots] must hold the slot identities on entry.
 void launch_agg_global(prism_gpu_ctx* ctx, const AggParams& p, int64_t* out);

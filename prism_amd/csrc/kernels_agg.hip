@@ -515,25 +515,38 @@ void launch_agg_global(prism_gpu_ctx* ctx, const AggParams& p, int64_t* out) {
   PRISM_HIP(hipGetLastError());
 }
 
-void launch_group_by(prism_gpu_ctx* ctx, const AggParams& p, uint64_t algorithmic_bytes) {
+void launch_group_by(prism_gpu_ctx* ctx, const AggParams& params, uint64_t algorithmic_bytes) {
+  AggParams p = params;
   uint64_t work = p.row_mode == kRowsSelvec ? ceil_div(p.n_sel, (uint64_t)kBlock * 16) : p.sd.n_tiles;
   if (work == 0) return;
   size_t lds = (size_t)p.lds_slots * 8 * (1 + p.n_slots);
-  // enough workgroups to fill every CU several times over, but long contiguous row
-  // ranges per workgroup so that its LDS table sees each group many times
-  size_t fast_lds = 0;
-  GroupByKernel fast = (p.row_mode != kRowsSelvec && p.lds_slots > 0) ? pick_stream_kernel(p, &fast_lds) : nullptr;
-  if (p.key_words == 2) { fast = nullptr; lds = 0; }
-  GroupByKernel kernel = p.key_words == 2 ? k_group_by_wide : (fast ? fast : k_group_by);
-  if (fast) lds = fast_lds;
+  uint32_t block = kBlock;
+  GroupByKernel kernel = k_group_by;
+  if (p.key_words == 2) {
+    kernel = k_group_by_wide;
+    lds = 0;
+  } else if (p.row_mode != kRowsSelvec && p.lds_slots > 0) {
+    size_t fast_lds = 0;
+    uint32_t fast_block = 0;
+    int fast_slots = 0;
+    if (GroupByKernel fast = pick_stream_kernel(p, &fast_lds, &fast_block, &fast_slots)) {
+      kernel = fast;
+      lds = fast_lds;
+      block = fast_block;
+      p.lds_slots = fast_slots;
+      if (lds > 48 * 1024)
+        PRISM_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+  }
   // One round of workgroups: exactly as many as are resident at once, each walking a
-  // contiguous run of tiles, so that no CU idles while a second, partial round runs.
+  // contiguous run of tiles, so that no CU idles while a second, partial round runs and
+  // every workgroup's LDS table sees each group many times.
   int per_cu = 0;
-  PRISM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)kBlock, lds));
+  PRISM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)block, lds));
   if (per_cu < 1) per_cu = 1;
   uint32_t grid = (uint32_t)std::min<uint64_t>(work, (uint64_t)ctx->n_cus * (uint64_t)per_cu);
   KernelTimer timer(ctx, "group_by", algorithmic_bytes);
-  kernel<<<dim3(grid), dim3(kBlock), lds, ctx->stream>>>(p);
+  kernel<<<dim3(grid), dim3(block), lds, ctx->stream>>>(p);
   PRISM_HIP(hipGetLastError());
 }
 

@@ -1,14 +1,23 @@
 // Streaming GROUP BY: the kernel that runs when every row (or a bitmap-selected subset)
 // of the scanned segments is aggregated.
 //
-// Per step a lane handles kU rows (row per lane, so a wave instruction reads one
-// contiguous run of each column).  The step is software pipelined:
+// Per step a wave handles kU runs of 64 consecutive rows (row per lane, so a wave
+// instruction reads one contiguous run of each column, and the validity / selection
+// bits of a run are one 64-bit word that is used directly as a lane mask).  The step is
+// software pipelined:
 //   1. convert: wait for the batch in flight and reduce it, in registers, to one packed
 //      key per row plus the widened aggregate inputs;
 //   2. issue:   start the loads of the next step (every column, kU rows, one unaligned
 //      8-byte load per value whatever the column width, so no branch separates them);
-//   3. consume: find-or-insert the key in the workgroup's LDS table and apply the slot
-//      updates with LDS atomics while the loads of (2) are in flight.
+//   3. consume: find the key in the workgroup's LDS table and apply the slot updates
+//      with LDS atomics while the loads of (2) are in flight.
+// The instruction count per row is what bounds this kernel once the loads are batched,
+// so the steady state avoids per-lane control flow altogether: the LDS table is 4-way
+// set associative (one 16-byte read returns the four candidate keys, no probe loop),
+// rows that must not touch the table (dead lanes, misses that go to HBM) update a
+// per-lane scratch entry instead of being masked off, and NULL inputs are replaced by
+// the slot's identity.  Inserting a new key, and the HBM fallback, are out-of-line
+// paths entered by a wave-uniform branch.
 // The kernel is specialised on the number of key columns (NK), of aggregate input
 // columns (NV) and on whether the packed key fits in 31 bits (K32: 32-bit key
 // arithmetic, 32-bit LDS keys, and date_bin as one 32-bit multiply-high when the
@@ -18,13 +27,31 @@
 
 #include "agg_device.hpp"
 
+#ifndef PRISM_STREAM_BLOCK
+#define PRISM_STREAM_BLOCK 512
+#endif
+#ifndef PRISM_STREAM_REPLICAS
+#define PRISM_STREAM_REPLICAS 16
+#endif
+#ifndef PRISM_STREAM_LDS_KB
+#define PRISM_STREAM_LDS_KB 72
+#endif
+
 namespace prism {
 
 namespace {
 
 constexpr int kU = 4;
-constexpr uint32_t kStepsPerTile = kTileRows / (kBlock * kU);
-constexpr int kLdsProbes = 16;
+constexpr uint32_t kWaveRows = 64 * kU;     // rows of one wave per step
+// Threads per workgroup.  All waves of a workgroup share one LDS table, so for a given
+// amount of LDS per CU a larger workgroup means a larger table, hence more replicas.
+constexpr uint32_t kStreamBlock = PRISM_STREAM_BLOCK;
+constexpr uint32_t kStepRows = kStreamBlock * kU;  // rows of the workgroup per step
+constexpr uint32_t kStepsPerTile = kTileRows / kStepRows;
+constexpr int kWays = 4;      // entries per LDS bucket
+constexpr int kScratchEntries = 64;  // one per lane, behind the table proper
+constexpr int kInitialReplicas = PRISM_STREAM_REPLICAS;  // halved whenever the table fills up
+constexpr uint32_t kReplicaSalt = 0x7FEB352Du;
 
 // Pointers read from descriptor arrays are generic; telling the compiler that they
 // point to global memory turns the column reads into global_load instructions (a flat
@@ -32,35 +59,50 @@ constexpr int kLdsProbes = 16;
 template <typename T>
 using GlobalPtr = const __attribute__((address_space(1))) T*;
 typedef unsigned long long __attribute__((aligned(1))) unaligned_u64;
+typedef uint32_t __attribute__((aligned(1))) unaligned_u32;
 
 __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
   uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
   return ((uint64_t)hi << 32) | lo;
 }
 
+// Lane predicate from a wave-uniform 64-bit mask (bit = lane).
+__device__ __forceinline__ bool lane_bit(uint64_t mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
+
 template <bool K32>
 using KeyT = std::conditional_t<K32, uint32_t, uint64_t>;
 
-// The workgroup's LDS table.  It is split into 2^rep_log2 replicas of S >> rep_log2
-// entries each; a lane uses the replica picked by its lane number.  Rows of a hot
-// group that meet in one wave instruction then update different addresses instead of
-// serialising on one (LDS atomics to the same address are applied one lane at a
-// time), at the price of holding each group up to 2^rep_log2 times.
+// The workgroup's LDS table: S entries in buckets of kWays, then kScratchEntries
+// entries that nobody reads.  state[slot][stride], keys[S].
 template <bool K32>
 struct Lds {
-  long long* state;   // [n_slots][S]
-  KeyT<K32>* keys;    // [S]
+  long long* state;
+  KeyT<K32>* keys;
   int S;
-  int rep_log2;
+  int stride;        // S + kScratchEntries
+  int bucket_shift;  // 32 - log2(S / kWays)
+  // Replicas: a lane adds `salt` (a multiple of its lane number modulo the replica
+  // count) to the key's hash, so the rows of one group that meet in one wave
+  // instruction land in up to `replicas` different entries.  LDS atomics of a wave are
+  // processed 16 lanes at a time and lanes of those 16 that hit the same address are
+  // applied one after the other (2 cycles each), which is what bounds this kernel when
+  // a few groups are hot.  Replicas of a group are merged when the table is flushed.
+  int replicas;
+  uint32_t salt;
 };
 
-template <int NK, int NV>
+// K32 plans only ever use the low 32 bits of a key value, so they load only those: a
+// register that is loaded but never read gets reused by the compiler, and the write
+// after the load then has to wait for the load to land.
+template <int NK, int NV, bool K32>
 struct RowBatch {
   static constexpr int NKA = NK > 0 ? NK : 1, NVA = NV > 0 ? NV : 1;
-  unsigned long long kraw[NKA][kU];
+  std::conditional_t<K32, uint32_t, unsigned long long> kraw[NKA][kU];
   unsigned long long vraw[NVA][kU];
-  uint32_t kok[NKA], vok[NVA];  // validity masks, bit u = row u
-  uint32_t live;                // rows that exist and are selected
+  // validity / selection words of the wave's kU runs (the same value in every lane)
+  unsigned long long kokw[NKA][kU], vokw[NVA][kU], selw[kU];
+  bool knull[NKA], vnull[NVA];  // the column has a validity bitmap in this segment
+  uint64_t tail[kU];            // lanes whose row exists
 };
 
 template <int NK, int NV, bool K32>
@@ -68,8 +110,9 @@ struct PackedRows {
   static constexpr int NVA = NV > 0 ? NV : 1;
   KeyT<K32> key[kU];
   long long val[NVA][kU];
-  uint32_t vok[NVA];
-  uint32_t live;
+  uint64_t vok[NVA][kU];  // lane masks
+  bool vnull[NVA];
+  uint64_t live[kU];      // lanes whose row exists and is selected
 };
 
 // Wave-uniform description of the segment the workgroup is walking.
@@ -109,230 +152,309 @@ __device__ __forceinline__ void seek(const AggParams& p, uint64_t tile, SegCurso
   }
 }
 
-// kU values of one column: a uniform base (column start + tile start) plus a 32-bit
-// per-lane byte offset.  One unaligned 8-byte load per value whatever the width: the
-// bytes beyond the value belong to the next rows or to the allocation's padding and
-// are dropped by widen().  Unaligned global loads are part of the amdhsa ABI.
+// kU values of one column: a uniform base (column start + tile start, in scalar
+// registers) plus a 32-bit per-lane byte offset.  One unaligned load of sizeof(T) bytes
+// per value whatever the column width: the bytes beyond the value belong to the next
+// rows or to the allocation's padding and are dropped by widen().  Unaligned global
+// loads are part of the amdhsa ABI.  Widths are powers of two, so the offsets are shifts.
+template <typename T>
 __device__ __forceinline__ void load_rows(uint64_t col_base, uint64_t tile_row0, int width, const uint32_t (&rel)[kU],
-                                          unsigned long long (&out)[kU]) {
-  GlobalPtr<unsigned char> tp = (GlobalPtr<unsigned char>)(col_base + tile_row0 * (uint64_t)width);
+                                          T (&out)[kU]) {
+  typedef T __attribute__((aligned(1))) unaligned_t;
+  const int lw = __builtin_ctz((unsigned)width);
+  GlobalPtr<unsigned char> tp = (GlobalPtr<unsigned char>)(col_base + (tile_row0 << lw));
 #pragma unroll
-  for (int u = 0; u < kU; ++u) out[u] = *(const __attribute__((address_space(1))) unaligned_u64*)(tp + rel[u] * (uint32_t)width);
+  for (int u = 0; u < kU; ++u) out[u] = *(const __attribute__((address_space(1))) unaligned_t*)(tp + (rel[u] << lw));
 }
 
-// Validity bits of the kU rows (all ones when the column has no bitmap).
-__device__ __forceinline__ uint32_t load_valid(uint64_t validity, uint64_t tile_row0, const uint32_t (&rel)[kU]) {
-  if (validity == 0) return (1u << kU) - 1u;
-  GlobalPtr<unsigned long long> b = (GlobalPtr<unsigned long long>)validity + (tile_row0 >> 6);
-  unsigned long long w[kU];
+// The kU consecutive bitmap words that cover the wave's rows of this step.  The address
+// is wave-uniform; bitmaps are allocated in whole tiles, so the words exist even where
+// the rows do not.
+__device__ __forceinline__ void load_words(uint64_t bitmap, uint64_t first_word, unsigned long long (&out)[kU]) {
+  GlobalPtr<unsigned long long> w = (GlobalPtr<unsigned long long>)bitmap + first_word;
 #pragma unroll
-  for (int u = 0; u < kU; ++u) w[u] = b[rel[u] >> 6];
-  uint32_t m = 0;
-#pragma unroll
-  for (int u = 0; u < kU; ++u) m |= (uint32_t)((w[u] >> (rel[u] & 63)) & 1ull) << u;
-  return m;
+  for (int u = 0; u < kU; ++u) out[u] = w[u];
 }
 
-template <int NK, int NV>
-__device__ __forceinline__ void issue(const AggParams& p, uint64_t j, SegCursor<NK, NV>& c, RowBatch<NK, NV>& b) {
+template <int NK, int NV, bool K32>
+__device__ __forceinline__ void issue(const AggParams& p, uint64_t j, uint32_t wave, uint32_t lane, SegCursor<NK, NV>& c,
+                                      RowBatch<NK, NV, K32>& b) {
   const uint64_t tile = j / kStepsPerTile;
   const uint32_t step = (uint32_t)(j % kStepsPerTile);
   seek(p, tile, c);
   const uint64_t tile_row0 = (tile - c.tile_base) * kTileRows;
   const uint64_t left = c.seg_rows - tile_row0;  // rows of the segment from this tile on (>= 1)
   const uint32_t last_rel = left > kTileRows ? kTileRows - 1 : (uint32_t)left - 1;
-  const uint32_t rel0 = step * kU * kBlock + threadIdx.x;
+  const uint32_t wave_rel0 = step * kStepRows + wave * kWaveRows;  // uniform
   uint32_t rel[kU];
-  uint32_t live = 0;
 #pragma unroll
   for (int u = 0; u < kU; ++u) {
-    uint32_t r = rel0 + u * kBlock;
-    live |= (r <= last_rel ? 1u : 0u) << u;
+    const uint32_t r = wave_rel0 + u * 64 + lane;
+    b.tail[u] = __ballot(r <= last_rel);
     rel[u] = r < last_rel ? r : last_rel;  // clamped: every lane loads, dead lanes discard
   }
 #pragma unroll
   for (int k = 0; k < NK; ++k) load_rows(c.kval[k], tile_row0, p.keys[k].width, rel, b.kraw[k]);
 #pragma unroll
   for (int v = 0; v < NV; ++v) load_rows(c.vval[v], tile_row0, p.vals[v].width, rel, b.vraw[v]);
-  if (p.row_mode == kRowsBitmap) {
-    GlobalPtr<unsigned long long> sb = (GlobalPtr<unsigned long long>)p.sel_bits + tile * kTileWords;
-    unsigned long long w[kU];
+  const uint64_t word0 = wave_rel0 >> 6;
+  if (p.row_mode == kRowsBitmap) load_words((uint64_t)p.sel_bits, tile * kTileWords + word0, b.selw);
 #pragma unroll
-    for (int u = 0; u < kU; ++u) w[u] = sb[(rel0 + u * kBlock) >> 6];
-    uint32_t m = 0;
-#pragma unroll
-    for (int u = 0; u < kU; ++u) m |= (uint32_t)((w[u] >> ((rel0 + u * kBlock) & 63)) & 1ull) << u;
-    live &= m;
+  for (int k = 0; k < NK; ++k) {
+    b.knull[k] = c.kvalid[k] != 0;
+    if (b.knull[k]) load_words(c.kvalid[k], (tile_row0 >> 6) + word0, b.kokw[k]);
   }
 #pragma unroll
-  for (int k = 0; k < NK; ++k) b.kok[k] = load_valid(c.kvalid[k], tile_row0, rel);
-#pragma unroll
-  for (int v = 0; v < NV; ++v) b.vok[v] = load_valid(c.vvalid[v], tile_row0, rel);
-  b.live = live;
+  for (int v = 0; v < NV; ++v) {
+    b.vnull[v] = c.vvalid[v] != 0;
+    if (b.vnull[v]) load_words(c.vvalid[v], (tile_row0 >> 6) + word0, b.vokw[v]);
+  }
 }
 
 // Low 32 bits of a fixed-width value from the 8 bytes loaded at its address, without
 // branching on the width: shift the value to the top of the dword and back down,
 // arithmetically for signed types.
-__device__ __forceinline__ uint32_t widen_lo(unsigned long long raw, int width, int is_unsigned) {
+__device__ __forceinline__ uint32_t widen_lo(uint32_t raw, int width, int is_unsigned) {
   const int sh = width >= 4 ? 0 : 16;
-  const uint32_t x = (uint32_t)raw << sh;
+  const uint32_t x = raw << sh;
   return is_unsigned ? (x >> sh) : (uint32_t)((int)x >> sh);
 }
 
 // The full value, also branch free.
 __device__ __forceinline__ long long widen(unsigned long long raw, int width, int is_unsigned) {
-  const uint32_t lo = widen_lo(raw, width, is_unsigned);
+  const uint32_t lo = widen_lo((uint32_t)raw, width, is_unsigned);
   const uint32_t ext = is_unsigned ? 0u : (uint32_t)((int)lo >> 31);
   const uint32_t hi = width == 8 ? (uint32_t)(raw >> 32) : ext;
   return (long long)(((unsigned long long)hi << 32) | lo);
 }
 
-// n / d for a divisor described by (magic, pre, shift), including d == 1
-// (magic 0, pre 0, shift 0), without a branch.
+// n / d for a divisor described by (magic, pre, shift).
 __device__ __forceinline__ uint32_t fast_div32(uint32_t n, uint32_t magic, int pre, int shift) {
   uint32_t q = __umulhi(magic, n);
   uint32_t t = ((n - q) >> pre) + q;
   return t >> shift;
 }
 
+// Branches below are on kernel arguments or on per-segment facts, so they are scalar
+// branches taken once per step (kU rows), not per row.
 template <int NK, int NV, bool K32>
-__device__ __forceinline__ void convert(const AggParams& p, const RowBatch<NK, NV>& b, PackedRows<NK, NV, K32>& out) {
+__device__ __forceinline__ void convert(const AggParams& p, const RowBatch<NK, NV, K32>& b, PackedRows<NK, NV, K32>& out) {
 #pragma unroll
-  for (int u = 0; u < kU; ++u) {
-    KeyT<K32> key = 0;
+  for (int u = 0; u < kU; ++u) out.key[u] = 0;
 #pragma unroll
-    for (int k = 0; k < NK; ++k) {
-      const KeySpec& ks = p.keys[k];
-      // Both alternatives (field, NULL marker) are computed from values in registers and
-      // selected by value: selecting between the addresses of two descriptor fields
-      // would become a vector load from the kernel arguments and stall the pipeline.
-      const int bit_pos = ks.bit_pos, null_bit = ks.null_bit;
-      const KeyT<K32> null_field = null_bit >= 0 ? ((KeyT<K32>)1 << null_bit) : (KeyT<K32>)0;
-      KeyT<K32> field;
-      if (K32) {
-        // every key of a K32 plan has the 32-bit form: (value - base) / divisor, with
-        // divisor 1 for a plain column and the stride for date_bin
-        field = fast_div32(widen_lo(b.kraw[k][u], ks.width, ks.is_unsigned) - (uint32_t)ks.base, ks.magic32, ks.pre32,
-                           ks.shift32);
-      } else {
+  for (int k = 0; k < NK; ++k) {
+    const KeySpec& ks = p.keys[k];
+    KeyT<K32> field[kU];
+    if (K32) {
+      // every key of a K32 plan has the 32-bit form: (value - base) / divisor, with
+      // divisor 1 for a plain column and the stride for date_bin
+#pragma unroll
+      for (int u = 0; u < kU; ++u) field[u] = widen_lo((uint32_t)b.kraw[k][u], ks.width, ks.is_unsigned) - (uint32_t)ks.base;
+      if (ks.date_bin) {
+#pragma unroll
+        for (int u = 0; u < kU; ++u) field[u] = fast_div32((uint32_t)field[u], ks.magic32, ks.pre32, ks.shift32);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
         long long v = widen(b.kraw[k][u], ks.width, ks.is_unsigned);
         if (ks.date_bin) v = bucket_number(v, ks);
-        field = (KeyT<K32>)((uint64_t)v - (uint64_t)ks.bias);
+        field[u] = (KeyT<K32>)((uint64_t)v - (uint64_t)ks.bias);
       }
-      field <<= bit_pos;
-      key |= ((b.kok[k] >> u) & 1u) ? field : null_field;
     }
-    out.key[u] = key;
+    const int bit_pos = ks.bit_pos;
 #pragma unroll
-    for (int v = 0; v < NV; ++v) out.val[v][u] = widen(b.vraw[v][u], p.vals[v].width, p.vals[v].is_unsigned);
+    for (int u = 0; u < kU; ++u) field[u] <<= bit_pos;
+    if (b.knull[k]) {
+      const KeyT<K32> null_field = (KeyT<K32>)1 << (ks.null_bit >= 0 ? ks.null_bit : 0);
+#pragma unroll
+      for (int u = 0; u < kU; ++u) field[u] = lane_bit(uniform_u64(b.kokw[k][u])) ? field[u] : null_field;
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) out.key[u] |= field[u];
   }
 #pragma unroll
-  for (int v = 0; v < NV; ++v) out.vok[v] = b.vok[v];
-  out.live = b.live;
+  for (int v = 0; v < NV; ++v) {
+    const int width = p.vals[v].width, is_unsigned = p.vals[v].is_unsigned;
+    if (width == 8) {
+#pragma unroll
+      for (int u = 0; u < kU; ++u) out.val[v][u] = (long long)b.vraw[v][u];
+    } else {
+#pragma unroll
+      for (int u = 0; u < kU; ++u) out.val[v][u] = widen(b.vraw[v][u], width, is_unsigned);
+    }
+    out.vnull[v] = b.vnull[v];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) out.vok[v][u] = b.vnull[v] ? uniform_u64(b.vokw[v][u]) : ~0ull;
+  }
+#pragma unroll
+  for (int u = 0; u < kU; ++u) out.live[u] = p.row_mode == kRowsBitmap ? (b.tail[u] & uniform_u64(b.selw[u])) : b.tail[u];
 }
 
-// Entry of `key` in the LDS table, or -1.  `insert` false: look-up only, a few probes
-// (the table is frozen: it keeps the groups it has, everything else goes to HBM).
 template <bool K32>
-__device__ __forceinline__ int lds_entry(const Lds<K32>& t, KeyT<K32> key, int* n_entries, bool insert) {
+__device__ __forceinline__ uint32_t lds_bucket(const Lds<K32>& t, KeyT<K32> key) {
+  const uint32_t mixed = K32 ? (uint32_t)key : ((uint32_t)key ^ (uint32_t)((uint64_t)key >> 32));
+  return (mixed * 0x9E3779B1u + t.salt) >> t.bucket_shift;
+}
+
+// Out-of-line part of the look-up: finds the key in, or inserts it into, the first
+// bucket with room at or after its home bucket (the inline part only looks at the home
+// bucket, so a displaced key comes through here every time; few are, since the table is
+// flushed when half full).  Returns the entry, or -1 when kProbeBuckets buckets are all
+// taken by other keys (the row then goes to HBM).
+constexpr int kProbeBuckets = 4;
+template <bool K32>
+__device__ __noinline__ int lds_insert(KeyT<K32>* keys, int first, int mask, KeyT<K32> key, int* n_entries, bool insert) {
   const KeyT<K32> empty = (KeyT<K32>)~(KeyT<K32>)0;
-  const int sub = t.S >> t.rep_log2;  // entries per replica
-  const int mask = sub - 1;
-  // replicas are interleaved (entry = slot * replicas + replica) so that the copies of
-  // one group sit in neighbouring banks rather than in the same one
-  const int rep = (int)(threadIdx.x & ((1u << t.rep_log2) - 1u));
-  uint32_t mixed = K32 ? (uint32_t)key : ((uint32_t)key ^ (uint32_t)((uint64_t)key >> 32));
-  int h = (int)((mixed * 0x9E3779B1u) >> 12) & mask;
-  const int max_probes = insert ? kLdsProbes : 4;
-  for (int probe = 0; probe < max_probes; ++probe) {
-    const int e = (h << t.rep_log2) + rep;
-    KeyT<K32> k = t.keys[e];
-    if (k == key) return e;
-    if (k == empty) {
-      if (!insert) return -1;
-      KeyT<K32> old;
-      if (K32) old = (KeyT<K32>)atomicCAS((unsigned int*)&t.keys[e], 0xffffffffu, (unsigned int)key);
-      else old = (KeyT<K32>)atomicCAS((unsigned long long*)&t.keys[e], ~0ull, (unsigned long long)key);
-      if (old == empty) { atomicAdd(n_entries, 1); return e; }
-      if (old == key) return e;
+  for (int b = 0; b < kProbeBuckets; ++b) {
+    for (int w = 0; w < kWays; ++w) {
+      const int e = first + w;
+      KeyT<K32> k = keys[e];
+      if (k == empty) {
+        if (!insert) return -1;
+        if (K32) k = (KeyT<K32>)atomicCAS((unsigned int*)&keys[e], 0xffffffffu, (unsigned int)key);
+        else k = (KeyT<K32>)atomicCAS((unsigned long long*)&keys[e], ~0ull, (unsigned long long)key);
+        if (k == empty) { atomicAdd(n_entries, 1); return e; }
+      }
+      if (k == key) return e;
     }
-    h = (h + 1) & mask;
+    first = (first + kWays) & mask;
   }
   return -1;
 }
 
-// Applies the kU rows of a lane.  Slot-major: the LDS entries of all rows are looked
-// up first (independent probe chains, so their LDS latencies overlap), then every slot
-// is decoded once and applied to all rows, so the per-slot dispatch is paid per step,
-// not per row.  Rows that found the LDS table full fall through to the HBM table.
+// Applies the kU rows of a lane.
 template <int NK, int NV, bool K32>
-__device__ __forceinline__ void consume(const AggParams& p, const Lds<K32>& t, bool insert, int* n_entries,
+__device__ __forceinline__ void consume(const AggParams& p, const Lds<K32>& t, bool insert, int* n_entries, uint32_t lane,
                                         const PackedRows<NK, NV, K32>& b) {
-  int e[kU];  // LDS entry, -1 = go to HBM, -2 = row not live
+  const KeyT<K32> empty = (KeyT<K32>)~(KeyT<K32>)0;
+  // 1. the four candidate keys of every row's bucket (independent reads, issued together)
+  int first[kU];
+  KeyT<K32> cand[kU][kWays];
 #pragma unroll
   for (int u = 0; u < kU; ++u) {
-    e[u] = -2;
-    if ((b.live >> u) & 1u) {
-      // a 64-bit key equal to the empty marker only lives in the HBM table's extra entry
-      const bool lds_ok = K32 || b.key[u] != (KeyT<K32>)kEmptyKey;
-      e[u] = lds_ok ? lds_entry<K32>(t, b.key[u], n_entries, insert) : -1;
+    first[u] = (int)lds_bucket<K32>(t, b.key[u]) * kWays;
+    if (K32) {
+      const uint4 c = *(const uint4*)&t.keys[first[u]];
+      cand[u][0] = (KeyT<K32>)c.x; cand[u][1] = (KeyT<K32>)c.y; cand[u][2] = (KeyT<K32>)c.z; cand[u][3] = (KeyT<K32>)c.w;
+    } else {
+      const ulonglong2 c0 = *(const ulonglong2*)&t.keys[first[u]], c1 = *(const ulonglong2*)&t.keys[first[u] + 2];
+      cand[u][0] = (KeyT<K32>)c0.x; cand[u][1] = (KeyT<K32>)c0.y; cand[u][2] = (KeyT<K32>)c1.x; cand[u][3] = (KeyT<K32>)c1.y;
     }
   }
+  // 2. the matching way, or -1
+  int e[kU];
+  bool miss = false;
+#pragma unroll
+  for (int u = 0; u < kU; ++u) {
+    int way = -1;
+#pragma unroll
+    for (int w = kWays - 1; w >= 0; --w) way = cand[u][w] == b.key[u] ? w : way;
+    // a 64-bit key equal to the empty marker only lives in the HBM table's extra entry
+    if (!K32 && b.key[u] == empty) way = -1;
+    const bool live = lane_bit(b.live[u]);
+    e[u] = way >= 0 ? first[u] + way : -1;
+    miss |= live && way < 0;
+  }
+  if (__ballot(miss) != 0ull) {
+    // some lane met a key the table does not hold: insert it (or leave it to HBM)
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      if (lane_bit(b.live[u]) && e[u] < 0 && (K32 || b.key[u] != empty))
+        e[u] = lds_insert<K32>(t.keys, first[u], t.S - 1, b.key[u], n_entries, insert);
+    }
+  }
+  // 3. byte offset of the entry to update: the row's, or the lane's scratch entry
+  uint32_t off[kU];
+  bool to_hbm = false;
+#pragma unroll
+  for (int u = 0; u < kU; ++u) {
+    const bool live = lane_bit(b.live[u]);
+    const bool hit = live && e[u] >= 0;
+    off[u] = (uint32_t)(hit ? e[u] : t.S + (int)lane) * 8u;
+    to_hbm |= live && e[u] < 0;
+  }
+  // 4. slot major: every slot is decoded once and applied to all rows
+  char* const state = (char*)t.state;
   for (int s = 0; s < p.n_slots; ++s) {
     const int op = p.slots[s].op, val = p.slots[s].val;
-    long long* base = t.state + s * t.S;
+    char* const base = state + (uint32_t)(s * t.stride) * 8u;
     if (op == kSlotAddOne) {
 #pragma unroll
-      for (int u = 0; u < kU; ++u)
-        if (e[u] >= 0) atomicAdd((unsigned long long*)&base[e[u]], 1ull);
+      for (int u = 0; u < kU; ++u) atomicAdd((unsigned long long*)(base + off[u]), 1ull);
       continue;
     }
     // the slot's input column, picked by a select chain (a runtime index would put the
     // values in scratch memory)
-    uint32_t ok = 0;
     long long x[kU];
+    uint64_t ok[kU];
+    bool has_null = false;
 #pragma unroll
-    for (int u = 0; u < kU; ++u) x[u] = 0;
+    for (int u = 0; u < kU; ++u) { x[u] = 0; ok[u] = ~0ull; }
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       if (v == val) {
-        ok = b.vok[v];
+        has_null = b.vnull[v];
 #pragma unroll
-        for (int u = 0; u < kU; ++u) x[u] = b.val[v][u];
+        for (int u = 0; u < kU; ++u) { x[u] = b.val[v][u]; ok[u] = b.vok[v][u]; }
       }
     }
-    const bool is_float = val >= 0 && p.vals[val].is_float;
+    if (op == kSlotAddValid) {
 #pragma unroll
-    for (int u = 0; u < kU; ++u) {
-      if (e[u] < 0 || !((ok >> u) & 1u)) continue;
-      long long* addr = &base[e[u]];
-      if (op == kSlotAddValid) atomicAdd((unsigned long long*)addr, 1ull);
-      else if (op == kSlotAddI64) atomicAdd((unsigned long long*)addr, (unsigned long long)x[u]);
-      else if (op == kSlotMax) atomicMax(addr, x[u]);
-      else if (op == kSlotMin) atomicMin(addr, x[u]);
-      else atomicAdd((double*)addr, is_float ? __longlong_as_double(x[u]) : (double)x[u]);
+      for (int u = 0; u < kU; ++u) atomicAdd((unsigned long long*)(base + off[u]), lane_bit(ok[u]) ? 1ull : 0ull);
+    } else if (op == kSlotAddI64) {
+      if (has_null) {
+#pragma unroll
+        for (int u = 0; u < kU; ++u) x[u] = lane_bit(ok[u]) ? x[u] : 0ll;
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) atomicAdd((unsigned long long*)(base + off[u]), (unsigned long long)x[u]);
+    } else if (op == kSlotMax) {
+      if (has_null) {
+#pragma unroll
+        for (int u = 0; u < kU; ++u) x[u] = lane_bit(ok[u]) ? x[u] : kI64Min;
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) atomicMax((long long*)(base + off[u]), x[u]);
+    } else if (op == kSlotMin) {
+      if (has_null) {
+#pragma unroll
+        for (int u = 0; u < kU; ++u) x[u] = lane_bit(ok[u]) ? x[u] : kI64Max;
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) atomicMin((long long*)(base + off[u]), x[u]);
+    } else {
+      const bool is_float = val >= 0 && p.vals[val].is_float;
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        double d = is_float ? __longlong_as_double(x[u]) : (double)x[u];
+        d = lane_bit(ok[u]) ? d : -0.0;  // x + -0.0 == x for every x, signed zeros included
+        atomicAdd((double*)(base + off[u]), d);
+      }
     }
   }
+  // 5. rows the LDS table could not take
+  if (__ballot(to_hbm) != 0ull) {
 #pragma unroll
-  for (int u = 0; u < kU; ++u) {
-    if (e[u] != -1) continue;
-    RowValsT<NV> rv;
-    rv.valid = 0;
+    for (int u = 0; u < kU; ++u) {
+      if (!(lane_bit(b.live[u]) && e[u] < 0)) continue;
+      RowValsT<NV> rv;
+      rv.valid = 0;
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      rv.v[v] = b.val[v][u];
-      rv.valid |= ((b.vok[v] >> u) & 1u) << v;
+      for (int v = 0; v < NV; ++v) {
+        rv.v[v] = b.val[v][u];
+        rv.valid |= (lane_bit(b.vok[v][u]) ? 1u : 0u) << v;
+      }
+      global_update(p, (uint64_t)b.key[u], rv);
     }
-    global_update(p, (uint64_t)b.key[u], rv);
   }
 }
 
 template <bool K32>
 __device__ __forceinline__ void lds_clear(const AggParams& p, const Lds<K32>& t) {
-  for (int i = threadIdx.x; i < t.S; i += blockDim.x) {
-    t.keys[i] = (KeyT<K32>)~(KeyT<K32>)0;
-    for (int s = 0; s < p.n_slots; ++s) t.state[s * t.S + i] = slot_identity(p.slots[s].op);
+  for (int i = threadIdx.x; i < t.stride; i += blockDim.x) {
+    if (i < t.S) t.keys[i] = (KeyT<K32>)~(KeyT<K32>)0;
+    for (int s = 0; s < p.n_slots; ++s) t.state[s * t.stride + i] = slot_identity(p.slots[s].op);
   }
 }
 
@@ -347,64 +469,76 @@ __device__ __forceinline__ void lds_flush(const AggParams& p, const Lds<K32>& t)
     uint64_t e = global_entry(p, (uint64_t)key);
     for (int s = 0; s < p.n_slots; ++s) {
       int op = p.slots[s].op;
-      long long v = t.state[s * t.S + i];
+      long long v = t.state[s * t.stride + i];
       if (e != ~0ull && v != slot_identity(op)) atomic_apply(&p.g_state[(uint64_t)s * (p.capacity + 1) + e], op, v);
-      t.state[s * t.S + i] = slot_identity(op);
+      t.state[s * t.stride + i] = slot_identity(op);
     }
     t.keys[i] = empty;
   }
 }
 
 template <int NK, int NV, bool K32>
-__global__ __launch_bounds__(kBlock) void k_group_by_stream(AggParams p) {
-  extern __shared__ unsigned long long lds_raw[];
+__global__ __launch_bounds__(kStreamBlock) void k_group_by_stream(AggParams p) {
+  extern __shared__ __align__(16) unsigned long long lds_raw[];
   __shared__ int n_entries;
-  constexpr int kInitialRepLog2 = 0;
   Lds<K32> t;
   t.S = p.lds_slots;
-  t.rep_log2 = kInitialRepLog2;
+  t.stride = t.S + kScratchEntries;
+  t.bucket_shift = 32 - (31 - __builtin_clz((unsigned)(t.S / kWays)));
   t.state = (long long*)lds_raw;
-  t.keys = (KeyT<K32>*)(lds_raw + (size_t)p.n_slots * t.S);
+  t.keys = (KeyT<K32>*)(lds_raw + (size_t)p.n_slots * t.stride);
+  t.replicas = kInitialReplicas;
+  t.salt = (threadIdx.x & (uint32_t)(t.replicas - 1)) * kReplicaSalt;
   if (threadIdx.x == 0) n_entries = 0;
   lds_clear<K32>(p, t);
   __syncthreads();
 
-  const uint64_t per = ceil_div(p.sd.n_tiles, (uint64_t)gridDim.x);
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  // The division runs on the vector ALU (there is no scalar one); without the
+  // readfirstlane everything derived from it, the segment cursor included, would be
+  // kept in vector registers and every uniform branch below would become a masked one.
+  const uint64_t per = uniform_u64(ceil_div(p.sd.n_tiles, (uint64_t)gridDim.x));
   const uint64_t t0 = per * blockIdx.x, t1 = t0 + per < p.sd.n_tiles ? t0 + per : p.sd.n_tiles;
   const uint64_t j0 = t0 * kStepsPerTile, j1 = t1 * kStepsPerTile;
   uint64_t rows_since_flush = 0;
   bool insert = true;  // false once the table is frozen
 
   SegCursor<NK, NV> cur;
-  RowBatch<NK, NV> raw;
+  RowBatch<NK, NV, K32> raw;
   PackedRows<NK, NV, K32> rows;
-  if (j0 < j1) issue(p, j0, cur, raw);
+  if (j0 < j1) issue<NK, NV, K32>(p, j0, wave, lane, cur, raw);
   for (uint64_t j = j0; j < j1; ++j) {
     convert<NK, NV, K32>(p, raw, rows);
     // The scheduling barriers keep the next step's loads from being hoisted above the
     // conversion (which would make the conversion wait for them too) and from being
     // sunk into the hashing (which would shorten the time they have to land).
     __builtin_amdgcn_sched_barrier(0);
-    if (j + 1 < j1) issue(p, j + 1, cur, raw);
+    if (j + 1 < j1) issue<NK, NV, K32>(p, j + 1, wave, lane, cur, raw);
     __builtin_amdgcn_sched_barrier(0);
-    consume<NK, NV, K32>(p, t, insert, &n_entries, rows);
+    consume<NK, NV, K32>(p, t, insert, &n_entries, lane, rows);
     if (insert && (j + 1) % kStepsPerTile == 0) {
       // Block-wide bookkeeping at the end of a tile, when the LDS table is half full.
-      // Keys that repeat a lot: fold the table into HBM and start over (with fewer
-      // copies per group if replicas were in use).  Keys that hardly repeat (high
-      // cardinality): freeze the table instead.  It then keeps the groups it has, which
-      // are the frequent ones (they show up first), so the hot groups still cost HBM no
-      // per-row atomics on one address, and every other row goes straight to HBM.
+      // Keys that repeat a lot: fold the table into HBM and start over, with half as
+      // many replicas per group if there was more than one.  Keys that
+      // hardly repeat (high cardinality): freeze the table instead.  It then keeps the
+      // groups it has, which are the frequent ones (they show up first), so the hot
+      // groups still cost HBM no per-row atomics on one address, and every other row
+      // goes straight to HBM.
       rows_since_flush += kTileRows;
       __syncthreads();
       const int n = n_entries;
       __syncthreads();
       if (n > t.S / 2) {
-        if (t.rep_log2 == 0 && (uint64_t)n * 4 > rows_since_flush) {
+        if (t.replicas == 1 && (uint64_t)n * 4 > rows_since_flush) {
           insert = false;
         } else {
           lds_flush<K32>(p, t);
-          if (t.rep_log2 > 0) t.rep_log2 -= 1;
+          // fewer replicas only if the table filled quickly: when it took long, it holds
+          // groups that are no longer coming (sorted input), not too many copies
+          if (t.replicas > 1 && rows_since_flush < 32 * kTileRows) {
+            t.replicas >>= 1;
+            t.salt = (threadIdx.x & (uint32_t)(t.replicas - 1)) * kReplicaSalt;
+          }
           if (threadIdx.x == 0) n_entries = 0;
           rows_since_flush = 0;
           __syncthreads();
@@ -441,10 +575,17 @@ GroupByKernel pick_nk(int nk, int nv) {
 
 }  // namespace
 
-GroupByKernel pick_stream_kernel(const AggParams& p, size_t* lds_bytes) {
+GroupByKernel pick_stream_kernel(const AggParams& p, size_t* lds_bytes, uint32_t* block, int* lds_slots) {
   bool k32 = p.key_bits <= 31;
   for (int k = 0; k < p.n_keys; ++k) k32 = k32 && p.keys[k].fast32 != 0;
-  *lds_bytes = (size_t)p.lds_slots * (8 * (size_t)p.n_slots + (k32 ? 4 : 8));
+  // the largest power-of-two table that fits the workgroup's share of the CU's LDS
+  const size_t per_entry = 8 * (size_t)p.n_slots + (k32 ? 4 : 8);
+  const size_t budget = (size_t)PRISM_STREAM_LDS_KB * 1024 - (size_t)kScratchEntries * 8 * (size_t)p.n_slots - 64;
+  int S = 256;
+  while ((size_t)S * 2 * per_entry <= budget && S < 8192) S *= 2;
+  *lds_slots = S;
+  *block = kStreamBlock;
+  *lds_bytes = (size_t)(S + kScratchEntries) * 8 * (size_t)p.n_slots + (size_t)S * (k32 ? 4 : 8);
   return k32 ? pick_nk<true>(p.n_keys, p.n_vals) : pick_nk<false>(p.n_keys, p.n_vals);
 }
 

@@ -58,7 +58,7 @@ bool bit_at(const uint8_t* bits, int64_t i) { return (bits[i >> 3] >> (i & 7)) &
 
 // Validity bits [offset, offset + n) re-aligned to bit 0, as 64-bit words.
 std::vector<uint64_t> realign_validity(const uint8_t* bits, int64_t offset, int64_t n) {
-  std::vector<uint64_t> out((size_t)ceil_div((uint64_t)n, 64) + 1, 0);
+  std::vector<uint64_t> out((size_t)ceil_div((uint64_t)n, kTileRows) * kTileWords, 0);  // whole tiles: kernels read a tile's words even past the last row
   if ((offset & 7) == 0) {
     std::memcpy(out.data(), bits + (offset >> 3), (size_t)ceil_div((uint64_t)n, 8));
     if (n & 63) out[(size_t)(n >> 6)] &= (1ull << (n & 63)) - 1ull;
