@@ -248,8 +248,13 @@ __device__ __forceinline__ void convert(const AggParams& p, const RowBatch<NK, N
     if (K32) {
       // every key of a K32 plan has the 32-bit form: (value - base) / divisor, with
       // divisor 1 for a plain column and the stride for date_bin
+      if (ks.width >= 4) {
 #pragma unroll
-      for (int u = 0; u < kU; ++u) field[u] = widen_lo((uint32_t)b.kraw[k][u], ks.width, ks.is_unsigned) - (uint32_t)ks.base;
+        for (int u = 0; u < kU; ++u) field[u] = (uint32_t)b.kraw[k][u] - (uint32_t)ks.base;
+      } else {
+#pragma unroll
+        for (int u = 0; u < kU; ++u) field[u] = widen_lo((uint32_t)b.kraw[k][u], ks.width, ks.is_unsigned) - (uint32_t)ks.base;
+      }
       if (ks.date_bin) {
 #pragma unroll
         for (int u = 0; u < kU; ++u) field[u] = fast_div32((uint32_t)field[u], ks.magic32, ks.pre32, ks.shift32);
@@ -323,6 +328,47 @@ __device__ __noinline__ int lds_insert(KeyT<K32>* keys, int first, int mask, Key
   return -1;
 }
 
+// One slot, kU rows: NULL inputs are replaced by the slot's identity instead of being
+// masked off.
+__device__ __forceinline__ void apply_slot(int op, char* base, const uint32_t (&off)[kU], const long long (&val)[kU],
+                                           const uint64_t (&ok)[kU], bool has_null, bool is_float) {
+  long long x[kU];
+#pragma unroll
+  for (int u = 0; u < kU; ++u) x[u] = val[u];
+  if (op == kSlotAddValid) {
+#pragma unroll
+    for (int u = 0; u < kU; ++u) atomicAdd((unsigned long long*)(base + off[u]), lane_bit(ok[u]) ? 1ull : 0ull);
+  } else if (op == kSlotAddI64) {
+    if (has_null) {
+#pragma unroll
+      for (int u = 0; u < kU; ++u) x[u] = lane_bit(ok[u]) ? x[u] : 0ll;
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) atomicAdd((unsigned long long*)(base + off[u]), (unsigned long long)x[u]);
+  } else if (op == kSlotMax) {
+    if (has_null) {
+#pragma unroll
+      for (int u = 0; u < kU; ++u) x[u] = lane_bit(ok[u]) ? x[u] : kI64Min;
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) atomicMax((long long*)(base + off[u]), x[u]);
+  } else if (op == kSlotMin) {
+    if (has_null) {
+#pragma unroll
+      for (int u = 0; u < kU; ++u) x[u] = lane_bit(ok[u]) ? x[u] : kI64Max;
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) atomicMin((long long*)(base + off[u]), x[u]);
+  } else {
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      double d = is_float ? __longlong_as_double(x[u]) : (double)x[u];
+      d = lane_bit(ok[u]) ? d : -0.0;  // x + -0.0 == x for every x, signed zeros included
+      atomicAdd((double*)(base + off[u]), d);
+    }
+  }
+}
+
 // Applies the kU rows of a lane.
 template <int NK, int NV, bool K32>
 __device__ __forceinline__ void consume(const AggParams& p, const Lds<K32>& t, bool insert, int* n_entries, uint32_t lane,
@@ -384,53 +430,12 @@ __device__ __forceinline__ void consume(const AggParams& p, const Lds<K32>& t, b
       for (int u = 0; u < kU; ++u) atomicAdd((unsigned long long*)(base + off[u]), 1ull);
       continue;
     }
-    // the slot's input column, picked by a select chain (a runtime index would put the
-    // values in scratch memory)
-    long long x[kU];
-    uint64_t ok[kU];
-    bool has_null = false;
-#pragma unroll
-    for (int u = 0; u < kU; ++u) { x[u] = 0; ok[u] = ~0ull; }
+    // the slot's input column is picked by a (scalar) branch per column: a runtime index
+    // would put the values in scratch memory, a select chain costs two selects per row
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      if (v == val) {
-        has_null = b.vnull[v];
-#pragma unroll
-        for (int u = 0; u < kU; ++u) { x[u] = b.val[v][u]; ok[u] = b.vok[v][u]; }
-      }
-    }
-    if (op == kSlotAddValid) {
-#pragma unroll
-      for (int u = 0; u < kU; ++u) atomicAdd((unsigned long long*)(base + off[u]), lane_bit(ok[u]) ? 1ull : 0ull);
-    } else if (op == kSlotAddI64) {
-      if (has_null) {
-#pragma unroll
-        for (int u = 0; u < kU; ++u) x[u] = lane_bit(ok[u]) ? x[u] : 0ll;
-      }
-#pragma unroll
-      for (int u = 0; u < kU; ++u) atomicAdd((unsigned long long*)(base + off[u]), (unsigned long long)x[u]);
-    } else if (op == kSlotMax) {
-      if (has_null) {
-#pragma unroll
-        for (int u = 0; u < kU; ++u) x[u] = lane_bit(ok[u]) ? x[u] : kI64Min;
-      }
-#pragma unroll
-      for (int u = 0; u < kU; ++u) atomicMax((long long*)(base + off[u]), x[u]);
-    } else if (op == kSlotMin) {
-      if (has_null) {
-#pragma unroll
-        for (int u = 0; u < kU; ++u) x[u] = lane_bit(ok[u]) ? x[u] : kI64Max;
-      }
-#pragma unroll
-      for (int u = 0; u < kU; ++u) atomicMin((long long*)(base + off[u]), x[u]);
-    } else {
-      const bool is_float = val >= 0 && p.vals[val].is_float;
-#pragma unroll
-      for (int u = 0; u < kU; ++u) {
-        double d = is_float ? __longlong_as_double(x[u]) : (double)x[u];
-        d = lane_bit(ok[u]) ? d : -0.0;  // x + -0.0 == x for every x, signed zeros included
-        atomicAdd((double*)(base + off[u]), d);
-      }
+      if (v != val) continue;
+      apply_slot(op, base, off, b.val[v], b.vok[v], b.vnull[v], p.vals[v].is_float != 0);
     }
   }
   // 5. rows the LDS table could not take

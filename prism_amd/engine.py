@@ -17,7 +17,8 @@ from . import _cabi as abi
 from .plan import QueryPlan, lower
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libprism_gpu.so")
+# PRISM_GPU_LIB points at another build of the same library (kernel tuning experiments)
+LIB_PATH = os.environ.get("PRISM_GPU_LIB") or os.path.join(_HERE, "lib", "libprism_gpu.so")
 
 # every symbol include/prism_gpu.h declares
 EXPORTED_SYMBOLS = [
