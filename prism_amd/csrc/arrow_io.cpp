@@ -80,6 +80,10 @@ namespace {
 
 struct BatchOwner {
   std::vector<std::unique_ptr<uint8_t[]>> blocks;
+  // 8-byte columns are not copied: their vectors move in here and the Arrow buffers
+  // point at them
+  std::vector<std::vector<int64_t>> kept_i64;
+  std::vector<std::vector<double>> kept_f64;
   std::vector<std::vector<const void*>> buffer_lists;
   std::vector<ArrowArray> children;
   std::vector<ArrowArray*> child_ptrs;
@@ -136,8 +140,9 @@ void export_record_batch(std::vector<OutColumn>& cols, ArrowArray* out) {
       size_t total = 0;
       for (size_t i = 0; i < n; ++i) total += col.valid[i] ? col.str_at(i).size() : 0;
       if (total > 0x7fffffffull) fail(PRISM_GPU_EUNSUPPORTED, "string output exceeds 2 GiB");
-      int32_t* off = (int32_t*)owner->block((n + 1) * 4);
-      uint8_t* data = owner->block(total);
+      int32_t* off = (int32_t*)owner->block((n + 1) * 4, false);
+      off[0] = 0;
+      uint8_t* data = owner->block(total, false);
       size_t pos = 0;
       for (size_t i = 0; i < n; ++i) {
         if (col.valid[i]) {
@@ -150,13 +155,11 @@ void export_record_batch(std::vector<OutColumn>& cols, ArrowArray* out) {
       bl.push_back(off);
       bl.push_back(data);
     } else if (col.type.is_float) {
-      double* v = (double*)owner->block(n * 8);
-      if (n) std::memcpy(v, col.f64.data(), n * 8);
-      bl.push_back(v);
+      owner->kept_f64.push_back(std::move(col.f64));
+      bl.push_back(owner->kept_f64.back().data());
     } else if (col.type.width == 8) {
-      int64_t* v = (int64_t*)owner->block(n * 8);
-      if (n) std::memcpy(v, col.i64.data(), n * 8);
-      bl.push_back(v);
+      owner->kept_i64.push_back(std::move(col.i64));
+      bl.push_back(owner->kept_i64.back().data());
     } else if (col.type.width == 4) {
       int32_t* v = (int32_t*)owner->block(n * 4);
       for (size_t i = 0; i < n; ++i) v[i] = (int32_t)col.i64[i];
