@@ -44,7 +44,18 @@ def main() -> int:
     ap.add_argument("--cpu-sample-partitions", type=int, default=8,
                     help="leading partitions of rank 0 the CPU baseline and the parity check run on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "state", "arrow"],
+                    help="merge between GPUs: device-resident group tables (state) or PARTIAL Arrow batches (arrow); "
+                         "auto = state when the plan allows it.  With one GPU, state/arrow run the same code in a "
+                         "one-rank group (to measure the exchange's overhead)")
     args = ap.parse_args()
+
+    # Exactly one line goes to stdout: RCCL prints a version banner there when the
+    # communicator is created, so everything else written to fd 1 is sent to stderr and the
+    # JSON line is written to the saved descriptor.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -59,14 +70,16 @@ def main() -> int:
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    grouped = world > 1 or args.exchange != "auto"
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from prism_amd import _cabi as abi
     from prism_amd import workloads
-    from prism_amd.distributed import all_gather_tables
-    from prism_amd.engine import Context, Plan
+    from prism_amd.distributed import all_gather_tables, exchange_and_finish
+    from prism_amd.engine import Context, Plan, PrismGpuError
 
     wl = workloads.WORKLOADS[args.workload]()
     rows = args.rows or wl.default_rows
@@ -80,11 +93,29 @@ def main() -> int:
     log(f"[rank {rank}] generated {rows:,} rows in {parts} partitions in {time.time() - t0:.1f}s")
 
     single = Plan(ctx, wl.schema, wl.query)
-    partial = Plan(ctx, wl.schema, wl.query.with_mode(abi.MODE_PARTIAL)) if world > 1 else None
+    partial = Plan(ctx, wl.schema, wl.query.with_mode(abi.MODE_PARTIAL)) if grouped else None
+
+    # How the per-GPU aggregates meet: on the group tables in HBM when the plan allows it
+    # (every rank takes the same decision: it depends on the plan only), else as PARTIAL
+    # Arrow batches.
+    exchange = "none (single GPU)"
+    if grouped:
+        exchange = args.exchange
+        if exchange in ("auto", "state"):
+            try:
+                exchange_and_finish(single, table, None, device)
+                exchange = "state"
+            except PrismGpuError as e:
+                if e.code != abi.EUNSUPPORTED or args.exchange == "state":
+                    raise
+                exchange = "arrow"
+        log(f"[rank {rank}] exchange between GPUs: {exchange}")
 
     def step():
-        if world == 1:
+        if not grouped:
             return single.execute(table)
+        if exchange == "state":
+            return exchange_and_finish(single, table, None, device)
         state = partial.execute(table)
         states = all_gather_tables(state, device)
         return partial.merge(states) if rank == 0 else None
@@ -122,7 +153,7 @@ def main() -> int:
         }
 
     def barrier():
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -138,7 +169,7 @@ def main() -> int:
     barrier()
     elapsed = time.perf_counter() - t0
     ctx.set_profiling(False)
-    if world > 1:
+    if grouped:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -182,20 +213,23 @@ def main() -> int:
             "data": "synthetic",
             "config": {"workload": f"{wl.name}: {wl.description}", "rows_per_gpu": rows, "partitions_per_gpu": parts,
                        "total_rows": total_rows, "groups": result.num_rows,
-                       "merge": "none (single GPU)" if world == 1 else "RCCL all-gather of PARTIAL state + Final merge on rank 0"},
+                       "merge": {"none (single GPU)": "none (single GPU)",
+                                 "state": "group tables stay in HBM: agreed key packing, RCCL reduce of the dense "
+                                          "accumulator arrays (or gather + merge of hash-table rows) onto rank 0",
+                                 "arrow": "RCCL all-gather of PARTIAL Arrow batches + Final merge on rank 0"}[exchange]},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "kernels": {n: {"launches": v["launches"], "avg_ms": v["total_ms"] / max(1, v["launches"])}
                         for n, v in stats["kernels"].items()},
         }
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=json_out, flush=True)
 
     single.close()
     if partial:
         partial.close()
     table.close()
     ctx.close()
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
     return 0
 

@@ -41,6 +41,7 @@ typedef struct prism_gpu_ctx prism_gpu_ctx;
 typedef struct prism_gpu_table prism_gpu_table;
 typedef struct prism_gpu_plan prism_gpu_plan;
 typedef struct prism_gpu_part prism_gpu_part;
+typedef struct prism_gpu_state prism_gpu_state;
 
 /* Error convention: stands in for datafusion::common::Result<T> on this path
  * (src/prism-query/src/providers/table_provider.rs:85,93 map failures to
@@ -267,6 +268,79 @@ int prism_gpu_merge(prism_gpu_plan* plan, struct ArrowArray* const* states,
 /* Schema of prism_gpu_merge's output (== the SINGLE-mode output schema). */
 int prism_gpu_plan_final_schema(const prism_gpu_plan* plan,
                                 struct ArrowSchema* out);
+
+/* ---- device-resident aggregate state: the exchange step between GPUs ------
+ * The reference makes every partition an independent unit that produces a Partial
+ * aggregate (one file group per partition, table_provider.rs:94-109) and lets
+ * DataFusion's RepartitionExec(Hash) + AggregateExec(FinalPartitioned) merge them.
+ * Between GPUs of one node the same merge is done on the group tables themselves,
+ * in HBM, with a collective in between (RCCL all-reduce for small, densely indexed
+ * group spaces; all-gather / all-to-all of (key, state) rows otherwise), instead of
+ * exporting Arrow state batches through the host:
+ *
+ *   prism_gpu_scan_stats     per-column min / max / NULL count of this rank's scan;
+ *                            the caller reduces them over the ranks (MIN, MAX, SUM)
+ *   prism_gpu_aggregate      scan -> filter -> GROUP BY with the keys packed from
+ *                            the agreed statistics, so equal groups have equal packed
+ *                            keys (and equal dense indices) on every rank; the group
+ *                            table stays in HBM behind the returned handle
+ *   prism_gpu_state_describe what the table looks like and how each 8-byte
+ *                            accumulator ("slot") merges
+ *   prism_gpu_state_export   dense table: the slot arrays, [n_slots][entries] int64;
+ *                            hash table: the occupied groups, [entries] packed keys
+ *                            followed by [n_slots][entries] accumulators;
+ *                            copied into a caller-provided DEVICE buffer
+ *   prism_gpu_state_import   dense table: replaces the slot arrays (after an
+ *                            all-reduce of the exported buffer)
+ *   prism_gpu_state_merge    hash table: merges groups exported by another rank
+ *   prism_gpu_state_finish   final rows (ORDER BY / LIMIT applied), as prism_gpu_merge
+ *
+ * Supported for plans with at least one GROUP BY key, no COUNT(DISTINCT) and a
+ * packed key of at most 64 bits; otherwise PRISM_GPU_EUNSUPPORTED, and the caller
+ * exchanges PARTIAL batches through prism_gpu_merge instead.  String keys travel
+ * as dictionary codes: the ranks must hold the same dictionary for the column
+ * (compare prism_gpu_table_dictionary_digest).  The table must outlive the state.
+ * Device buffers are read and written on the library's own stream, and the calls return
+ * once that work is done: the caller makes sure that nothing it queued on other streams
+ * (an initialising kernel, a collective) is still pending on the buffer when it calls. */
+typedef struct prism_gpu_col_stats {
+  int64_t min, max; /* min > max: no non-NULL value */
+  uint64_t nulls;
+} prism_gpu_col_stats;
+
+enum prism_gpu_slot_merge {
+  PRISM_SLOT_SUM_I64 = 0, /* wrapping */
+  PRISM_SLOT_SUM_F64 = 1,
+  PRISM_SLOT_MIN_I64 = 2,
+  PRISM_SLOT_MAX_I64 = 3
+};
+
+#define PRISM_GPU_MAX_SLOTS 24
+typedef struct prism_gpu_state_info {
+  int32_t dense;     /* 1: entries = size of the key space, every rank has the same */
+  int32_t n_slots;
+  uint64_t entries;  /* dense: entries per slot array; hash: occupied groups */
+  uint64_t export_bytes;
+  int32_t slot_merge[PRISM_GPU_MAX_SLOTS]; /* prism_gpu_slot_merge */
+} prism_gpu_state_info;
+
+/* `out` has one entry per column of the plan's input schema. */
+int prism_gpu_scan_stats(prism_gpu_plan* plan, prism_gpu_table* table,
+                         const uint32_t* partition_ids, size_t n_partitions,
+                         prism_gpu_col_stats* out);
+/* `stats` (one per input column) may be NULL: the local statistics are used. */
+int prism_gpu_aggregate(prism_gpu_plan* plan, prism_gpu_table* table,
+                        const uint32_t* partition_ids, size_t n_partitions,
+                        const prism_gpu_col_stats* stats, prism_gpu_state** out);
+int prism_gpu_state_describe(prism_gpu_state* state, prism_gpu_state_info* out);
+int prism_gpu_state_export(prism_gpu_state* state, void* device_dst, size_t bytes);
+int prism_gpu_state_import(prism_gpu_state* state, const void* device_src, size_t bytes);
+int prism_gpu_state_merge(prism_gpu_state* state, const void* device_src, uint64_t n_groups);
+int prism_gpu_state_finish(prism_gpu_state* state, struct ArrowArray* out);
+void prism_gpu_state_free(prism_gpu_state* state);
+/* FNV-1a over the dictionary values of a string column, in code order. */
+int prism_gpu_table_dictionary_digest(prism_gpu_table* table, int32_t column,
+                                      uint64_t* digest, uint32_t* n_values);
 
 /* ---- measurement ---------------------------------------------------------
  * Per-kernel device time measured with HIP events on the stream the kernels run

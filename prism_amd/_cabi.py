@@ -128,6 +128,24 @@ class SynthCol(C.Structure):
 MAX_KERNEL_STATS = 24
 
 
+class ColStats(C.Structure):
+    _fields_ = [("min", C.c_int64), ("max", C.c_int64), ("nulls", C.c_uint64)]
+
+
+MAX_SLOTS = 24
+SLOT_SUM_I64, SLOT_SUM_F64, SLOT_MIN_I64, SLOT_MAX_I64 = 0, 1, 2, 3
+
+
+class StateInfo(C.Structure):
+    _fields_ = [
+        ("dense", C.c_int32),
+        ("n_slots", C.c_int32),
+        ("entries", C.c_uint64),
+        ("export_bytes", C.c_uint64),
+        ("slot_merge", C.c_int32 * MAX_SLOTS),
+    ]
+
+
 class KernelStat(C.Structure):
     _fields_ = [
         ("name", C.c_char * 48),

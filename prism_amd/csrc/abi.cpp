@@ -222,6 +222,77 @@ int prism_gpu_merge(prism_gpu_plan* plan, struct ArrowArray* const* states, size
   });
 }
 
+int prism_gpu_scan_stats(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions,
+                         prism_gpu_col_stats* out) {
+  return guarded([&] {
+    require(plan && table && out, "null argument");
+    prism::scan_stats(plan, table, partition_ids, n_partitions, out);
+  });
+}
+
+int prism_gpu_aggregate(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions,
+                        const prism_gpu_col_stats* stats, prism_gpu_state** out) {
+  return guarded([&] {
+    require(plan && table && out, "null argument");
+    *out = prism::aggregate_state(plan, table, partition_ids, n_partitions, stats);
+  });
+}
+
+int prism_gpu_state_describe(prism_gpu_state* state, prism_gpu_state_info* out) {
+  return guarded([&] {
+    require(state && out, "null argument");
+    prism::state_describe(state, out);
+  });
+}
+
+int prism_gpu_state_export(prism_gpu_state* state, void* device_dst, size_t bytes) {
+  return guarded([&] {
+    require(state && (device_dst || bytes == 0), "null argument");
+    prism::state_export(state, device_dst, bytes);
+  });
+}
+
+int prism_gpu_state_import(prism_gpu_state* state, const void* device_src, size_t bytes) {
+  return guarded([&] {
+    require(state && device_src, "null argument");
+    prism::state_import(state, device_src, bytes);
+  });
+}
+
+int prism_gpu_state_merge(prism_gpu_state* state, const void* device_src, uint64_t n_groups) {
+  return guarded([&] {
+    require(state && (device_src || n_groups == 0), "null argument");
+    prism::state_merge(state, device_src, n_groups);
+  });
+}
+
+int prism_gpu_state_finish(prism_gpu_state* state, struct ArrowArray* out) {
+  return guarded([&] {
+    require(state && out, "null argument");
+    prism::state_finish(state, out);
+  });
+}
+
+void prism_gpu_state_free(prism_gpu_state* state) { prism::state_free(state); }
+
+int prism_gpu_table_dictionary_digest(prism_gpu_table* table, int32_t column, uint64_t* digest, uint32_t* n_values) {
+  return guarded([&] {
+    require(table && digest && n_values, "null argument");
+    require(column >= 0 && (size_t)column < table->fields.size(), "column out of range");
+    std::lock_guard<std::mutex> g(table->mu);
+    const prism::ColumnDict& d = table->dicts[column];
+    uint64_t h = 0xcbf29ce484222325ull;
+    auto mix = [&](uint8_t b) { h = (h ^ b) * 0x100000001b3ull; };
+    for (const std::string& v : d.values) {
+      for (unsigned char c : v) mix(c);
+      mix(0xff);  // separator: no UTF-8 byte
+    }
+    if (!d.alive) h = ~h;
+    *digest = h;
+    *n_values = (uint32_t)d.values.size();
+  });
+}
+
 int prism_gpu_set_profiling(prism_gpu_ctx* ctx, int enabled) {
   return guarded([&] {
     require(ctx != nullptr, "ctx is null");

@@ -64,23 +64,28 @@ __device__ __forceinline__ void atomic_apply(P* addr, int op, long long x) {
 
 // Entry of `key` in the HBM table, inserting it if absent; capacity (the extra
 // entry) for the all-ones key; ~0 when the table is full.
-__device__ __forceinline__ uint64_t global_entry(const AggParams& p, uint64_t key) {
-  if (p.dense) return key;
-  if (key == kEmptyKey) return p.capacity;
-  uint64_t mask = p.capacity - 1;
+__device__ __forceinline__ uint64_t global_entry_raw(int dense, uint64_t capacity, uint64_t* g_keys, uint32_t* overflow,
+                                                     uint64_t key) {
+  if (dense) return key;
+  if (key == kEmptyKey) return capacity;
+  uint64_t mask = capacity - 1;
   uint64_t h = hash64(key) & mask;
-  const uint64_t max_probes = p.capacity < 4096 ? p.capacity : 4096;  // far beyond any chain at load <= 0.5
+  const uint64_t max_probes = capacity < 4096 ? capacity : 4096;  // far beyond any chain at load <= 0.5
   for (uint64_t probe = 0; probe < max_probes; ++probe) {
-    unsigned long long k = p.g_keys[h];
+    unsigned long long k = g_keys[h];
     if (k == key) return h;
     if (k == kEmptyKey) {
-      unsigned long long old = atomicCAS((unsigned long long*)&p.g_keys[h], kEmptyKey, key);
+      unsigned long long old = atomicCAS((unsigned long long*)&g_keys[h], kEmptyKey, key);
       if (old == kEmptyKey || old == key) return h;
     }
     h = (h + 1) & mask;
   }
-  *p.overflow = 1u;
+  *overflow = 1u;
   return ~0ull;
+}
+
+__device__ __forceinline__ uint64_t global_entry(const AggParams& p, uint64_t key) {
+  return global_entry_raw(p.dense, p.capacity, p.g_keys, p.overflow, key);
 }
 
 // Two-word keys.  The low word claims the entry with a CAS; the winner then publishes

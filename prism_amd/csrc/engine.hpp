@@ -127,6 +127,18 @@ std::unique_ptr<prism_gpu_plan> plan_create(prism_gpu_ctx* ctx, const ArrowSchem
 void execute_plan(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions,
                   bool merge_input, ArrowArray* out);
 
+// Device-resident aggregate state (prism_gpu_aggregate and friends).
+void scan_stats(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions,
+                prism_gpu_col_stats* out);
+prism_gpu_state* aggregate_state(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids,
+                                 size_t n_partitions, const prism_gpu_col_stats* stats);
+void state_describe(prism_gpu_state* st, prism_gpu_state_info* out);
+void state_export(prism_gpu_state* st, void* device_dst, size_t bytes);
+void state_import(prism_gpu_state* st, const void* device_src, size_t bytes);
+void state_merge(prism_gpu_state* st, const void* device_src, uint64_t n_groups);
+void state_finish(prism_gpu_state* st, ArrowArray* out);
+void state_free(prism_gpu_state* st);
+
 // Host implementation of SQL LIKE, used on dictionary values.
 std::vector<LikeToken> like_compile(const std::string& pattern);
 bool like_match_host(const std::vector<LikeToken>& tokens, const std::string& s, bool case_insensitive);

@@ -26,6 +26,7 @@ struct ScanSet {
   std::vector<ScanSeg> segs;
   uint64_t n_tiles = 0, rows = 0;
   std::vector<ColUse> uses;
+  const prism_gpu_col_stats* stats_override = nullptr;  // agreed between ranks: replaces the chunks' statistics
   Scratch d_segs, d_cols;
   ScanDesc desc{};
 
@@ -72,6 +73,12 @@ struct ColInfo {  // statistics of one column over the scan set
 
 ColInfo col_info(const ScanSet& ss, int column) {
   ColInfo ci;
+  if (ss.stats_override) {
+    ci.min = ss.stats_override[column].min;
+    ci.max = ss.stats_override[column].max;
+    ci.nulls = ss.stats_override[column].nulls;
+    return ci;
+  }
   for (const Chunk* ch : ss.chunks) {
     const ColStats& s = ch->stats[column];
     ci.min = std::min<long long>(ci.min, s.min);
@@ -727,12 +734,79 @@ int lds_slots_for(int n_slots) {
   return s;
 }
 
+
+// Reads the groups of a finished table and appends them to `cols`; with ORDER BY ...
+// LIMIT only the leading groups leave the device.  Returns the number of groups read.
+uint64_t emit_groups(prism_gpu_ctx* ctx, const prism_gpu_plan* plan, const prism_gpu_table* table,
+                     const std::vector<KeySrc>& keys, const KeyLayout& layout, const Lowered& low, const GroupTable& gt,
+                     bool partial, std::vector<OutColumn>& cols) {
+  GroupRows g;
+  {
+    HostTimer ht(ctx, "host:read_groups");
+    TopKOrder order;
+    const uint64_t entries = gt.dense ? gt.capacity : gt.capacity + 1;
+    if (!partial && entries >= kTopKMinEntries && topk_order(plan, table, keys, layout, low, cols, order)) {
+      Scratch d_topk(ctx, sizeof(TopKState));
+      launch_topk_threshold(ctx, gt.dense, gt.capacity, gt.keys.as<uint64_t>(), gt.keys_hi.as<uint64_t>(),
+                            gt.state.as<int64_t>(), order, (uint64_t)std::max<int64_t>(1, plan->limit),
+                            d_topk.as<TopKState>());
+      g = table_read(ctx, gt, &order, d_topk.as<TopKState>());
+    } else {
+      g = table_read(ctx, gt);
+    }
+  }
+  HostTimer ht(ctx, "host:assemble");
+  append_key_columns(table, keys, layout, 0, g, cols, 0);
+  append_agg_columns(low, g, partial, cols, keys.size());
+  return g.n;
+}
+
 }  // namespace
+
+}  // namespace prism
+
+// A group table kept in HBM between prism_gpu_aggregate and prism_gpu_state_finish.
+struct prism_gpu_state {
+  prism_gpu_plan* plan = nullptr;
+  prism_gpu_table* table = nullptr;
+  std::vector<prism::KeySrc> keys;
+  prism::KeyLayout layout;
+  prism::Lowered low;
+  prism::GroupTable gt;
+  std::vector<int> slot_ops;
+  // the occupied groups in compact form (hash tables): [n] keys, [n_slots][n] accumulators
+  bool compacted = false;
+  uint64_t c_n = 0;
+  prism::Scratch c_keys, c_state;
+};
+
+namespace prism {
+
+namespace {
+
+}  // namespace
+
+namespace {
+void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions,
+                  bool merge_input, ArrowArray* out, const prism_gpu_col_stats* stats_override, prism_gpu_state** capture);
+}
 
 void execute_plan(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions,
                   bool merge_input, ArrowArray* out) {
+  execute_impl(plan, table, partition_ids, n_partitions, merge_input, out, nullptr, nullptr);
+}
+
+namespace {
+
+// With `capture` the GROUP BY stops once the group table is complete and hands the table
+// over instead of producing rows; `stats_override` then replaces the scan's own column
+// statistics so that every rank of a multi-GPU query packs keys the same way.
+void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions,
+                  bool merge_input, ArrowArray* out, const prism_gpu_col_stats* stats_override, prism_gpu_state** capture) {
   prism_gpu_ctx* ctx = plan->ctx;
   bind(ctx);
+  if (capture && (plan->keys.empty() || plan->distinct_plan))
+    fail(PRISM_GPU_EUNSUPPORTED, "device-resident aggregate state needs a GROUP BY without COUNT(DISTINCT)");
   HostTimer whole(ctx, "host:execute");
   if (table->ctx != ctx) fail(PRISM_GPU_EINVAL, "plan and table belong to different contexts");
   const std::vector<FieldType>& expect = merge_input ? plan->partial_fields : plan->fields;
@@ -745,6 +819,7 @@ void execute_plan(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
   // ---- which chunks ----
   ScanSet ss;
   ss.ctx = ctx;
+  ss.stats_override = stats_override;
   for (const Chunk& ch : table->chunks) {
     bool take = partition_ids == nullptr || n_partitions == 0;
     for (size_t i = 0; !take && i < n_partitions; ++i) take = partition_ids[i] == ch.partition_id;
@@ -779,7 +854,7 @@ void execute_plan(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
   std::memset(&ap, 0, sizeof(ap));
   KeyLayout layout;
   KeyCursor cursor;
-  if (!ss.chunks.empty()) {
+  if (!ss.chunks.empty() || capture) {
     if (plan->distinct_plan) {
       layout_keys(ss, table, {distinct_src}, cursor, layout);
       // (x, keys) beyond one word: x alone in the low word, the group key in the high one
@@ -867,7 +942,7 @@ void execute_plan(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
   for (int j = 0; j < ap.n_vals; ++j) value_bytes += ap.vals[j].width;
   for (auto& s : layout.specs) value_bytes += s.width;
 
-  if (ss.chunks.empty() || selected == 0) {
+  if ((ss.chunks.empty() || selected == 0) && !capture) {
     // no input rows: an ungrouped aggregate still yields one row
     if (plan->keys.empty()) {
       size_t c = 0;
@@ -932,26 +1007,28 @@ void execute_plan(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       if (capacity >= max_capacity) fail(PRISM_GPU_EINTERNAL, "group table overflow at maximum capacity");
       capacity = std::min(max_capacity, capacity * 8);  // more groups than expected: grow and redo the pass
     }
-    if (!plan->distinct_plan) {
-      GroupRows g;
+    if (capture) {
+      if (layout.words != 1) fail(PRISM_GPU_EUNSUPPORTED, "device-resident aggregate state needs a packed key of at most 64 bits");
+      PRISM_HIP(hipStreamSynchronize(ctx->stream));
+      collect_timings(ctx);
+      auto st = std::make_unique<prism_gpu_state>();
+      st->plan = plan;
+      st->table = table;
+      st->keys = keys;
+      st->layout = layout;
+      st->low = low;
+      st->gt = std::move(gt);
+      st->slot_ops = slot_ops;
       {
-        HostTimer ht(ctx, "host:read_groups");
-        TopKOrder order;
-        const uint64_t entries = gt.dense ? gt.capacity : gt.capacity + 1;
-        if (!partial && entries >= kTopKMinEntries && topk_order(plan, table, keys, layout, low, cols, order)) {
-          Scratch d_topk(ctx, sizeof(TopKState));
-          launch_topk_threshold(ctx, gt.dense, gt.capacity, gt.keys.as<uint64_t>(), gt.keys_hi.as<uint64_t>(),
-                                gt.state.as<int64_t>(), order, (uint64_t)std::max<int64_t>(1, plan->limit),
-                                d_topk.as<TopKState>());
-          g = table_read(ctx, gt, &order, d_topk.as<TopKState>());
-        } else {
-          g = table_read(ctx, gt);
-        }
+        std::lock_guard<std::mutex> g(ctx->mu);
+        ctx->stats.rows_scanned += ss.rows;
+        ctx->stats.rows_selected += selected;
       }
-      HostTimer ht(ctx, "host:assemble");
-      append_key_columns(table, keys, layout, 0, g, cols, 0);
-      append_agg_columns(low, g, partial, cols, keys.size());
-      groups_out = g.n;
+      *capture = st.release();
+      return;
+    }
+    if (!plan->distinct_plan) {
+      groups_out = emit_groups(ctx, plan, table, keys, layout, low, gt, partial, cols);
     } else if (partial) {
       // inner GROUP BY (keys, x): one row per distinct pair
       GroupRows g = table_read(ctx, gt);
@@ -1027,6 +1104,185 @@ void execute_plan(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
   }
   HostTimer ht(ctx, "host:export");
   export_record_batch(cols, out);
+}
+
+void state_compact(prism_gpu_state* st) {
+  if (st->compacted) return;
+  prism_gpu_ctx* ctx = st->plan->ctx;
+  const GroupTable& g = st->gt;
+  Scratch d_count(ctx, 256);
+  PRISM_HIP(hipMemsetAsync(d_count.p, 0, 8, ctx->stream));
+  launch_emit(ctx, g.dense, g.capacity, g.keys.as<uint64_t>(), nullptr, g.state.as<int64_t>(), g.n_slots, nullptr, nullptr,
+              nullptr, 0, d_count.as<unsigned long long>());
+  unsigned long long n = 0;
+  PRISM_HIP(hipMemcpyAsync(&n, d_count.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+  PRISM_HIP(hipStreamSynchronize(ctx->stream));
+  st->c_n = n;
+  st->c_keys = Scratch(ctx, std::max<uint64_t>(1, n) * 8);
+  st->c_state = Scratch(ctx, std::max<uint64_t>(1, n) * 8 * g.n_slots);
+  if (n) {
+    PRISM_HIP(hipMemsetAsync(d_count.p, 0, 8, ctx->stream));
+    launch_emit(ctx, g.dense, g.capacity, g.keys.as<uint64_t>(), nullptr, g.state.as<int64_t>(), g.n_slots,
+                st->c_keys.as<uint64_t>(), nullptr, st->c_state.as<int64_t>(), n, d_count.as<unsigned long long>());
+    PRISM_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  st->compacted = true;
+}
+
+MergeParams merge_params(const prism_gpu_state* st, const GroupTable& g) {
+  MergeParams mp{};
+  mp.dense = g.dense ? 1 : 0;
+  mp.capacity = g.capacity;
+  mp.g_keys = g.keys.as<uint64_t>();
+  mp.g_state = g.state.as<int64_t>();
+  mp.overflow = g.overflow.as<uint32_t>();
+  mp.n_slots = g.n_slots;
+  for (int s = 0; s < g.n_slots; ++s) mp.ops[s] = st->slot_ops[s];
+  return mp;
+}
+
+}  // namespace
+
+void scan_stats(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions,
+                prism_gpu_col_stats* out) {
+  bind(plan->ctx);
+  if (table->fields.size() != plan->fields.size()) fail(PRISM_GPU_EINVAL, "table schema does not match the plan's input schema");
+  table_sync_stats(table);
+  ScanSet ss;
+  ss.ctx = plan->ctx;
+  for (const Chunk& ch : table->chunks) {
+    bool take = partition_ids == nullptr || n_partitions == 0;
+    for (size_t i = 0; !take && i < n_partitions; ++i) take = partition_ids[i] == ch.partition_id;
+    if (take && ch.rows) ss.chunks.push_back(&ch);
+  }
+  for (size_t c = 0; c < table->fields.size(); ++c) {
+    ColInfo ci = col_info(ss, (int)c);
+    out[c].min = ci.min;
+    out[c].max = ci.max;
+    out[c].nulls = ci.nulls;
+  }
+}
+
+prism_gpu_state* aggregate_state(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids,
+                                 size_t n_partitions, const prism_gpu_col_stats* stats) {
+  prism_gpu_state* st = nullptr;
+  execute_impl(plan, table, partition_ids, n_partitions, false, nullptr, stats, &st);
+  return st;
+}
+
+void state_describe(prism_gpu_state* st, prism_gpu_state_info* out) {
+  bind(st->plan->ctx);
+  std::memset(out, 0, sizeof(*out));
+  out->dense = st->gt.dense ? 1 : 0;
+  out->n_slots = st->gt.n_slots;
+  if (st->gt.dense) {
+    out->entries = st->gt.capacity;
+    out->export_bytes = st->gt.capacity * 8 * (uint64_t)st->gt.n_slots;
+  } else {
+    state_compact(st);
+    out->entries = st->c_n;
+    out->export_bytes = st->c_n * 8 * (1 + (uint64_t)st->gt.n_slots);
+  }
+  for (int s = 0; s < st->gt.n_slots; ++s) {
+    const int op = st->slot_ops[s];
+    out->slot_merge[s] = op == kSlotMin ? PRISM_SLOT_MIN_I64 : op == kSlotMax ? PRISM_SLOT_MAX_I64
+                         : op == kSlotAddF64 ? PRISM_SLOT_SUM_F64 : PRISM_SLOT_SUM_I64;
+  }
+}
+
+void state_export(prism_gpu_state* st, void* device_dst, size_t bytes) {
+  prism_gpu_ctx* ctx = st->plan->ctx;
+  bind(ctx);
+  prism_gpu_state_info info;
+  state_describe(st, &info);
+  if (bytes != info.export_bytes) fail(PRISM_GPU_EINVAL, "export buffer has " + std::to_string(bytes) + " bytes, the state needs " + std::to_string(info.export_bytes));
+  if (bytes == 0) return;
+  uint8_t* dst = (uint8_t*)device_dst;
+  if (st->gt.dense) {
+    const uint64_t n = st->gt.capacity;
+    for (int s = 0; s < st->gt.n_slots; ++s)
+      PRISM_HIP(hipMemcpyAsync(dst + (uint64_t)s * n * 8, st->gt.state.as<int64_t>() + (uint64_t)s * (n + 1), n * 8,
+                               hipMemcpyDeviceToDevice, ctx->stream));
+  } else {
+    PRISM_HIP(hipMemcpyAsync(dst, st->c_keys.p, st->c_n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    PRISM_HIP(hipMemcpyAsync(dst + st->c_n * 8, st->c_state.p, st->c_n * 8 * (uint64_t)st->gt.n_slots, hipMemcpyDeviceToDevice,
+                             ctx->stream));
+  }
+  PRISM_HIP(hipStreamSynchronize(ctx->stream));
+}
+
+void state_import(prism_gpu_state* st, const void* device_src, size_t bytes) {
+  prism_gpu_ctx* ctx = st->plan->ctx;
+  bind(ctx);
+  if (!st->gt.dense) fail(PRISM_GPU_EINVAL, "only a dense state can be replaced; merge rows into a hash state instead");
+  const uint64_t n = st->gt.capacity;
+  if (bytes != n * 8 * (uint64_t)st->gt.n_slots) fail(PRISM_GPU_EINVAL, "import buffer size does not match the state");
+  const uint8_t* src = (const uint8_t*)device_src;
+  for (int s = 0; s < st->gt.n_slots; ++s)
+    PRISM_HIP(hipMemcpyAsync(st->gt.state.as<int64_t>() + (uint64_t)s * (n + 1), src + (uint64_t)s * n * 8, n * 8,
+                             hipMemcpyDeviceToDevice, ctx->stream));
+  PRISM_HIP(hipStreamSynchronize(ctx->stream));
+}
+
+void state_merge(prism_gpu_state* st, const void* device_src, uint64_t n_groups) {
+  prism_gpu_ctx* ctx = st->plan->ctx;
+  bind(ctx);
+  if (n_groups == 0) return;
+  const uint64_t* src_keys = (const uint64_t*)device_src;
+  const int64_t* src_state = (const int64_t*)device_src + n_groups;
+  if (!st->gt.dense) {
+    // room for every incoming group being new; otherwise rebuild a larger table first
+    state_compact(st);
+    const uint64_t need = st->c_n + n_groups;
+    if (need * 2 > st->gt.capacity) {
+      GroupTable bigger;
+      table_alloc(ctx, bigger, false, pow2_ceil(std::max<uint64_t>(1024, need * 2)), st->slot_ops, 1);
+      MergeParams own = merge_params(st, bigger);
+      own.src_keys = st->c_keys.as<uint64_t>();
+      own.src_state = st->c_state.as<int64_t>();
+      own.n = st->c_n;
+      launch_merge_packed(ctx, own);
+      PRISM_HIP(hipStreamSynchronize(ctx->stream));
+      st->gt = std::move(bigger);
+    }
+  }
+  MergeParams mp = merge_params(st, st->gt);
+  mp.src_keys = src_keys;
+  mp.src_state = src_state;
+  mp.n = n_groups;
+  launch_merge_packed(ctx, mp);
+  if (table_overflowed(ctx, st->gt)) {
+    PRISM_HIP(hipMemsetAsync(st->gt.overflow.p, 0, 4, ctx->stream));
+    PRISM_HIP(hipStreamSynchronize(ctx->stream));
+    fail(st->gt.dense ? PRISM_GPU_EINVAL : PRISM_GPU_EINTERNAL,
+         st->gt.dense ? "merged keys fall outside the dense table: the states were not built from the same column statistics"
+                      : "group table overflow while merging states");
+  }
+  PRISM_HIP(hipStreamSynchronize(ctx->stream));
+  collect_timings(ctx);
+  st->compacted = false;  // the compact copy no longer describes the table
+}
+
+void state_finish(prism_gpu_state* st, ArrowArray* out) {
+  prism_gpu_plan* plan = st->plan;
+  prism_gpu_ctx* ctx = plan->ctx;
+  bind(ctx);
+  HostTimer whole(ctx, "host:state_finish");
+  std::vector<OutColumn> cols = make_columns(plan->final_fields);
+  const uint64_t groups = emit_groups(ctx, plan, st->table, st->keys, st->layout, st->low, st->gt, false, cols);
+  PRISM_HIP(hipStreamSynchronize(ctx->stream));
+  collect_timings(ctx);
+  sort_and_limit(plan, cols);
+  {
+    std::lock_guard<std::mutex> g(ctx->mu);
+    ctx->stats.groups_out += groups;
+  }
+  export_record_batch(cols, out);
+}
+
+void state_free(prism_gpu_state* st) {
+  if (st) bind(st->plan->ctx);
+  delete st;
 }
 
 }  // namespace prism

@@ -204,6 +204,23 @@ void launch_topk_threshold(prism_gpu_ctx* ctx, bool dense, uint64_t capacity, co
                            const uint64_t* g_keys_hi, const int64_t* g_state, const TopKOrder& order, uint64_t k,
                            TopKState* d_state);
 
+// Merges groups exported from another table (packed keys + slot-major accumulators with
+// stride `n`) into a table: find-or-insert the key, then apply every accumulator with the
+// slot's merge rule (all "add" rules add, min and max stay min and max).
+struct MergeParams {
+  int dense;
+  uint64_t capacity;
+  uint64_t* g_keys;
+  int64_t* g_state;
+  uint32_t* overflow;
+  int n_slots;
+  int ops[kMaxSlots];  // SlotOp of each slot
+  const uint64_t* src_keys;
+  const int64_t* src_state;
+  uint64_t n;
+};
+void launch_merge_packed(prism_gpu_ctx* ctx, const MergeParams& p);
+
 // Fills n entries with `value`.
 void launch_fill_i64(prism_gpu_ctx* ctx, int64_t* dst, uint64_t n, int64_t value);
 // Compacts the occupied entries of a table: out_keys[i], out_state[s * out_stride + i].

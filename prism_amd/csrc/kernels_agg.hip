@@ -366,6 +366,24 @@ __global__ __launch_bounds__(kBlock) void k_distinct_fold(DistinctFoldParams q) 
 
 // ---- table maintenance --------------------------------------------------------------
 
+__global__ __launch_bounds__(kBlock) void k_merge_packed(MergeParams p) {
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < p.n; i += (uint64_t)gridDim.x * kBlock) {
+    const uint64_t key = p.src_keys[i];
+    // a dense table is indexed by the key itself: a key beyond it comes from a state that
+    // was packed from other statistics, and must not be written anywhere
+    if (p.dense && key >= p.capacity) { *p.overflow = 2u; continue; }
+    const uint64_t e = global_entry_raw(p.dense, p.capacity, p.g_keys, p.overflow, key);
+    if (e == ~0ull) continue;
+    for (int s = 0; s < p.n_slots; ++s) {
+      const int op = p.ops[s];
+      const long long v = p.src_state[(uint64_t)s * p.n + i];
+      if (v == slot_identity(op)) continue;
+      // counters merge by addition, like the sums
+      atomic_apply(&p.g_state[(uint64_t)s * (p.capacity + 1) + e], (op == kSlotAddOne || op == kSlotAddValid) ? kSlotAddI64 : op, v);
+    }
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void k_fill_i64(long long* dst, uint64_t n, long long value) {
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) dst[i] = value;
 }
@@ -554,6 +572,13 @@ void launch_distinct_fold(prism_gpu_ctx* ctx, const DistinctFoldParams& p) {
   uint32_t grid = stream_grid(ctx, p.set_capacity);
   KernelTimer timer(ctx, "distinct_fold", p.set_capacity * 8);
   k_distinct_fold<<<dim3(grid), dim3(kBlock), 0, ctx->stream>>>(p);
+  PRISM_HIP(hipGetLastError());
+}
+
+void launch_merge_packed(prism_gpu_ctx* ctx, const MergeParams& p) {
+  if (p.n == 0) return;
+  KernelTimer timer(ctx, "merge_packed", p.n * 8 * (1 + (uint64_t)p.n_slots));
+  k_merge_packed<<<dim3(stream_grid(ctx, p.n)), dim3(kBlock), 0, ctx->stream>>>(p);
   PRISM_HIP(hipGetLastError());
 }
 

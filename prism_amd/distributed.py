@@ -7,8 +7,20 @@ produces a Partial aggregate (one file group per partition,
 src/prism-query/src/providers/table_provider.rs:94-109) and merges partials in a
 Final stage; here the partitions of a table are dealt to the GPUs of a node, each
 GPU runs scan -> filter -> partial aggregate over its share with no communication,
-and the only exchange is the all-gather of the (small) PARTIAL state batches, after
-which the Final merge runs.
+and the only exchange is the merge of the per-GPU group tables.
+
+Two forms of that exchange:
+
+* `exchange_and_finish`: the group tables stay in HBM (prism_gpu_aggregate ..
+  prism_gpu_state_finish).  The ranks first agree on the column statistics the keys
+  are packed from (one tiny all-gather), so equal groups get equal packed keys
+  everywhere.  A small key space then indexes a dense table and the merge is an RCCL
+  reduce of the accumulator arrays onto the finishing rank (SUM / MIN / MAX per
+  slot); otherwise the occupied (key, accumulators) rows are gathered and merged
+  into the finishing rank's hash table.
+* `all_gather_tables` + `Plan.merge`: PARTIAL state batches in DataFusion's own
+  layout, all-gathered as Arrow IPC bytes; works for every plan (COUNT(DISTINCT),
+  ungrouped aggregates) and is what a DataFusion Final stage would consume.
 """
 from __future__ import annotations
 
@@ -82,3 +94,118 @@ def sharded_query(run_partial, merge_final, partitions: Sequence[int], sizes: Se
     state = run_partial(mine)
     states = all_gather_tables(state, device)
     return merge_final(states)
+
+
+# ---- device-resident exchange -------------------------------------------------------------
+
+def agree_on_stats(local_stats, digests: Sequence[int], device):
+    """All ranks' column statistics ([n_columns, 3] int64: min, max, nulls) reduced to the
+    statistics of the union, with ONE collective: an all-gather of the small vector, reduced
+    locally.  `digests` are dictionary digests of the string key columns; they must be equal
+    on every rank (string keys travel as dictionary codes).  Returns (stats, same_dicts)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size()
+    n = local_stats.shape[0]
+    vec = np.concatenate([local_stats.reshape(-1), np.array(list(digests), dtype=np.uint64).view(np.int64)])
+    mine = torch.from_numpy(vec.astype(np.int64)).to(device)
+    all_ = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(all_, mine)
+    m = torch.stack(all_).cpu().numpy()
+    st = m[:, : n * 3].reshape(world, n, 3)
+    out = np.stack([st[:, :, 0].min(axis=0), st[:, :, 1].max(axis=0), st[:, :, 2].sum(axis=0)], axis=1)
+    dig = m[:, n * 3:]
+    same = bool((dig == dig[0]).all())
+    return out, same
+
+
+def reduce_dense_state(buf, slot_merge: Sequence[int], entries: int, dst: int = 0) -> None:
+    """Reduces a dense state buffer (int64 [n_slots * entries], slot-major) onto rank `dst`:
+    runs of neighbouring slots with the same merge rule go out as one collective."""
+    import torch
+    import torch.distributed as dist
+
+    from . import _cabi as abi
+
+    ops = {abi.SLOT_SUM_I64: dist.ReduceOp.SUM, abi.SLOT_SUM_F64: dist.ReduceOp.SUM,
+           abi.SLOT_MIN_I64: dist.ReduceOp.MIN, abi.SLOT_MAX_I64: dist.ReduceOp.MAX}
+    s = 0
+    n_slots = len(slot_merge)
+    while s < n_slots:
+        e = s + 1
+        while e < n_slots and slot_merge[e] == slot_merge[s]:
+            e += 1
+        view = buf[s * entries: e * entries]
+        if slot_merge[s] == abi.SLOT_SUM_F64:
+            view = view.view(torch.float64)
+        dist.reduce(view, dst, op=ops[slot_merge[s]])
+        s = e
+
+
+def gather_rows(buf, n_groups: int, n_slots: int, dst: int = 0):
+    """Gathers every rank's exported hash-table rows (int64 [(1 + n_slots) * n_groups]) on
+    rank `dst`.  Returns [(tensor, n_groups)] per rank there, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n = torch.tensor([n_groups], dtype=torch.int64, device=buf.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    counts = [int(x.item()) for x in sizes]
+    cap = max(1, max(counts)) * (1 + n_slots)
+    mine = torch.zeros(cap, dtype=torch.int64, device=buf.device)
+    mine[: buf.numel()] = buf
+    parts = [torch.empty_like(mine) for _ in range(world)] if rank == dst else None
+    dist.gather(mine, parts, dst=dst)
+    if rank != dst:
+        return None
+    return [(parts[r][: counts[r] * (1 + n_slots)].contiguous(), counts[r]) for r in range(world)]
+
+
+def exchange_and_finish(plan, table, partitions, device, dst: int = 0):
+    """One sharded GROUP BY query with the exchange done on device-resident group tables.
+    Every rank aggregates its `partitions` of `table`; rank `dst` returns the final rows
+    (pyarrow.Table), the others None.  Raises PrismGpuError(EUNSUPPORTED) for plans the state
+    interface does not cover; use all_gather_tables + Plan.merge for those."""
+    import torch
+    import torch.distributed as dist
+
+    from .engine import PrismGpuError
+
+    rank = dist.get_rank()
+    key_cols = [k.column if hasattr(k, "column") else k for k in plan.query.keys]
+    digests = []
+    for c in key_cols:
+        if pa.types.is_string(plan.schema.field(c).type) or pa.types.is_binary(plan.schema.field(c).type):
+            digests.append(table.dictionary_digest(c)[0])
+    stats, same_dicts = agree_on_stats(plan.scan_stats(table, partitions), digests, device)
+    if not same_dicts:
+        raise PrismGpuError(-2, "string key columns have different dictionaries on different ranks")
+    state = plan.aggregate(table, partitions, stats)
+    try:
+        info = state.describe()
+        slot_merge = list(info.slot_merge[: info.n_slots])
+        buf = torch.empty(max(1, info.export_bytes // 8), dtype=torch.int64, device=device)
+        state.export_to(buf.data_ptr(), info.export_bytes)
+        if info.dense:
+            reduce_dense_state(buf[: info.export_bytes // 8], slot_merge, info.entries, dst)
+            if buf.is_cuda:
+                torch.cuda.current_stream().synchronize()
+            if rank != dst:
+                return None
+            state.import_from(buf.data_ptr(), info.export_bytes)
+            return state.finish()
+        parts = gather_rows(buf[: info.export_bytes // 8], info.entries, info.n_slots, dst)
+        if buf.is_cuda:
+            torch.cuda.current_stream().synchronize()
+        if rank != dst:
+            return None
+        for r, (rows, n) in enumerate(parts):
+            if r != dst and n:
+                state.merge_from(rows.data_ptr(), n)
+        return state.finish()
+    finally:
+        state.close()

@@ -30,6 +30,9 @@ EXPORTED_SYMBOLS = [
     "prism_gpu_execute",
     "prism_gpu_partition_open", "prism_gpu_push_batch", "prism_gpu_finish", "prism_gpu_part_free",
     "prism_gpu_merge",
+    "prism_gpu_scan_stats", "prism_gpu_aggregate", "prism_gpu_state_describe", "prism_gpu_state_export",
+    "prism_gpu_state_import", "prism_gpu_state_merge", "prism_gpu_state_finish", "prism_gpu_state_free",
+    "prism_gpu_table_dictionary_digest",
     "prism_gpu_set_profiling", "prism_gpu_get_stats", "prism_gpu_reset_stats",
 ]
 
@@ -51,6 +54,13 @@ def load_library() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise FileNotFoundError(
             f"{LIB_PATH} is missing: build it with `make -C prism_amd/csrc` (or __graft_entry__.build())")
+    # PyTorch ships its own copy of the HIP runtime, and two copies cannot both drive the GPU
+    # from one process: when torch is installed let its copy load first, so that this
+    # library binds to the same one (torch.distributed carries the exchange between GPUs).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     P, V = C.POINTER, C.c_void_p
     L.prism_gpu_last_error.restype = C.c_char_p
@@ -78,6 +88,16 @@ def load_library() -> C.CDLL:
     L.prism_gpu_part_free.argtypes = [V]
     L.prism_gpu_part_free.restype = None
     L.prism_gpu_merge.argtypes = [V, P(P(abi.ArrowArray)), C.c_size_t, P(abi.ArrowArray)]
+    L.prism_gpu_scan_stats.argtypes = [V, V, P(C.c_uint32), C.c_size_t, P(abi.ColStats)]
+    L.prism_gpu_aggregate.argtypes = [V, V, P(C.c_uint32), C.c_size_t, P(abi.ColStats), P(V)]
+    L.prism_gpu_state_describe.argtypes = [V, P(abi.StateInfo)]
+    L.prism_gpu_state_export.argtypes = [V, V, C.c_size_t]
+    L.prism_gpu_state_import.argtypes = [V, V, C.c_size_t]
+    L.prism_gpu_state_merge.argtypes = [V, V, C.c_uint64]
+    L.prism_gpu_state_finish.argtypes = [V, P(abi.ArrowArray)]
+    L.prism_gpu_state_free.argtypes = [V]
+    L.prism_gpu_state_free.restype = None
+    L.prism_gpu_table_dictionary_digest.argtypes = [V, C.c_int32, P(C.c_uint64), P(C.c_uint32)]
     L.prism_gpu_set_profiling.argtypes = [V, C.c_int]
     L.prism_gpu_get_stats.argtypes = [V, P(abi.Stats)]
     L.prism_gpu_reset_stats.argtypes = [V]
@@ -167,6 +187,13 @@ class Table:
         _check(self._lib.prism_gpu_table_synth(self._h, partition_id, seed, first_row, n_rows, total_rows, arr,
                                                len(cols)))
 
+    def dictionary_digest(self, column: str) -> tuple:
+        """(digest, number of values) of a string column's dictionary."""
+        d, n = C.c_uint64(), C.c_uint32()
+        _check(self._lib.prism_gpu_table_dictionary_digest(self._h, self.schema.names.index(column), C.byref(d),
+                                                           C.byref(n)))
+        return d.value, n.value
+
     @property
     def num_rows(self) -> int:
         n = C.c_uint64()
@@ -252,7 +279,72 @@ class Plan:
                 abi.release_array(a)  # borrowed by the library, still ours
         return pa.Table.from_batches([abi.import_batch(out, self.final_schema)])
 
+    @staticmethod
+    def _partition_args(partitions: Optional[Iterable[int]]):
+        if partitions is None:
+            return None, 0
+        ids = list(partitions)
+        arr = (C.c_uint32 * max(1, len(ids)))(*ids)
+        if not ids:
+            arr[0] = 0xFFFFFFFF  # an id no partition has: scan nothing
+        return arr, max(1, len(ids))
+
+    def scan_stats(self, table: Table, partitions: Optional[Iterable[int]] = None):
+        """Per input column (min, max, nulls) of the scan, as an int64 array [n_columns, 3]
+        (nulls reinterpreted as int64)."""
+        import numpy as np
+
+        n = len(self.schema.names)
+        out = (abi.ColStats * n)()
+        arr, k = self._partition_args(partitions)
+        _check(self._lib.prism_gpu_scan_stats(self._h, table._h, arr, k, out))
+        return np.array([[c.min, c.max, c.nulls] for c in out], dtype=np.int64).reshape(n, 3)
+
+    def aggregate(self, table: Table, partitions: Optional[Iterable[int]] = None, stats=None) -> "State":
+        """scan -> filter -> GROUP BY; the group table stays in HBM behind the returned State.
+        `stats`: [n_columns, 3] array of (min, max, nulls) agreed between the ranks."""
+        cs = None
+        if stats is not None:
+            cs = (abi.ColStats * len(stats))(*[abi.ColStats(int(r[0]), int(r[1]), int(r[2])) for r in stats])
+        arr, k = self._partition_args(partitions)
+        h = C.c_void_p()
+        _check(self._lib.prism_gpu_aggregate(self._h, table._h, arr, k, cs, C.byref(h)))
+        return State(self, h)
+
     def close(self) -> None:
         if self._h:
             self._lib.prism_gpu_plan_free(self._h)
+            self._h = C.c_void_p()
+
+
+class State:
+    """prism_gpu_state: a group table in HBM between Plan.aggregate and finish()."""
+
+    def __init__(self, plan: Plan, handle):
+        self.plan = plan
+        self._lib = plan._lib
+        self._h = handle
+
+    def describe(self) -> abi.StateInfo:
+        info = abi.StateInfo()
+        _check(self._lib.prism_gpu_state_describe(self._h, C.byref(info)))
+        return info
+
+    def export_to(self, device_ptr: int, nbytes: int) -> None:
+        _check(self._lib.prism_gpu_state_export(self._h, C.c_void_p(device_ptr), nbytes))
+
+    def import_from(self, device_ptr: int, nbytes: int) -> None:
+        _check(self._lib.prism_gpu_state_import(self._h, C.c_void_p(device_ptr), nbytes))
+
+    def merge_from(self, device_ptr: int, n_groups: int) -> None:
+        _check(self._lib.prism_gpu_state_merge(self._h, C.c_void_p(device_ptr), n_groups))
+
+    def finish(self) -> pa.Table:
+        out = abi.ArrowArray()
+        _check(self._lib.prism_gpu_state_finish(self._h, C.byref(out)))
+        return pa.Table.from_batches([abi.import_batch(out, self.plan.final_schema)])
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.prism_gpu_state_free(self._h)
             self._h = C.c_void_p()

@@ -81,3 +81,73 @@ def test_partition_assignment_balances_by_size():
     assert max(loads) - min(loads) <= 20
     assert assign_partitions([5], 4) == [[0], [], [], []]
     assert assign_partitions([], 2) == [[], []]
+
+
+def _collective_worker(rank: int, world: int, port: int, q):
+    """Runs the collectives of the device-resident exchange on CPU tensors (gloo)."""
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from prism_amd import _cabi as abi
+    from prism_amd.distributed import agree_on_stats, gather_rows, reduce_dense_state
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cpu")
+        # statistics: min of mins, max of maxes, sum of NULL counts; equal digests
+        local = np.array([[10 * rank, 100 + rank, rank + 1], [2**62, -(2**62), 0]], dtype=np.int64)
+        stats, same = agree_on_stats(local, [0xFEEDFACECAFEBEEF], dev)
+        _, differ = agree_on_stats(local, [rank], dev)
+        # dense state: slots SUM_I64, SUM_I64 (wrapping), MAX, MIN, SUM_F64
+        entries = 5
+        merge = [abi.SLOT_SUM_I64, abi.SLOT_SUM_I64, abi.SLOT_MAX_I64, abi.SLOT_MIN_I64, abi.SLOT_SUM_F64]
+        buf = torch.zeros(len(merge) * entries, dtype=torch.int64)
+        buf[0:5] = torch.arange(5) + rank
+        buf[5:10] = torch.tensor([2**62, 2**62, 1, 2, 3]) if rank == 0 else torch.tensor([2**62, 2**62, 1, 2, 3])
+        buf[10:15] = torch.tensor([rank * 7, -rank, 3, 3, -(2**63)])
+        buf[15:20] = torch.tensor([rank * 7, -rank, 3, 3, 2**63 - 1])
+        buf[20:25] = torch.tensor([0.5 + rank, -1.25, 0.0, 1e300, 3.0], dtype=torch.float64).view(torch.int64)
+        reduce_dense_state(buf, merge, entries, dst=0)
+        # hash rows: rank r sends r + 1 rows of (key, 2 slots)
+        n = rank + 1
+        rows = torch.cat([torch.arange(n) + 100 * rank, torch.full((n,), rank), torch.full((n,), -rank)]).to(torch.int64)
+        parts = gather_rows(rows, n, 2, dst=0)
+        q.put((rank, stats.tolist(), same, differ, buf.tolist() if rank == 0 else None,
+               [(p.tolist(), k) for p, k in parts] if parts is not None else None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_state_exchange_collectives_two_ranks():
+    import struct
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_collective_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = {}
+    for _ in procs:
+        r = q.get(timeout=120)
+        out[r[0]] = r[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        stats, same, differ = out[r][0], out[r][1], out[r][2]
+        assert stats == [[0, 101, 3], [2**62, -(2**62), 0]]
+        assert same is True and differ is False
+    buf = out[0][3]
+    assert buf[0:5] == [1, 3, 5, 7, 9]
+    assert buf[5:10] == [-(2**63), -(2**63), 2, 4, 6]          # 2^62 + 2^62 wraps
+    assert buf[10:15] == [7, 0, 3, 3, -(2**63)]
+    assert buf[15:20] == [0, -1, 3, 3, 2**63 - 1]
+    f = [struct.unpack("<d", struct.pack("<q", v))[0] for v in buf[20:25]]
+    assert f == [2.0, -2.5, 0.0, 2e300, 6.0]
+    parts = out[0][4]
+    assert out[1][4] is None
+    assert parts[0] == ([0, 0, 0], 1)
+    assert parts[1] == ([100, 101, 1, 1, -1, -1], 2)
