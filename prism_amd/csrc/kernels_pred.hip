@@ -97,20 +97,78 @@ __device__ __forceinline__ unsigned long long leaf_tile(const T* vals, const uin
   return local;
 }
 
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
+  uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// Every workgroup walks one contiguous share of the tiles, in batches of kLeafLoads
+// 16-byte loads per lane (4 / 2 / 1 tiles for 2- / 4- / 8-byte values).  The segment a
+// tile belongs to is tracked in scalar registers and looked up again only when a segment
+// ends: a binary search over the segment list per tile is a chain of dependent loads that
+// costs more than streaming a tile of a narrow column.  A batch that lies wholly inside
+// one segment issues all its loads before it touches any of them.
+constexpr int kLeafLoads = 8;
+
 template <typename T, typename Pred>
 __device__ __forceinline__ void leaf_body(const ScanDesc& sd, const ColPtr* col, Pred pred, uint64_t* bits,
                                           unsigned long long* count) {
+  constexpr int V = 16 / sizeof(T);
+  constexpr int kRowsPerIter = kBlock * V;
+  constexpr int kItersPerTile = kTileRows / kRowsPerIter;
+  constexpr uint64_t kTilesPerBatch = kLeafLoads / kItersPerTile;
+  static_assert(kLeafLoads % kItersPerTile == 0, "a batch is a whole number of tiles");
   unsigned long long local = 0;
-  for (uint64_t tile = blockIdx.x; tile < sd.n_tiles; tile += gridDim.x) {
-    uint32_t s = find_seg(sd, tile);
-    uint64_t seg_rows = sd.segs[s].rows;
-    uint64_t tile_row0 = (tile - sd.segs[s].tile_base) * kTileRows;
-    const T* vals = (const T*)col[s].values;
-    const uint64_t* validity = col[s].validity;
-    if (tile_row0 + kTileRows <= seg_rows)
-      local += leaf_tile<T, true>(vals, validity, seg_rows, tile_row0, tile, pred, bits);
-    else
-      local += leaf_tile<T, false>(vals, validity, seg_rows, tile_row0, tile, pred, bits);
+  const uint64_t n_batches = ceil_div(sd.n_tiles, kTilesPerBatch);
+  const uint64_t per = uniform_u64(ceil_div(n_batches, (uint64_t)gridDim.x));
+  const uint64_t b0 = per * blockIdx.x, b1 = b0 + per < n_batches ? b0 + per : n_batches;
+  uint32_t seg = 0xffffffffu;
+  uint64_t seg_rows = 0, seg_tile_base = 0, next_tile_base = 0;  // next_tile_base = 0 forces the first lookup
+  const T* vals = nullptr;
+  const uint64_t* validity = nullptr;
+  for (uint64_t b = b0; b < b1; ++b) {
+    const uint64_t first = b * kTilesPerBatch;
+    const uint64_t last = first + kTilesPerBatch < sd.n_tiles ? first + kTilesPerBatch : sd.n_tiles;
+    for (uint64_t tile = first; tile < last;) {
+      if (tile >= next_tile_base) {
+        uint32_t s = seg == 0xffffffffu ? find_seg(sd, tile) : seg + 1;
+        while (s + 1 < sd.n_segs && sd.segs[s + 1].tile_base <= tile) ++s;
+        seg = __builtin_amdgcn_readfirstlane(s);
+        seg_rows = uniform_u64(sd.segs[seg].rows);
+        seg_tile_base = uniform_u64(sd.segs[seg].tile_base);
+        next_tile_base = seg + 1 < sd.n_segs ? uniform_u64(sd.segs[seg + 1].tile_base) : ~0ull;
+        vals = (const T*)uniform_u64((uint64_t)col[seg].values);
+        validity = (const uint64_t*)uniform_u64((uint64_t)col[seg].validity);
+      }
+      const uint64_t tile_row0 = (tile - seg_tile_base) * kTileRows;
+      const bool whole_batch = tile == first && last - first == kTilesPerBatch && last <= next_tile_base &&
+                               tile_row0 + kTilesPerBatch * kTileRows <= seg_rows;
+      if (whole_batch) {
+        Vec16<T> v[kLeafLoads];
+#pragma unroll
+        for (int it = 0; it < kLeafLoads; ++it) v[it] = load16<T>(vals + tile_row0 + (uint64_t)it * kRowsPerIter + threadIdx.x * V);
+#pragma unroll
+        for (int it = 0; it < kLeafLoads; ++it) {
+          const uint64_t in_batch = (uint64_t)it * kRowsPerIter + (uint64_t)threadIdx.x * V;
+          uint32_t m = 0;
+#pragma unroll
+          for (int j = 0; j < V; ++j) m |= (pred(v[it].e[j]) ? 1u : 0u) << j;
+          if (validity) {
+            const uint64_t r = tile_row0 + in_batch;
+            m &= (uint32_t)((validity[r >> 6] >> (r & 63)) & ((1u << V) - 1u));
+          }
+          local += __popc(m);
+          if (bits) store_bits<V>(bits, tile * kTileRows + in_batch, m);
+        }
+        tile = last;
+      } else {
+        if (tile_row0 + kTileRows <= seg_rows)
+          local += leaf_tile<T, true>(vals, validity, seg_rows, tile_row0, tile, pred, bits);
+        else
+          local += leaf_tile<T, false>(vals, validity, seg_rows, tile_row0, tile, pred, bits);
+        ++tile;
+      }
+    }
   }
   if (count) block_count_add(local, count);
 }
