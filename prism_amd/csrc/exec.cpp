@@ -598,6 +598,7 @@ void sort_and_limit(const prism_gpu_plan* p, std::vector<OutColumn>& cols) {
 // ---- HBM group tables --------------------------------------------------------------------------
 
 constexpr int kDenseMaxBits = 22;
+constexpr int kDenseMaxBitsLarge = 28;
 
 struct GroupTable {
   bool dense = false;
@@ -643,7 +644,7 @@ bool table_overflowed(prism_gpu_ctx* ctx, const GroupTable& g) {
 // Reads the occupied entries of a table; with `order`, only those whose rank reaches the
 // threshold launch_topk_threshold left in d_threshold.
 GroupRows table_read(prism_gpu_ctx* ctx, const GroupTable& g, const TopKOrder* order = nullptr,
-                     const TopKState* d_threshold = nullptr) {
+                     TopKState* d_threshold = nullptr) {
   GroupRows rows;
   Scratch d_count(ctx, 256);
   PRISM_HIP(hipMemsetAsync(d_count.p, 0, 8, ctx->stream));
@@ -957,20 +958,46 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
     }
   } else if (plan->keys.empty() && !plan->distinct_plan) {
     // ---- ungrouped aggregates ----
-    std::vector<int64_t> init(ap.n_slots);
-    for (int s = 0; s < ap.n_slots; ++s) init[s] = slot_identity_host(ap.slots[s].op);
-    Scratch d_out(ctx, 256);
-    PRISM_HIP(hipMemcpyAsync(d_out.p, init.data(), init.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-    {
-      KernelTimer timer(ctx, "agg_global", (ap.row_mode == kRowsSelvec ? selected : ss.rows) * value_bytes);
-      launch_agg_global(ctx, ap, d_out.as<int64_t>());
-    }
     GroupRows g;
     g.n = 1;
     g.keys.assign(1, 0);
     g.state.resize(ap.n_slots);
-    PRISM_HIP(hipMemcpyAsync(g.state.data(), d_out.p, g.state.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-    PRISM_HIP(hipStreamSynchronize(ctx->stream));
+    const uint64_t agg_bytes = (ap.row_mode == kRowsSelvec ? selected : ss.rows) * value_bytes;
+    if (ap.row_mode != kRowsSelvec) {
+      // every row, or a bitmap-selected share of them: the streaming GROUP BY kernel with no
+      // key columns, i.e. one group whose replicas in LDS keep the lanes of a wave apart
+      std::vector<int> slot_ops;
+      for (int s = 0; s < ap.n_slots; ++s) slot_ops.push_back(ap.slots[s].op);
+      GroupTable gt;
+      table_alloc(ctx, gt, true, 1, slot_ops);
+      ap.n_keys = 0;
+      ap.key_bits = 0;
+      ap.key_words = 1;
+      ap.lds_slots = lds_slots_for(ap.n_slots);
+      ap.dense = 1;
+      ap.capacity = 1;
+      ap.g_keys = nullptr;
+      ap.g_keys_hi = nullptr;
+      ap.g_state = gt.state.as<int64_t>();
+      ap.overflow = gt.overflow.as<uint32_t>();
+      launch_group_by(ctx, ap, agg_bytes, "agg_global");
+      std::vector<int64_t> both((size_t)ap.n_slots * 2);  // entry 0 and the unused extra entry of every slot
+      PRISM_HIP(hipMemcpyAsync(both.data(), gt.state.p, both.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+      PRISM_HIP(hipStreamSynchronize(ctx->stream));
+      for (int s = 0; s < ap.n_slots; ++s) g.state[s] = both[(size_t)s * 2];
+    } else {
+      // a selection vector of few rows: gather them
+      std::vector<int64_t> init(ap.n_slots);
+      for (int s = 0; s < ap.n_slots; ++s) init[s] = slot_identity_host(ap.slots[s].op);
+      Scratch d_out(ctx, 256);
+      PRISM_HIP(hipMemcpyAsync(d_out.p, init.data(), init.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+      {
+        KernelTimer timer(ctx, "agg_global", agg_bytes);
+        launch_agg_global(ctx, ap, d_out.as<int64_t>());
+      }
+      PRISM_HIP(hipMemcpyAsync(g.state.data(), d_out.p, g.state.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+      PRISM_HIP(hipStreamSynchronize(ctx->stream));
+    }
     append_agg_columns(low, g, partial, cols, 0);
     groups_out = 1;
   } else {
@@ -986,7 +1013,13 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
     uint64_t bound = selected;
     if (total_bits < 63) bound = std::min<uint64_t>(bound, 1ull << total_bits);
     GroupTable gt;
-    bool dense = total_bits <= kDenseMaxBits;
+    // The packed key indexes the table directly when the key space is small, or when it is
+    // not much larger than the number of rows (say GROUP BY a timestamp in ms over sorted
+    // data: neighbouring rows then update neighbouring entries, where a hash table would
+    // scatter them over gigabytes).
+    // (Not when the ranks of a multi-GPU query must take the same decision: the row count is local.)
+    bool dense = total_bits <= kDenseMaxBits ||
+                 (!ss.stats_override && total_bits <= kDenseMaxBitsLarge && (1ull << total_bits) <= 2 * bound);
     uint64_t capacity = dense ? (1ull << total_bits)
                               : pow2_ceil(std::max<uint64_t>(1024, 2 * (plan->groups_hint ? std::min<uint64_t>(plan->groups_hint, bound)
                                                                                          : std::min<uint64_t>(bound, 1ull << 24))));

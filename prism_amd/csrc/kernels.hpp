@@ -159,7 +159,7 @@ GroupByKernel pick_stream_kernel(const AggParams& p, size_t* lds_bytes, uint32_t
 // Ungrouped aggregates: out[n_slots] must hold the slot identities on entry.
 void launch_agg_global(prism_gpu_ctx* ctx, const AggParams& p, int64_t* out);
 // GROUP BY: accumulates into p.g_keys / p.g_state.
-void launch_group_by(prism_gpu_ctx* ctx, const AggParams& p, uint64_t algorithmic_bytes);
+void launch_group_by(prism_gpu_ctx* ctx, const AggParams& p, uint64_t algorithmic_bytes, const char* stat_name = "group_by");
 // Second level of COUNT(DISTINCT x) GROUP BY k: every occupied entry of the
 // (k, x) set adds 1 (when its x field is not NULL) to group k of table `q`.
 struct DistinctFoldParams {
@@ -196,7 +196,10 @@ constexpr int kTopKBins = 2048;
 struct TopKState {
   uint64_t prefix, mask;  // ranks still in play: (rank & mask) == prefix
   uint64_t k_rem;         // how many of those are wanted
-  uint32_t done, pad;
+  uint32_t done;          // a pass found a bin with few entries: everything from `prefix` up passes
+  uint32_t exact;         // all 64 rank bits are resolved: of the entries whose rank equals `prefix`
+                          // only k_rem are wanted (ties are broken arbitrarily)
+  unsigned long long ties_taken;  // ties let through by the emit pass in progress
   uint32_t hist[kTopKBins];
 };
 // Leaves the threshold in d_state->prefix.  d_state is overwritten.
@@ -228,7 +231,7 @@ void launch_fill_i64(prism_gpu_ctx* ctx, int64_t* dst, uint64_t n, int64_t value
 void launch_emit(prism_gpu_ctx* ctx, bool dense, uint64_t capacity, const uint64_t* g_keys, const uint64_t* g_keys_hi,
                  const int64_t* g_state, int n_slots, uint64_t* out_keys, uint64_t* out_keys_hi, int64_t* out_state,
                  uint64_t out_stride, unsigned long long* out_count, const TopKOrder* order = nullptr,
-                 const TopKState* d_threshold = nullptr);
+                 TopKState* d_threshold = nullptr);
 
 // ---- loader support ----------------------------------------------------------
 

@@ -489,20 +489,41 @@ __global__ __launch_bounds__(kBlock) void k_topk_pick(TopKState* st, int shift, 
     }
   }
   for (int j = 0; j < kPer; ++j) st->hist[top - j] = 0;
+  __syncthreads();  // the thread that owns the chosen bin may just have set st->done
+  if (t == 0 && shift == 0 && !done) st->exact = st->done ? 0u : 1u;
 }
 
 __global__ __launch_bounds__(kBlock) void k_emit(int dense, uint64_t capacity, const uint64_t* g_keys,
                                                 const uint64_t* g_keys_hi, const long long* g_state, int n_slots,
                                                 uint64_t* out_keys, uint64_t* out_keys_hi, long long* out_state,
                                                 uint64_t out_stride, unsigned long long* out_count, int filtered,
-                                                TopKOrder order, const TopKState* threshold) {
+                                                TopKOrder order, TopKState* threshold) {
   const uint64_t n = dense ? capacity : capacity + 1;
   const uint64_t min_rank = filtered ? threshold->prefix : 0ull;
+  const bool exact = filtered && threshold->exact != 0;
+  const uint64_t ties_wanted = filtered ? threshold->k_rem : 0ull;
   const int lane = threadIdx.x & 63;
   for (uint64_t base = (uint64_t)blockIdx.x * kBlock; base < n; base += (uint64_t)gridDim.x * kBlock) {
     const uint64_t i = base + threadIdx.x;
     bool take = i < n && occupied(dense != 0, capacity, g_keys, g_state, i);
-    if (take && filtered) take = topk_rank(order, dense != 0, capacity, g_keys, g_keys_hi, g_state, i) >= min_rank;
+    if (take && filtered) {
+      const uint64_t rank = topk_rank(order, dense != 0, capacity, g_keys, g_keys_hi, g_state, i);
+      take = rank >= min_rank;
+      // entries that tie with the threshold: only as many as are still wanted get through
+      // (once the quota is full a plain read of the counter settles it, without an atomic)
+      bool tie = exact && rank == min_rank;
+      if (tie && __hip_atomic_load(&threshold->ties_taken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= ties_wanted) {
+        tie = false;
+        take = false;
+      }
+      const uint64_t tm = __ballot(tie);
+      if (tm) {
+        unsigned long long first_tie = 0;
+        if (lane == __ffsll((long long)tm) - 1) first_tie = atomicAdd(&threshold->ties_taken, (unsigned long long)__popcll(tm));
+        first_tie = __shfl(first_tie, __ffsll((long long)tm) - 1);
+        if (tie) take = first_tie + __popcll(tm & ((1ull << lane) - 1)) < ties_wanted;
+      }
+    }
     // one counter update per wave
     const uint64_t m = __ballot(take);
     if (m == 0) continue;
@@ -533,7 +554,7 @@ void launch_agg_global(prism_gpu_ctx* ctx, const AggParams& p, int64_t* out) {
   PRISM_HIP(hipGetLastError());
 }
 
-void launch_group_by(prism_gpu_ctx* ctx, const AggParams& params, uint64_t algorithmic_bytes) {
+void launch_group_by(prism_gpu_ctx* ctx, const AggParams& params, uint64_t algorithmic_bytes, const char* stat_name) {
   AggParams p = params;
   uint64_t work = p.row_mode == kRowsSelvec ? ceil_div(p.n_sel, (uint64_t)kBlock * 16) : p.sd.n_tiles;
   if (work == 0) return;
@@ -563,7 +584,7 @@ void launch_group_by(prism_gpu_ctx* ctx, const AggParams& params, uint64_t algor
   PRISM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)block, lds));
   if (per_cu < 1) per_cu = 1;
   uint32_t grid = (uint32_t)std::min<uint64_t>(work, (uint64_t)ctx->n_cus * (uint64_t)per_cu);
-  KernelTimer timer(ctx, "group_by", algorithmic_bytes);
+  KernelTimer timer(ctx, stat_name, algorithmic_bytes);
   kernel<<<dim3(grid), dim3(block), lds, ctx->stream>>>(p);
   PRISM_HIP(hipGetLastError());
 }
@@ -591,11 +612,14 @@ void launch_fill_i64(prism_gpu_ctx* ctx, int64_t* dst, uint64_t n, int64_t value
 void launch_emit(prism_gpu_ctx* ctx, bool dense, uint64_t capacity, const uint64_t* g_keys, const uint64_t* g_keys_hi,
                  const int64_t* g_state, int n_slots, uint64_t* out_keys, uint64_t* out_keys_hi, int64_t* out_state,
                  uint64_t out_stride, unsigned long long* out_count, const TopKOrder* order,
-                 const TopKState* d_threshold) {
+                 TopKState* d_threshold) {
   uint64_t n = dense ? capacity : capacity + 1;
   if (n == 0) return;
   TopKOrder o{};
-  if (order) o = *order;
+  if (order) {
+    o = *order;
+    PRISM_HIP(hipMemsetAsync(&d_threshold->ties_taken, 0, sizeof(d_threshold->ties_taken), ctx->stream));
+  }
   k_emit<<<dim3(stream_grid(ctx, n)), dim3(kBlock), 0, ctx->stream>>>(dense ? 1 : 0, capacity, g_keys, g_keys_hi,
                                                                     (const long long*)g_state, n_slots, out_keys,
                                                                     out_keys_hi, (long long*)out_state, out_stride,
