@@ -362,6 +362,7 @@ typedef struct prism_gpu_stats {
   double staging_ms;
   uint32_t n_kernels;
   prism_gpu_kernel_stat kernels[PRISM_GPU_MAX_KERNEL_STATS];
+  uint64_t chunks_pruned; /* chunks skipped because their min/max rule the predicate out */
 } prism_gpu_stats;
 
 int prism_gpu_set_profiling(prism_gpu_ctx* ctx, int enabled);

@@ -164,6 +164,7 @@ class Stats(C.Structure):
         ("staging_ms", C.c_double),
         ("n_kernels", C.c_uint32),
         ("kernels", KernelStat * MAX_KERNEL_STATS),
+        ("chunks_pruned", C.c_uint64),
     ]
 
 

@@ -727,6 +727,33 @@ bool topk_order(const prism_gpu_plan* p, const prism_gpu_table* t, const std::ve
   return true;
 }
 
+// Zone-map pruning: can the predicate be TRUE for any row of the chunk, judging by the
+// chunk's per-column min / max / NULL count?  The reference scans every partition of a
+// table (time_range: None, src/prism-query/src/providers/table_provider.rs:90); a WHERE on
+// the timestamp therefore reads everything there, while here chunks outside the range
+// are dropped before any kernel runs.  Unknown shapes answer "maybe".
+bool chunk_may_match(const prism_gpu_plan* p, const prism_gpu_table* t, int node, const Chunk& ch) {
+  const PredNode& n = p->pred[node];
+  switch (n.kind) {
+    case PredNode::AND: return chunk_may_match(p, t, n.lhs, ch) && chunk_may_match(p, t, n.rhs, ch);
+    case PredNode::OR: return chunk_may_match(p, t, n.lhs, ch) || chunk_may_match(p, t, n.rhs, ch);
+    case PredNode::IS_NULL: return ch.stats[n.column].null_count > 0;
+    case PredNode::IS_NOT_NULL: return ch.stats[n.column].null_count < ch.rows;
+    case PredNode::CMP: {
+      const FieldType& f = t->fields[n.column];
+      if (f.is_string || f.is_float) return true;
+      const ColStats& s = ch.stats[n.column];
+      if (s.min > s.max) return false;  // only NULLs: a comparison is never TRUE
+      bool any = false;
+      if (n.cmp_mask & kLt) any = any || s.min < n.lit_i64;
+      if (n.cmp_mask & kEq) any = any || (s.min <= n.lit_i64 && n.lit_i64 <= s.max);
+      if (n.cmp_mask & kGt) any = any || s.max > n.lit_i64;
+      return any;
+    }
+    default: return true;
+  }
+}
+
 int lds_slots_for(int n_slots) {
   // about 32 KiB of LDS per workgroup, so that several workgroups share a CU
   size_t per_entry = 8 * (1 + (size_t)n_slots);
@@ -821,14 +848,23 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
   ScanSet ss;
   ss.ctx = ctx;
   ss.stats_override = stats_override;
+  uint64_t chunks_pruned = 0;
   for (const Chunk& ch : table->chunks) {
     bool take = partition_ids == nullptr || n_partitions == 0;
     for (size_t i = 0; !take && i < n_partitions; ++i) take = partition_ids[i] == ch.partition_id;
     if (!take || ch.rows == 0) continue;
+    if (plan->pred_root >= 0 && !merge_input && !chunk_may_match(plan, table, plan->pred_root, ch)) {
+      chunks_pruned += 1;
+      continue;
+    }
     ss.chunks.push_back(&ch);
     ss.segs.push_back({ch.rows, ss.n_tiles});
     ss.n_tiles += ceil_div(ch.rows, kTileRows);
     ss.rows += ch.rows;
+  }
+  if (chunks_pruned) {
+    std::lock_guard<std::mutex> g(ctx->mu);
+    ctx->stats.chunks_pruned += chunks_pruned;
   }
   if (ss.n_tiles * (uint64_t)kTileRows > 0xffffffffull)
     fail(PRISM_GPU_EUNSUPPORTED, "more than 2^32 rows in one scan; split the scan by partition");

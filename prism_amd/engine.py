@@ -138,6 +138,7 @@ class Context:
             "groups_out": s.groups_out,
             "bytes_staged": s.bytes_staged,
             "staging_ms": s.staging_ms,
+            "chunks_pruned": s.chunks_pruned,
             "kernels": {
                 s.kernels[i].name.decode(): {
                     "launches": s.kernels[i].launches,

@@ -35,7 +35,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(abi.Expr) == 48 and C.sizeof(abi.Key) == 32 and C.sizeof(abi.Agg) == 16
     assert C.sizeof(abi.PlanDesc) == 80 and C.sizeof(abi.SynthCol) == 56
     assert C.sizeof(abi.KernelStat) == 72
-    assert C.sizeof(abi.Stats) == 48 + 72 * abi.MAX_KERNEL_STATS
+    assert C.sizeof(abi.Stats) == 48 + 72 * abi.MAX_KERNEL_STATS + 8
 
 
 def test_no_gpu_means_a_loud_error_not_a_fallback():

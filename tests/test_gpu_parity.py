@@ -275,3 +275,33 @@ def test_unsupported_and_invalid_plans(gpu_ctx):
     assert e.value.code == abi.EUNSUPPORTED
     with pytest.raises(KeyError):
         Plan(gpu_ctx, t.schema, QueryPlan([count_star()], keys=["something"]))
+
+
+def test_chunks_outside_the_predicate_range_are_pruned(gpu_ctx, oracle):
+    """Zone maps: a WHERE on the (sorted) timestamp drops whole chunks before any kernel
+    runs; the answer is the same as scanning everything."""
+    from prism_amd.engine import Plan, Table
+
+    t = helpers.random_table(40_000, seed=3, nulls=True)  # ts ascending over 3 hours
+    g = Table(gpu_ctx, t.schema)
+    g.append_table(t, 8)
+    ts = t.column("ts").cast(pa.int64()).to_numpy()
+    lo, hi = int(ts[len(ts) // 4]), int(ts[len(ts) // 2])
+    try:
+        for pred, expect_pruned in [((col("ts") >= lo) & (col("ts") < hi), True),
+                                    ((col("ts") < lo) | (col("ts") >= hi), True),
+                                    (col("ts") > int(ts[-1]), True),
+                                    (col("i32") > 2000, True),        # above every value: all chunks go
+                                    (col("i32") > -2000, False)]:
+            q = QueryPlan([count_star(), sum_("value")], keys=["service"], predicate=pred)
+            plan = Plan(gpu_ctx, t.schema, q)
+            try:
+                before = gpu_ctx.stats()["chunks_pruned"]
+                got = plan.execute(g)
+                pruned = gpu_ctx.stats()["chunks_pruned"] - before
+            finally:
+                plan.close()
+            assert_tables_match(got, oracle.execute(t, q), 1)
+            assert (pruned > 0) == expect_pruned, (pred, pruned)
+    finally:
+        g.close()
