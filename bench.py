@@ -38,7 +38,7 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3", "C5"])
+    ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3", "C4", "C4G", "C5"])
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the workload's)")
     ap.add_argument("--partitions", type=int, default=0, help="partitions per GPU")
     ap.add_argument("--cpu-sample-partitions", type=int, default=8,
@@ -179,7 +179,8 @@ def main() -> int:
         # full-size, size-independent checks: every row lands in exactly one group
         if args.workload in ("C2",):
             assert sum(result.column("COUNT(*)").to_pylist()) == total_rows, "COUNT(*) does not add up to the rows scanned"
-        kname = {"C1": "filter_count", "C2": "group_by", "C3": "group_by", "C5": "group_by"}[args.workload]
+        kname = {"C1": "filter_count", "C2": "group_by", "C3": "group_by", "C4": "like_contains", "C4G": "like_contains",
+                 "C5": "group_by"}[args.workload]
         ks = stats["kernels"].get(kname)
         roofline = None
         if ks and ks["launches"]:

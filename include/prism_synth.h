@@ -42,7 +42,15 @@ typedef enum prism_synth_kind {
    * discrete log-uniform law, the integer-only cousin of Zipf s = 1) over
    * 2^B - 1 ranks.  The value is a 63-bit hash of the rank, so ids are spread
    * over the whole non-negative Int64 range like ClickBench UserIDs. */
-  PRISM_SYNTH_LOGUNIFORM_ID = 5
+  PRISM_SYNTH_LOGUNIFORM_ID = 5,
+  /* Variable-length ASCII strings for Utf8 columns (URL-like, for LIKE '%needle%').
+   * cdf[0..len-1] is a table of byte lengths, the quantiles of the wanted length
+   * distribution: a row's length is cdf[floor(u * len)] for a uniform u.  The bytes
+   * are drawn from [a-z0-9/.:-], eight per hash.  p0 = P(needle) * 2^32: with that
+   * probability "google" overwrites 6 bytes at a uniform offset; p1 = P(near miss)
+   * * 2^32: with that probability "googl" or "gogle" (5 bytes) does.  Strings shorter
+   * than the pattern are left alone.  See prism_synth_url_length / _bytes. */
+  PRISM_SYNTH_URL = 6
 } prism_synth_kind;
 
 PRISM_HD uint64_t prism_mix64(uint64_t z) {
@@ -104,6 +112,49 @@ PRISM_HD int64_t prism_synth_value(int32_t kind, const int64_t* p,
     }
     default:
       return 0;
+  }
+}
+
+/* ---- PRISM_SYNTH_URL ---- */
+
+PRISM_HD uint32_t prism_synth_url_length(const uint32_t* lens, uint32_t n_lens,
+                                         uint64_t column_key, uint64_t global_row) {
+  uint64_t r = prism_synth_rand(column_key, global_row);
+  return lens[(uint32_t)(((r >> 32) * (uint64_t)n_lens) >> 32)];
+}
+
+PRISM_HD uint8_t prism_synth_url_char(uint32_t byte) {
+  uint32_t i = (byte * 40u) >> 8; /* 0..39 */
+  if (i < 26u) return (uint8_t)('a' + i);
+  if (i < 36u) return (uint8_t)('0' + (i - 26u));
+  return i == 36u ? (uint8_t)'/' : i == 37u ? (uint8_t)'.' : i == 38u ? (uint8_t)':' : (uint8_t)'-';
+}
+
+/* Writes the `len` bytes of the row's string to dst. */
+PRISM_HD void prism_synth_url_bytes(uint8_t* dst, uint32_t len, const int64_t* p,
+                                    uint64_t column_key, uint64_t global_row) {
+  const uint64_t row_key = prism_mix64(prism_synth_rand(column_key, global_row) ^ 0xA24BAED4963EE407ull);
+  for (uint32_t w = 0; w * 8u < len; ++w) {
+    uint64_t h = prism_mix64(row_key + w);
+    for (uint32_t j = 0; j < 8u && w * 8u + j < len; ++j)
+      dst[w * 8u + j] = prism_synth_url_char((uint32_t)(h >> (8u * j)) & 0xffu);
+  }
+  const uint64_t r = prism_mix64(row_key ^ 0x9FB21C651E98DF25ull);
+  const uint64_t hi = r >> 32, lo = r & 0xFFFFFFFFull;
+  const uint8_t needle[6] = {'g', 'o', 'o', 'g', 'l', 'e'};
+  const uint8_t miss_a[5] = {'g', 'o', 'o', 'g', 'l'};
+  const uint8_t miss_b[5] = {'g', 'o', 'g', 'l', 'e'};
+  if (hi < (uint64_t)p[0]) {
+    if (len >= 6u) {
+      uint32_t off = (uint32_t)((lo * (uint64_t)(len - 5u)) >> 32);
+      for (uint32_t j = 0; j < 6u; ++j) dst[off + j] = needle[j];
+    }
+  } else if (hi < (uint64_t)p[0] + (uint64_t)p[1]) {
+    if (len >= 5u) {
+      uint32_t off = (uint32_t)((lo * (uint64_t)(len - 4u)) >> 32);
+      const uint8_t* m = ((r >> 7) & 1ull) ? miss_a : miss_b;
+      for (uint32_t j = 0; j < 5u; ++j) dst[off + j] = m[j];
+    }
   }
 }
 

@@ -990,10 +990,29 @@ int prism_oracle_synth_create(const ArrowSchema* schema, uint64_t seed, uint64_t
       uint64_t lo = n_rows * pi / n_parts, hi = n_rows * (pi + 1) / n_parts;
       auto b = std::make_unique<Batch>();
       b->n = (int64_t)(hi - lo);
-      b->owned.resize(n_cols);
+      b->owned.resize(2 * (size_t)n_cols);  // [n_cols + ci]: the bytes of a generated string column
       for (uint32_t ci = 0; ci < n_cols; ++ci) {
         const prism_gpu_synth_col& sc = cols[ci];
         const ColType& t = T->types[sc.column];
+        if (sc.kind == PRISM_SYNTH_URL) {
+          if (t.phys != Phys::STR) fail(PRISM_GPU_EINVAL, "oracle: the URL generator needs a string column");
+          uint64_t key = prism_synth_column_key(seed, (uint32_t)sc.column);
+          std::vector<uint8_t>& offs = b->owned[ci];
+          offs.resize((size_t)(hi - lo + 1) * 4);
+          int32_t* o = (int32_t*)offs.data();
+          uint64_t pos = 0;
+          o[0] = 0;
+          for (uint64_t r = lo; r < hi; ++r) {
+            pos += prism_synth_url_length(sc.cdf, sc.cdf_len, key, first_row + r);
+            if (pos > 0x7fffffffull) fail(PRISM_GPU_EUNSUPPORTED, "oracle: string data of one partition exceeds 2 GiB");
+            o[r - lo + 1] = (int32_t)pos;
+          }
+          std::vector<uint8_t>& data = b->owned[n_cols + ci];
+          data.resize((size_t)pos + 8);
+          for (uint64_t r = lo; r < hi; ++r)
+            prism_synth_url_bytes(data.data() + o[r - lo], (uint32_t)(o[r - lo + 1] - o[r - lo]), sc.p, key, first_row + r);
+          continue;
+        }
         int w = t.phys == Phys::STR ? 4 : (t.phys == Phys::I16 || t.phys == Phys::U16) ? 2 : t.phys == Phys::I32 ? 4 : 8;
         b->owned[ci].resize((size_t)(hi - lo) * w + 8);
         uint8_t* dst = b->owned[ci].data();
@@ -1010,7 +1029,8 @@ int prism_oracle_synth_create(const ArrowSchema* schema, uint64_t seed, uint64_t
       for (uint32_t ci = 0; ci < n_cols; ++ci) {
         ColView v;
         v.type = T->types[cols[ci].column];
-        if (v.type.phys == Phys::STR) { v.type.phys = Phys::I32; }  // dictionary codes stand for the strings
+        if (cols[ci].kind == PRISM_SYNTH_URL) v.data = b->owned[n_cols + ci].data();  // real strings
+        else if (v.type.phys == Phys::STR) { v.type.phys = Phys::I32; }  // dictionary codes stand for the strings
         v.n = b->n;
         v.values = b->owned[ci].data();
         b->cols[cols[ci].column] = v;

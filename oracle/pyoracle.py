@@ -140,8 +140,11 @@ class SynthTable:
         ms = C.c_double(0)
         _check(lib().prism_oracle_synth_execute(self._h, C.byref(self._cs), lp.ptr(), threads, C.byref(out),
                                                 C.byref(ms)))
-        # generated Utf8 columns are dictionary codes: the output schema has Int32 there
-        fields = [pa.field(f.name, pa.int32() if pa.types.is_string(f.type) else f.type) for f in self.schema]
+        # generated Utf8 columns are dictionary codes (the output schema has Int32 there),
+        # except those made by the URL generator, which are real strings
+        raw = {sc.column for sc in self._keep if sc.kind == abi.SYNTH_URL}
+        fields = [pa.field(f.name, pa.int32() if pa.types.is_string(f.type) and i not in raw else f.type)
+                  for i, f in enumerate(self.schema)]
         osch = output_schema(pa.schema(fields), plan)
         return pa.Table.from_batches([abi.import_batch(out, osch)]), ms.value
 

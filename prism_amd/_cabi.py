@@ -31,7 +31,7 @@ AGG_COUNT_STAR, AGG_COUNT, AGG_SUM, AGG_MIN, AGG_MAX, AGG_AVG, AGG_COUNT_DISTINC
 # prism_gpu_agg_mode
 MODE_SINGLE, MODE_PARTIAL = 0, 1
 # prism_synth_kind
-SYNTH_TS_LINEAR, SYNTH_CATEGORICAL, SYNTH_UNIFORM, SYNTH_SPARSE, SYNTH_LOGUNIFORM_ID = range(1, 6)
+SYNTH_TS_LINEAR, SYNTH_CATEGORICAL, SYNTH_UNIFORM, SYNTH_SPARSE, SYNTH_LOGUNIFORM_ID, SYNTH_URL = range(1, 7)
 
 
 class ArrowSchema(C.Structure):

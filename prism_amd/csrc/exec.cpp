@@ -447,8 +447,28 @@ struct PredEval {
           for (size_t k = 1; k + 1 < toks.size(); ++k) needle.push_back((char)toks[k].byte);
           const uint8_t* d_needle = to_device(needle.data(), needle.size());
           Scratch bits = new_bits(true);
+          // all segments in one streaming launch; should the needle occur more often than
+          // there are rows (a one-letter needle, say), segment by segment with the search
+          // for the row done in place
+          std::vector<ContainsSeg> csegs(ss.segs.size());
+          uint64_t n_chunks = 0;
+          for (size_t s = 0; s < ss.segs.size(); ++s) {
+            const DeviceColumn& dc = ss.chunks[s]->cols[n.column];
+            csegs[s] = {(const int32_t*)dc.values, dc.bytes, ss.segs[s].rows, dc.n_bytes, ss.segs[s].tile_base, n_chunks};
+            n_chunks += ceil_div(dc.n_bytes, kContainsChunkBytes);
+          }
+          const ContainsSeg* d_csegs = (const ContainsSeg*)to_device(csegs.data(), csegs.size() * sizeof(ContainsSeg));
+          const uint64_t match_capacity = std::max<uint64_t>(ss.rows, 1u << 16);
+          Scratch d_matches(ctx, match_capacity * 8), d_n_matches(ctx, 256);
+          bool done;
           {
             KernelTimer timer(ctx, "like_contains", str_bytes + ss.rows * 4);
+            done = launch_contains_all(ctx, d_csegs, (uint32_t)csegs.size(), n_chunks, d_needle, (uint32_t)needle.size(),
+                                       d_matches.as<uint64_t>(), match_capacity, d_n_matches.as<unsigned long long>(),
+                                       bits.as<uint64_t>());
+          }
+          if (!done) {
+            KernelTimer timer(ctx, "like_contains_dense", str_bytes + ss.rows * 4);
             for (size_t s = 0; s < ss.segs.size(); ++s) {
               const DeviceColumn& dc = ss.chunks[s]->cols[n.column];
               ColPtr cp{dc.values, dc.validity, dc.bytes};

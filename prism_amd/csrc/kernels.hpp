@@ -55,6 +55,25 @@ void launch_str_leaf(prism_gpu_ctx* ctx, const ScanDesc& sd, const ColPtr* col, 
                      uint32_t n_tokens, bool negated, bool case_insensitive, uint64_t* bits);
 // LIKE '%needle%' as a byte-stream search over one segment's string buffer: coalesced
 // 16-byte loads, matches mapped back to rows through the offsets.  `bits` must be zeroed.
+// '%needle%' over every segment of a raw string column in two passes: the first streams
+// the string bytes of all segments in one launch and appends the byte positions where
+// the needle occurs to a list; the second maps each position to its row (binary search
+// in the segment's offsets; an occurrence that straddles two rows is none) and sets the
+// row's bit.  Occurrences are rare next to bytes, so the first pass is a pure streaming
+// read.  Returns false when the list overflowed (then nothing was marked and the caller
+// falls back to launch_contains_stream per segment).
+struct ContainsSeg {
+  const int32_t* off;
+  const uint8_t* bytes;
+  uint64_t rows;
+  uint64_t n_bytes;
+  uint64_t tile_base;
+  uint64_t chunk_base;  // chunks of kContainsChunkBytes before this segment
+};
+constexpr uint64_t kContainsChunkBytes = 16384;
+bool launch_contains_all(prism_gpu_ctx* ctx, const ContainsSeg* d_segs, uint32_t n_segs, uint64_t n_chunks,
+                         const uint8_t* d_needle, uint32_t needle_len, uint64_t* d_matches, uint64_t match_capacity,
+                         unsigned long long* d_n_matches, uint64_t* bits);
 void launch_contains_stream(prism_gpu_ctx* ctx, const ColPtr& col, uint64_t rows, uint64_t tile_base,
                             const uint8_t* needle /*device*/, uint32_t needle_len, uint64_t* bits);
 // bits &= validity (per segment), or bits = validity & ~bits when `negate`.
@@ -253,6 +272,9 @@ struct SynthColDev {
   uint32_t cdf_len;
   uint64_t column_key;
 };
+// PRISM_SYNTH_URL: fills the bytes of n_rows strings whose offsets are given.
+void launch_synth_url(prism_gpu_ctx* ctx, const int32_t* offsets, uint8_t* bytes, uint64_t n_rows, uint64_t first_row,
+                      int64_t p0, int64_t p1, uint64_t column_key);
 void launch_synth(prism_gpu_ctx* ctx, const SynthColDev& col, uint64_t first_row, uint64_t n_rows,
                   uint64_t total_rows);
 

@@ -39,7 +39,25 @@ __global__ __launch_bounds__(kBlock) void k_synth(SynthColDev c, uint64_t first_
   }
 }
 
+// One thread per row writes the row's generated string between its offsets.
+__global__ __launch_bounds__(kBlock) void k_synth_url(const int32_t* offsets, uint8_t* bytes, uint64_t n_rows,
+                                                     uint64_t first_row, long long p0, long long p1, uint64_t column_key) {
+  const int64_t p[2] = {p0, p1};
+  for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < n_rows; r += (uint64_t)gridDim.x * kBlock) {
+    const uint32_t lo = (uint32_t)offsets[r], hi = (uint32_t)offsets[r + 1];
+    prism_synth_url_bytes(bytes + lo, hi - lo, p, column_key, first_row + r);
+  }
+}
+
 }  // namespace
+
+void launch_synth_url(prism_gpu_ctx* ctx, const int32_t* offsets, uint8_t* bytes, uint64_t n_rows, uint64_t first_row,
+                      int64_t p0, int64_t p1, uint64_t column_key) {
+  if (n_rows == 0) return;
+  uint32_t grid = (uint32_t)std::min<uint64_t>(ceil_div(n_rows, (uint64_t)kBlock), (uint64_t)ctx->n_cus * 16);
+  k_synth_url<<<dim3(std::max(1u, grid)), dim3(kBlock), 0, ctx->stream>>>(offsets, bytes, n_rows, first_row, p0, p1, column_key);
+  PRISM_HIP(hipGetLastError());
+}
 
 void launch_col_stats(prism_gpu_ctx* ctx, const void* values, const uint64_t* validity, int width, bool is_unsigned,
                       uint64_t rows, ColStats* stats, hipStream_t stream) {

@@ -385,6 +385,149 @@ void launch_str_leaf(prism_gpu_ctx* ctx, const ScanDesc& sd, const ColPtr* col, 
   PRISM_HIP(hipGetLastError());
 }
 
+namespace {
+
+// Pass 1: every workgroup walks a contiguous share of 16-KiB chunks of the concatenated
+// segments; a lane tests the 16 byte positions of each of its four 16-byte pieces.
+__global__ __launch_bounds__(kBlock) void k_contains_find(const ContainsSeg* segs, uint32_t n_segs, uint64_t n_chunks,
+                                                         const uint8_t* needle, uint32_t L, uint64_t* matches,
+                                                         uint64_t capacity, unsigned long long* n_matches) {
+  constexpr int K = (int)(kContainsChunkBytes / (kBlock * 16));
+  const uint32_t k = L < 4 ? L : 4;
+  uint32_t first = 0;
+  for (uint32_t i = 0; i < k; ++i) first |= (uint32_t)needle[i] << (8 * i);
+  const uint32_t nmask = k == 4 ? 0xffffffffu : ((1u << (8 * k)) - 1u);
+  const uint64_t per = uniform_u64(ceil_div(n_chunks, (uint64_t)gridDim.x));
+  const uint64_t c0 = per * blockIdx.x, c1 = c0 + per < n_chunks ? c0 + per : n_chunks;
+  uint32_t seg = 0;
+  const int lane = threadIdx.x & 63;
+  // Occurrences are collected in LDS and moved to the list a few hundred at a time: one
+  // atomic on the list's counter per occurrence would serialise on that one address.
+  constexpr uint32_t kBuf = 1024;
+  __shared__ uint64_t buf[kBuf];
+  __shared__ uint32_t buf_n;
+  __shared__ unsigned long long flush_base;
+  if (threadIdx.x == 0) buf_n = 0;
+  __syncthreads();
+  auto flush = [&]() {  // block-wide, between barriers
+    const uint32_t n = buf_n < kBuf ? buf_n : kBuf;
+    if (threadIdx.x == 0) flush_base = atomicAdd(n_matches, (unsigned long long)n);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += kBlock)
+      if (flush_base + i < capacity) matches[flush_base + i] = buf[i];
+    __syncthreads();
+    if (threadIdx.x == 0) buf_n = 0;
+    __syncthreads();
+  };
+  for (uint64_t c = c0; c < c1; ++c) {
+    while (seg + 1 < n_segs && segs[seg + 1].chunk_base <= c) ++seg;
+    seg = __builtin_amdgcn_readfirstlane(seg);
+    const uint8_t* bytes = (const uint8_t*)uniform_u64((uint64_t)segs[seg].bytes);
+    const uint64_t total = uniform_u64(segs[seg].n_bytes);
+    const uint64_t base = (c - uniform_u64(segs[seg].chunk_base)) * kContainsChunkBytes;
+    uint32_t d[K][5];
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+      const uint64_t p = base + (uint64_t)q * (kBlock * 16) + (uint64_t)threadIdx.x * 16;
+      if (p < total) {
+        // the buffer is padded by the loader, so these 20 bytes are always readable
+        const uint4 own = stream16(bytes + p);
+        d[q][0] = own.x; d[q][1] = own.y; d[q][2] = own.z; d[q][3] = own.w;
+        d[q][4] = *(const uint32_t*)(bytes + p + 16);
+      } else {
+        d[q][0] = d[q][1] = d[q][2] = d[q][3] = d[q][4] = 0;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+      const uint64_t p = base + (uint64_t)q * (kBlock * 16) + (uint64_t)threadIdx.x * 16;
+      uint32_t cand = 0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const uint32_t w = __builtin_amdgcn_alignbyte(d[q][(j >> 2) + 1], d[q][j >> 2], j & 3);
+        cand |= (((w & nmask) == first) ? 1u : 0u) << j;
+      }
+      if (p >= total) cand = 0;
+      // rare from here on: verify the rest of the needle, then append the position
+      while (__ballot(cand != 0) != 0ull) {
+        bool hit = false;
+        uint64_t pos = 0;
+        if (cand) {
+          const int j = __ffs(cand) - 1;
+          cand &= cand - 1;
+          pos = p + j;
+          hit = pos + L <= total;
+          for (uint32_t i = 4; i < L && hit; ++i) hit = bytes[pos + i] == needle[i];
+        }
+        const uint64_t m = __ballot(hit);
+        if (m) {
+          uint32_t at = 0;
+          if (lane == __ffsll((long long)m) - 1) at = atomicAdd(&buf_n, (uint32_t)__popcll(m));
+          at = __shfl(at, __ffsll((long long)m) - 1);
+          if (hit) {
+            at += __popcll(m & ((1ull << lane) - 1));
+            const uint64_t rec = ((uint64_t)seg << 32) | pos;  // pos < 2^31: offsets are i32
+            if (at < kBuf) {
+              buf[at] = rec;
+            } else {
+              // the buffer filled up within one chunk (a needle that occurs all over): append directly
+              const unsigned long long g = atomicAdd(n_matches, 1ull);
+              if (g < capacity) matches[g] = rec;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (buf_n > kBuf / 2) flush();  // uniform: every thread reads the same counter after the barrier
+    else __syncthreads();
+  }
+  __syncthreads();
+  flush();
+}
+
+// Pass 2: one thread per occurrence.
+__global__ __launch_bounds__(kBlock) void k_contains_mark(const ContainsSeg* segs, const uint64_t* matches, uint64_t n,
+                                                         uint32_t L, uint64_t* bits) {
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+    const uint64_t m = matches[i];
+    const ContainsSeg& s = segs[m >> 32];
+    const uint64_t pos = m & 0xffffffffull;
+    // row with off[row] <= pos < off[row + 1]
+    uint64_t lo = 0, hi = s.rows;
+    while (hi - lo > 1) {
+      const uint64_t mid = (lo + hi) >> 1;
+      if ((uint64_t)(uint32_t)s.off[mid] <= pos) lo = mid; else hi = mid;
+    }
+    if (pos + L <= (uint64_t)(uint32_t)s.off[lo + 1] && (uint64_t)(uint32_t)s.off[lo] <= pos) {
+      const uint64_t pid = s.tile_base * kTileRows + lo;
+      atomicOr((unsigned long long*)&bits[pid >> 6], 1ull << (pid & 63));
+    }
+  }
+}
+
+}  // namespace
+
+bool launch_contains_all(prism_gpu_ctx* ctx, const ContainsSeg* d_segs, uint32_t n_segs, uint64_t n_chunks,
+                         const uint8_t* d_needle, uint32_t needle_len, uint64_t* d_matches, uint64_t match_capacity,
+                         unsigned long long* d_n_matches, uint64_t* bits) {
+  if (n_chunks == 0) return true;
+  PRISM_HIP(hipMemsetAsync(d_n_matches, 0, 8, ctx->stream));
+  const uint32_t grid = (uint32_t)std::min<uint64_t>(n_chunks, (uint64_t)ctx->n_cus * 8);
+  k_contains_find<<<dim3(grid), dim3(kBlock), 0, ctx->stream>>>(d_segs, n_segs, n_chunks, d_needle, needle_len, d_matches,
+                                                               match_capacity, d_n_matches);
+  PRISM_HIP(hipGetLastError());
+  unsigned long long n = 0;
+  PRISM_HIP(hipMemcpyAsync(&n, d_n_matches, 8, hipMemcpyDeviceToHost, ctx->stream));
+  PRISM_HIP(hipStreamSynchronize(ctx->stream));
+  if (n > match_capacity) return false;
+  if (n == 0) return true;
+  const uint32_t g2 = (uint32_t)std::min<uint64_t>(ceil_div(n, kBlock), (uint64_t)ctx->n_cus * 8);
+  k_contains_mark<<<dim3(g2), dim3(kBlock), 0, ctx->stream>>>(d_segs, d_matches, n, needle_len, bits);
+  PRISM_HIP(hipGetLastError());
+  return true;
+}
+
 void launch_contains_stream(prism_gpu_ctx* ctx, const ColPtr& col, uint64_t rows, uint64_t tile_base,
                             const uint8_t* needle, uint32_t needle_len, uint64_t* bits) {
   if (rows == 0) return;

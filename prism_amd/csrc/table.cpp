@@ -286,6 +286,36 @@ void table_synth(prism_gpu_table* t, uint32_t partition_id, uint64_t seed, uint6
     const FieldType& f = t->fields[sc.column];
     DeviceColumn& dc = ch.cols[sc.column];
     if (dc.values || dc.codes) fail(PRISM_GPU_EINVAL, "two generators for one column");
+    if (sc.kind == PRISM_SYNTH_URL) {
+      // raw strings: lengths (hence offsets) on the host, bytes on the device
+      if (!f.is_string) fail(PRISM_GPU_EINVAL, "the URL generator needs a string column");
+      if (!sc.cdf || sc.cdf_len == 0) fail(PRISM_GPU_EINVAL, "the URL generator needs a table of lengths");
+      ColumnDict& dict = t->dicts[sc.column];
+      if (!dict.values.empty()) fail(PRISM_GPU_EINVAL, "the column already has a dictionary");
+      dict.alive = false;  // high cardinality by construction: raw representation only
+      const uint64_t key = prism_synth_column_key(seed, (uint32_t)sc.column);
+      std::vector<int32_t> offs((size_t)n_rows + 1);
+      uint64_t pos = 0;
+      offs[0] = 0;
+      for (uint64_t r = 0; r < n_rows; ++r) {
+        pos += prism_synth_url_length(sc.cdf, sc.cdf_len, key, first_row + r);
+        if (pos > 0x7fffffffull) fail(PRISM_GPU_EUNSUPPORTED, "string data of one partition exceeds 2 GiB; use more partitions");
+        offs[(size_t)r + 1] = (int32_t)pos;
+      }
+      dc.values = dev_alloc(offs.size() * 4);
+      stage_copy(ctx, dc.values, offs.data(), offs.size() * 4);
+      PRISM_HIP(hipStreamSynchronize(ctx->copy_stream));
+      {
+        std::lock_guard<std::mutex> gs(ctx->mu);
+        ctx->stage_busy[0] = ctx->stage_busy[1] = false;
+      }
+      dc.bytes = (uint8_t*)dev_alloc(pos);
+      dc.n_bytes = pos;
+      launch_synth_url(ctx, (const int32_t*)dc.values, dc.bytes, n_rows, first_row, sc.p[0], sc.p[1], key);
+      launch_col_stats(ctx, dc.values, nullptr, 4, true, n_rows, &ch.d_stats[sc.column], ctx->stream);
+      PRISM_HIP(hipStreamSynchronize(ctx->stream));
+      continue;
+    }
     SynthColDev d{};
     d.width = f.is_string ? 4 : f.width;
     d.kind = sc.kind;

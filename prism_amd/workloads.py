@@ -9,10 +9,9 @@ include/prism_synth.h, which the GPU and the CPU checker evaluate identically.
     C1  hits-like:   COUNT(*) WHERE "AdvEngineID" <> 0
     C2  log events:  date_bin(1 minute, timestamp), service -> COUNT(*), SUM(value), MAX(value)
     C3  hits-like:   "UserID", COUNT(*) GROUP BY 1 ORDER BY 2 DESC LIMIT 10
+    C4  hits-like:   COUNT(*) WHERE "URL" LIKE '%google%'  (URL-like strings, mean 64 bytes)
+    C4G              "UserID", COUNT(*) WHERE "URL" LIKE '%google%' GROUP BY 1  (the compaction variant)
     C5  time series: date_bin(1 hour, timestamp), service -> COUNT(DISTINCT user)
-
-(C4, the LIKE workload, needs variable-length strings and is built from pyarrow
-tables in the tests rather than from these fixed-width generators.)
 """
 from __future__ import annotations
 
@@ -23,6 +22,20 @@ import pyarrow as pa
 
 from . import _cabi as abi
 from .plan import QueryPlan, col, count_distinct, count_star, date_bin, max_, sum_
+
+
+def url_length_table(n: int = 1024, mu: float = 4.0, sigma: float = 0.6, lo: int = 8, hi: int = 512) -> List[int]:
+    """Quantiles of clamp(lognormal(mu, sigma), lo, hi), in bytes: the length table of the
+    URL generator.  Computed with the inverse normal CDF at the bin centres."""
+    import math
+    from statistics import NormalDist
+
+    nd = NormalDist()
+    out = []
+    for i in range(n):
+        z = nd.inv_cdf((i + 0.5) / n)
+        out.append(int(min(hi, max(lo, round(math.exp(mu + sigma * z))))))
+    return out
 
 
 def zipf_cdf(n: int, s: float) -> List[int]:
@@ -107,6 +120,32 @@ def c3(id_bits: int = 24) -> Workload:
         default_rows=100_000_000, default_partitions=100, bytes_per_row=8, bytes_per_group=16, dictionaries={})
 
 
+def _c4(name: str, grouped: bool) -> Workload:
+    schema = pa.schema([("URL", pa.string()), ("UserID", pa.int64())])
+    lens = url_length_table()
+    mean_len = sum(lens) / len(lens)
+    cols = lambda: [synth_col(0, abi.SYNTH_URL, (int(0.02 * 2 ** 32), int(0.01 * 2 ** 32)), lens),  # noqa: E731
+                    synth_col(1, abi.SYNTH_LOGUNIFORM_ID, (24, 0x5EED))]
+    if grouped:
+        q = QueryPlan([count_star()], keys=["UserID"], predicate=col("URL").like("%google%"))
+        sql = 'SELECT "UserID", COUNT(*) FROM hits WHERE "URL" LIKE \'%google%\' GROUP BY "UserID"'
+    else:
+        q = QueryPlan([count_star()], predicate=col("URL").like("%google%"))
+        sql = 'SELECT COUNT(*) FROM hits WHERE "URL" LIKE \'%google%\''
+    # offsets 4 B + mean string bytes per row (+ 8 B UserID for the selected rows only: not counted)
+    return Workload(name, sql, schema, cols, q, 1 if grouped else 0, seed=4, default_rows=100_000_000,
+                    default_partitions=100, bytes_per_row=4 + int(round(mean_len)), bytes_per_group=16 if grouped else 8,
+                    dictionaries={})
+
+
+def c4() -> Workload:
+    return _c4("C4", False)
+
+
+def c4g() -> Workload:
+    return _c4("C4G", True)
+
+
 def c5(n_services: int = 256, user_bits: int = 26) -> Workload:
     schema = pa.schema([("timestamp", pa.timestamp("ms")), ("service", pa.string()), ("user", pa.int64())])
     cdf = zipf_cdf(n_services, 1.1)
@@ -121,7 +160,7 @@ def c5(n_services: int = 256, user_bits: int = 26) -> Workload:
         dictionaries={"service": [f"svc-{i:03d}" for i in range(n_services)]})
 
 
-WORKLOADS = {"C1": c1, "C2": c2, "C3": c3, "C5": c5}
+WORKLOADS = {"C1": c1, "C2": c2, "C3": c3, "C4": c4, "C4G": c4g, "C5": c5}
 
 
 def partition_bounds(n_rows: int, n_parts: int, p: int):

@@ -203,3 +203,22 @@ def test_keys_wider_than_64_bits(gpu_ctx, oracle):
                 plan.close()
     finally:
         g.close()
+
+
+def test_c4_generated_urls_like_and_compaction_variant(gpu_ctx, oracle):
+    """C4 on device-generated URL-like strings (no dictionary: the raw-string kernels run),
+    a middle slice of a larger table with ragged partitions; plus near-miss patterns and
+    the GROUP BY variant that aggregates only the matching rows."""
+    wl = workloads.c4()
+    _both(gpu_ctx, oracle, wl, 300_007, 7, first=123_456, total=1_000_000, queries=[
+        (wl.query, 0),
+        (QueryPlan([count_star()], predicate=col("URL").like("%googl%")), 0),
+        (QueryPlan([count_star()], predicate=col("URL").like("%gogle%") | col("URL").like("%google%")), 0),
+        (QueryPlan([count_star()], predicate=~col("URL").like("%google%")), 0),
+        (QueryPlan([count_star()], predicate=col("URL").like("%g_ogle%")), 0),
+        (QueryPlan([count_star()], predicate=col("URL").like("a%")), 0),
+        # more occurrences than rows: the position list overflows and the per-segment search runs
+        (QueryPlan([count_star()], predicate=col("URL").like("%a%")), 0),
+        (QueryPlan([count_star()], predicate=col("URL").like("%/%") & ~col("URL").like("%google%")), 0),
+        (workloads.c4g().query, 1),
+    ])
