@@ -464,6 +464,56 @@ __device__ __forceinline__ void consume(const AggParams& p, const Lds<K32>& t, b
   }
 }
 
+// Ungrouped aggregates (no key columns) with few slots: there is one group, so every lane
+// keeps its own accumulators in registers and the LDS table is not touched at all; the
+// lanes' accumulators are combined once, when the workgroup is done.
+constexpr int kUngroupedSlots = 8;
+
+template <int NV, bool K32>
+__device__ __forceinline__ void consume_ungrouped(const AggParams& p, const PackedRows<0, NV, K32>& b,
+                                                  long long (&acc)[kUngroupedSlots]) {
+#pragma unroll
+  for (int s = 0; s < kUngroupedSlots; ++s) {
+    if (s >= p.n_slots) continue;
+    const int op = p.slots[s].op, val = p.slots[s].val;
+    if (op == kSlotAddOne) {
+#pragma unroll
+      for (int u = 0; u < kU; ++u) acc[s] += lane_bit(b.live[u]) ? 1 : 0;
+      continue;
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      if (v != val) continue;
+      const bool is_float = p.vals[v].is_float != 0;
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const bool ok = lane_bit(b.live[u] & b.vok[v][u]);
+        const long long x = b.val[v][u];
+        if (op == kSlotAddValid) acc[s] += ok ? 1 : 0;
+        else if (op == kSlotAddI64) acc[s] = (long long)((unsigned long long)acc[s] + (unsigned long long)(ok ? x : 0ll));
+        else if (op == kSlotMax) acc[s] = ok && x > acc[s] ? x : acc[s];
+        else if (op == kSlotMin) acc[s] = ok && x < acc[s] ? x : acc[s];
+        else acc[s] = __double_as_longlong(__longlong_as_double(acc[s]) + (ok ? (is_float ? __longlong_as_double(x) : (double)x) : 0.0));
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void finish_ungrouped(const AggParams& p, const long long (&acc)[kUngroupedSlots]) {
+#pragma unroll
+  for (int s = 0; s < kUngroupedSlots; ++s) {
+    if (s >= p.n_slots) continue;
+    const int op = p.slots[s].op;
+    long long v = acc[s];
+    if (op == kSlotMin) v = wave_min_i64(v);
+    else if (op == kSlotMax) v = wave_max_i64(v);
+    else if (op == kSlotAddF64) v = __double_as_longlong(wave_sum_f64(__longlong_as_double(v)));
+    else v = (long long)wave_sum_u64((unsigned long long)v);
+    if ((threadIdx.x & 63u) == 0 && v != slot_identity(op))
+      atomic_apply(&p.g_state[(uint64_t)s * (p.capacity + 1)], (op == kSlotAddOne || op == kSlotAddValid) ? kSlotAddI64 : op, v);
+  }
+}
+
 template <bool K32>
 __device__ __forceinline__ void lds_clear(const AggParams& p, const Lds<K32>& t) {
   for (int i = threadIdx.x; i < t.stride; i += blockDim.x) {
@@ -521,6 +571,22 @@ __global__ __launch_bounds__(kStreamBlock) void k_group_by_stream(AggParams p) {
   RowBatch<NK, NV, K32> raw;
   PackedRows<NK, NV, K32> rows;
   if (j0 < j1) issue<NK, NV, K32>(p, j0, wave, lane, cur, raw);
+  if constexpr (NK == 0) {
+    if (p.n_slots <= kUngroupedSlots) {
+      long long acc[kUngroupedSlots];
+#pragma unroll
+      for (int s = 0; s < kUngroupedSlots; ++s) acc[s] = s < p.n_slots ? slot_identity(p.slots[s].op) : 0;
+      for (uint64_t j = j0; j < j1; ++j) {
+        convert<NK, NV, K32>(p, raw, rows);
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + 1 < j1) issue<NK, NV, K32>(p, j + 1, wave, lane, cur, raw);
+        __builtin_amdgcn_sched_barrier(0);
+        consume_ungrouped<NV, K32>(p, rows, acc);
+      }
+      finish_ungrouped(p, acc);
+      return;
+    }
+  }
   for (uint64_t j = j0; j < j1; ++j) {
     convert<NK, NV, K32>(p, raw, rows);
     // The scheduling barriers keep the next step's loads from being hoisted above the
