@@ -31,6 +31,16 @@ __device__ __forceinline__ long long bucket_number(long long ts, const KeySpec& 
   return q;
 }
 
+// Probes before an insertion gives up and reports overflow: far beyond any chain of a
+// table at load <= 0.5, yet small enough that a pass over a table that turned out too
+// small (it is re-run with a larger one) does not crawl.
+constexpr uint64_t kMaxProbes = 512;
+
+// Set once an insertion failed: the pass will be re-run, so kernels stop early.
+__device__ __forceinline__ bool table_gave_up(const AggParams& p) {
+  return __hip_atomic_load(p.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+}
+
 template <int N>
 struct RowValsT {
   long long v[N > 0 ? N : 1];
@@ -70,7 +80,7 @@ __device__ __forceinline__ uint64_t global_entry_raw(int dense, uint64_t capacit
   if (key == kEmptyKey) return capacity;
   uint64_t mask = capacity - 1;
   uint64_t h = hash64(key) & mask;
-  const uint64_t max_probes = capacity < 4096 ? capacity : 4096;  // far beyond any chain at load <= 0.5
+  const uint64_t max_probes = capacity < kMaxProbes ? capacity : kMaxProbes;
   for (uint64_t probe = 0; probe < max_probes; ++probe) {
     unsigned long long k = g_keys[h];
     if (k == key) return h;
@@ -97,7 +107,7 @@ __device__ __forceinline__ uint64_t global_entry(const AggParams& p, uint64_t ke
 __device__ __forceinline__ uint64_t global_entry2(const AggParams& p, uint64_t lo, uint64_t hi) {
   const uint64_t mask = p.capacity - 1;
   uint64_t h = hash64(lo ^ hash64(hi)) & mask;
-  const uint64_t max_probes = p.capacity < 4096 ? p.capacity : 4096;
+  const uint64_t max_probes = p.capacity < kMaxProbes ? p.capacity : kMaxProbes;
   uint64_t probes = 0, result = ~0ull;
   bool done = false;
   while (!done) {

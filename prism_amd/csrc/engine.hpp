@@ -1,6 +1,7 @@
 // Host-side engine objects behind the opaque handles of prism_gpu.h.
 #pragma once
 
+#include <atomic>
 #include <cstdint>
 #include <memory>
 #include <mutex>
@@ -109,6 +110,9 @@ struct prism_gpu_plan {
   bool distinct_plan = false;
   int distinct_col = -1;
   std::vector<prism::FieldType> partial_fields, final_fields;
+  // capacity the GROUP BY hash table ended up with the last time this plan ran: the next
+  // run starts there instead of growing into it again (0: no run yet)
+  std::atomic<uint64_t> learned_capacity{0};
 };
 
 struct prism_gpu_part {

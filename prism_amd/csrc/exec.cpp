@@ -1080,6 +1080,10 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
                               : pow2_ceil(std::max<uint64_t>(1024, 2 * (plan->groups_hint ? std::min<uint64_t>(plan->groups_hint, bound)
                                                                                          : std::min<uint64_t>(bound, 1ull << 24))));
     const uint64_t max_capacity = pow2_ceil(std::max<uint64_t>(1024, 2 * bound));
+    if (!dense) {
+      const uint64_t learned = plan->learned_capacity.load(std::memory_order_relaxed);
+      if (learned > capacity) capacity = std::min(learned, max_capacity);
+    }
     for (;;) {
       {
         HostTimer ht(ctx, "host:table_alloc");
@@ -1094,8 +1098,9 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       launch_group_by(ctx, ap, (ap.row_mode == kRowsSelvec ? selected : ss.rows) * value_bytes);
       if (dense || !table_overflowed(ctx, gt)) break;
       if (capacity >= max_capacity) fail(PRISM_GPU_EINTERNAL, "group table overflow at maximum capacity");
-      capacity = std::min(max_capacity, capacity * 8);  // more groups than expected: grow and redo the pass
+      capacity = std::min(max_capacity, capacity * 4);  // more groups than expected: grow and redo the pass
     }
+    if (!dense) plan->learned_capacity.store(capacity, std::memory_order_relaxed);
     if (capture) {
       if (layout.words != 1) fail(PRISM_GPU_EUNSUPPORTED, "device-resident aggregate state needs a packed key of at most 64 bits");
       PRISM_HIP(hipStreamSynchronize(ctx->stream));

@@ -239,6 +239,7 @@ __global__ __launch_bounds__(kBlock) void k_group_by_wide(AggParams p) {
     return;
   }
   for (uint64_t tile = blockIdx.x; tile < p.sd.n_tiles; tile += gridDim.x) {
+    if (table_gave_up(p)) return;  // the table is too small: this pass will be re-run
     uint32_t seg = find_seg(p.sd, tile);
     uint64_t seg_rows = p.sd.segs[seg].rows;
     uint64_t tile_row0 = (tile - p.sd.segs[seg].tile_base) * kTileRows;

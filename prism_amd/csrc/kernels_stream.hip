@@ -596,6 +596,9 @@ __global__ __launch_bounds__(kStreamBlock) void k_group_by_stream(AggParams p) {
     if (j + 1 < j1) issue<NK, NV, K32>(p, j + 1, wave, lane, cur, raw);
     __builtin_amdgcn_sched_barrier(0);
     consume<NK, NV, K32>(p, t, insert, &n_entries, lane, rows);
+    // frozen table = nearly every row goes to the HBM table: if that one turned out too
+    // small the pass will be re-run with a larger one, so stop early
+    if (!insert && (j + 1) % kStepsPerTile == 0 && table_gave_up(p)) break;
     if (insert && (j + 1) % kStepsPerTile == 0) {
       // Block-wide bookkeeping at the end of a tile, when the LDS table is half full.
       // Keys that repeat a lot: fold the table into HBM and start over, with half as
