@@ -198,6 +198,12 @@ def main() -> int:
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
                         "kernel_avg_ms": avg_s * 1e3, "algorithmic_bytes_per_launch": alg}
+            try:  # the streaming-read rate a plain sum kernel reaches on this part (committed measurement)
+                ceil_gbs = json.load(open(os.path.join(ROOT, "profiles", "r1", "read_ceiling.json")))["read_GBps"]
+                roofline["measured_read_ceiling"] = ceil_gbs
+                roofline["frac_of_measured_ceiling"] = achieved / ceil_gbs
+            except (OSError, KeyError, ValueError):
+                pass
         ms_per_step = elapsed / args.steps * 1e3
         line = {
             "metric": "rows/sec scanned+aggregated (node)",
