@@ -169,42 +169,55 @@ def exchange_and_finish(plan, table, partitions, device, dst: int = 0):
     """One sharded GROUP BY query with the exchange done on device-resident group tables.
     Every rank aggregates its `partitions` of `table`; rank `dst` returns the final rows
     (pyarrow.Table), the others None.  Raises PrismGpuError(EUNSUPPORTED) for plans the state
-    interface does not cover; use all_gather_tables + Plan.merge for those."""
+    interface does not cover; use all_gather_tables + Plan.merge for those.
+
+    `device` is where the group tables live (a cuda device).  With the nccl backend (RCCL) the
+    collectives run on those HBM buffers; with gloo (tests: several ranks sharing one GPU)
+    the exported buffers are staged through host memory for the collective."""
     import torch
     import torch.distributed as dist
 
     from .engine import PrismGpuError
 
     rank = dist.get_rank()
+    on_device = dist.get_backend() == "nccl"
+    comm_device = device if on_device else torch.device("cpu")
     key_cols = [k.column if hasattr(k, "column") else k for k in plan.query.keys]
     digests = []
     for c in key_cols:
         if pa.types.is_string(plan.schema.field(c).type) or pa.types.is_binary(plan.schema.field(c).type):
             digests.append(table.dictionary_digest(c)[0])
-    stats, same_dicts = agree_on_stats(plan.scan_stats(table, partitions), digests, device)
+    stats, same_dicts = agree_on_stats(plan.scan_stats(table, partitions), digests, comm_device)
     if not same_dicts:
         raise PrismGpuError(-2, "string key columns have different dictionaries on different ranks")
     state = plan.aggregate(table, partitions, stats)
     try:
         info = state.describe()
         slot_merge = list(info.slot_merge[: info.n_slots])
-        buf = torch.empty(max(1, info.export_bytes // 8), dtype=torch.int64, device=device)
+        n_words = info.export_bytes // 8
+        buf = torch.empty(max(1, n_words), dtype=torch.int64, device=device)
         state.export_to(buf.data_ptr(), info.export_bytes)
+        comm = buf if on_device else buf.cpu()
         if info.dense:
-            reduce_dense_state(buf[: info.export_bytes // 8], slot_merge, info.entries, dst)
-            if buf.is_cuda:
-                torch.cuda.current_stream().synchronize()
+            reduce_dense_state(comm[:n_words], slot_merge, info.entries, dst)
             if rank != dst:
+                if on_device:
+                    torch.cuda.current_stream().synchronize()
                 return None
+            if not on_device:
+                buf.copy_(comm)
+            torch.cuda.current_stream().synchronize()  # the library reads buf on its own stream
             state.import_from(buf.data_ptr(), info.export_bytes)
             return state.finish()
-        parts = gather_rows(buf[: info.export_bytes // 8], info.entries, info.n_slots, dst)
-        if buf.is_cuda:
+        parts = gather_rows(comm[:n_words], info.entries, info.n_slots, dst)
+        if on_device:
             torch.cuda.current_stream().synchronize()
         if rank != dst:
             return None
         for r, (rows, n) in enumerate(parts):
             if r != dst and n:
+                rows = rows if on_device else rows.to(device)
+                torch.cuda.current_stream().synchronize()
                 state.merge_from(rows.data_ptr(), n)
         return state.finish()
     finally:
