@@ -784,29 +784,133 @@ int lds_slots_for(int n_slots) {
 
 
 // Reads the groups of a finished table and appends them to `cols`; with ORDER BY ...
-// LIMIT only the leading groups leave the device.  Returns the number of groups read.
+// LIMIT only the leading groups leave the device.  The columns are assembled on the device
+// (launch_emit_columns) and arrive through pinned memory as whole columns.  Returns the
+// number of groups read.
 uint64_t emit_groups(prism_gpu_ctx* ctx, const prism_gpu_plan* plan, const prism_gpu_table* table,
                      const std::vector<KeySrc>& keys, const KeyLayout& layout, const Lowered& low, const GroupTable& gt,
                      bool partial, std::vector<OutColumn>& cols) {
-  GroupRows g;
+  EmitColumns ec{};
+  ec.n_keys = (int)keys.size();
+  for (size_t i = 0; i < keys.size(); ++i) {
+    const KeyField& kf = layout.fields[i];
+    ec.keys[i] = {kf.word, kf.bit_pos, kf.bits, kf.null_bit, kf.bias, keys[i].date_bin ? 1 : 0, keys[i].stride, keys[i].origin};
+  }
+  auto add = [&](int kind, int main_slot, int count_slot) {
+    if (ec.n_aggs >= kMaxEmitAggs) fail(PRISM_GPU_EUNSUPPORTED, "too many aggregate output columns in one plan");
+    ec.aggs[ec.n_aggs++] = {kind, main_slot, count_slot};
+  };
+  for (const AggRule& r : low.rules) {
+    switch (r.func) {
+      case PRISM_AGG_COUNT_STAR:
+      case PRISM_AGG_COUNT: add(kEmitInt, r.main_slot, -1); break;
+      case PRISM_AGG_SUM:
+      case PRISM_AGG_MIN:
+      case PRISM_AGG_MAX: add(kEmitInt, r.main_slot, r.count_slot); break;
+      case PRISM_AGG_AVG:
+        if (partial) {
+          if (r.count_slot >= 0) add(kEmitInt, r.count_slot, -1); else add(kEmitOne, -1, -1);
+          add(kEmitF64, r.main_slot, r.count_slot);
+        } else {
+          add(kEmitAvg, r.main_slot, r.count_slot);
+        }
+        break;
+      default: fail(PRISM_GPU_EINTERNAL, "aggregate cannot be emitted");
+    }
+  }
+  const size_t n_cols = (size_t)ec.n_keys + (size_t)ec.n_aggs;
+  if (n_cols != cols.size()) fail(PRISM_GPU_EINTERNAL, "result columns do not match the output schema");
+
+  uint64_t n = 0;
+  const int64_t* h_vals = nullptr;
+  const uint8_t* h_valid = nullptr;
+  std::unique_lock<std::mutex> pinned_lock(ctx->result_mu, std::defer_lock);
   {
     HostTimer ht(ctx, "host:read_groups");
     TopKOrder order;
+    Scratch d_topk;
+    const TopKOrder* use_order = nullptr;
     const uint64_t entries = gt.dense ? gt.capacity : gt.capacity + 1;
     if (!partial && entries >= kTopKMinEntries && topk_order(plan, table, keys, layout, low, cols, order)) {
-      Scratch d_topk(ctx, sizeof(TopKState));
+      d_topk = Scratch(ctx, sizeof(TopKState));
       launch_topk_threshold(ctx, gt.dense, gt.capacity, gt.keys.as<uint64_t>(), gt.keys_hi.as<uint64_t>(),
-                            gt.state.as<int64_t>(), order, (uint64_t)std::max<int64_t>(1, plan->limit),
-                            d_topk.as<TopKState>());
-      g = table_read(ctx, gt, &order, d_topk.as<TopKState>());
+                            gt.state.as<int64_t>(), order, (uint64_t)std::max<int64_t>(1, plan->limit), d_topk.as<TopKState>());
+      use_order = &order;
+    }
+    auto emit = [&](int64_t* vals, uint8_t* valid, uint64_t stride, unsigned long long* count) {
+      PRISM_HIP(hipMemsetAsync(count, 0, 8, ctx->stream));
+      launch_emit_columns(ctx, gt.dense, gt.capacity, gt.keys.as<uint64_t>(), gt.keys_hi.as<uint64_t>(), gt.state.as<int64_t>(),
+                          ec, vals, valid, stride, count, use_order, d_topk.as<TopKState>());
+    };
+    Scratch d_count(ctx, 256), d_vals, d_valid;
+    unsigned long long count = 0;
+    uint64_t stride = 0;
+    // A table with few entries is compacted in one pass into buffers sized for all of them;
+    // a large one is counted first.
+    if (!use_order && entries * n_cols * 9 <= (48ull << 20)) {
+      stride = entries;
+      d_vals = Scratch(ctx, stride * n_cols * 8);
+      d_valid = Scratch(ctx, stride * n_cols);
+      emit(d_vals.as<int64_t>(), d_valid.as<uint8_t>(), stride, d_count.as<unsigned long long>());
+      PRISM_HIP(hipMemcpyAsync(&count, d_count.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+      PRISM_HIP(hipStreamSynchronize(ctx->stream));
     } else {
-      g = table_read(ctx, gt);
+      emit(nullptr, nullptr, 0, d_count.as<unsigned long long>());
+      PRISM_HIP(hipMemcpyAsync(&count, d_count.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+      PRISM_HIP(hipStreamSynchronize(ctx->stream));
+      if (count) {
+        stride = count;
+        d_vals = Scratch(ctx, stride * n_cols * 8);
+        d_valid = Scratch(ctx, stride * n_cols);
+        emit(d_vals.as<int64_t>(), d_valid.as<uint8_t>(), stride, d_count.as<unsigned long long>());
+      }
+    }
+    n = count;
+    if (n) {
+      // HBM -> pinned host memory, compacted to n entries per column on the way
+      pinned_lock.lock();
+      const size_t need = (size_t)n * n_cols * 9;
+      if (ctx->result_pinned_bytes < need) {
+        if (ctx->result_pinned) (void)hipHostFree(ctx->result_pinned);
+        ctx->result_pinned = nullptr;
+        ctx->result_pinned_bytes = 0;
+        const size_t want = pow2_ceil(need);
+        PRISM_HIP(hipHostMalloc(&ctx->result_pinned, want, hipHostMallocDefault));
+        ctx->result_pinned_bytes = want;
+      }
+      uint8_t* pin = (uint8_t*)ctx->result_pinned;
+      PRISM_HIP(hipMemcpy2DAsync(pin, n * 8, d_vals.p, stride * 8, n * 8, n_cols, hipMemcpyDeviceToHost, ctx->stream));
+      PRISM_HIP(hipMemcpy2DAsync(pin + (size_t)n * n_cols * 8, n, d_valid.p, stride, n, n_cols, hipMemcpyDeviceToHost, ctx->stream));
+      PRISM_HIP(hipStreamSynchronize(ctx->stream));
+      h_vals = (const int64_t*)pin;
+      h_valid = pin + (size_t)n * n_cols * 8;
     }
   }
   HostTimer ht(ctx, "host:assemble");
-  append_key_columns(table, keys, layout, 0, g, cols, 0);
-  append_agg_columns(low, g, partial, cols, keys.size());
-  return g.n;
+  for (size_t c = 0; c < n_cols && n; ++c) {
+    OutColumn& oc = cols[c];
+    const int64_t* v = h_vals + c * n;
+    const uint8_t* ok = h_valid + c * n;
+    oc.valid.insert(oc.valid.end(), ok, ok + n);
+    if (c < keys.size() && table->fields[keys[c].column].is_string) {
+      const ColumnDict& d = table->dicts[keys[c].column];
+      if (oc.codes.empty()) oc.dict = &d.values;
+      if (oc.dict != &d.values) fail(PRISM_GPU_EINTERNAL, "string key column built from two dictionaries");
+      const size_t base = oc.codes.size();
+      oc.codes.resize(base + n);
+      const uint64_t n_values = d.values.size();
+      for (size_t r = 0; r < n; ++r) {
+        if (ok[r] && (uint64_t)v[r] >= n_values) fail(PRISM_GPU_EINTERNAL, "dictionary code out of range in result");
+        oc.codes[base + r] = (uint32_t)v[r];
+      }
+    } else if (oc.type.is_float) {
+      const double* f = (const double*)v;
+      oc.f64.insert(oc.f64.end(), f, f + n);
+    } else {
+      oc.i64.insert(oc.i64.end(), v, v + n);
+    }
+  }
+  return n;
 }
 
 }  // namespace

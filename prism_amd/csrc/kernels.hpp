@@ -226,6 +226,38 @@ void launch_topk_threshold(prism_gpu_ctx* ctx, bool dense, uint64_t capacity, co
                            const uint64_t* g_keys_hi, const int64_t* g_state, const TopKOrder& order, uint64_t k,
                            TopKState* d_state);
 
+// Result columns assembled on the device: the occupied entries of a table are compacted
+// straight into the values the result batch holds (keys unpacked from the packed key,
+// date_bin buckets turned back into timestamps, AVG divided, NULL flags worked out), so
+// the host copies columns instead of decoding rows.
+struct EmitKey {
+  int word, bit_pos, bits, null_bit;
+  long long bias;
+  int date_bin;
+  long long stride, origin;
+};
+enum EmitAggKind {
+  kEmitInt = 0,  // the main slot; NULL when a count slot is given and it is 0
+  kEmitAvg = 1,  // Float64: main slot (a double) / count slot; NULL when the count is 0
+  kEmitF64 = 2,  // Float64: main slot as is; NULL (0.0) when the count is 0
+  kEmitOne = 3   // constant 1
+};
+struct EmitAgg {
+  int kind, main_slot, count_slot;
+};
+constexpr int kMaxEmitAggs = 32;
+struct EmitColumns {
+  int n_keys;
+  EmitKey keys[kMaxKeys];
+  int n_aggs;
+  EmitAgg aggs[kMaxEmitAggs];
+};
+// out_values: [n_keys + n_aggs][stride] 8-byte values, out_valid: the same shape in bytes
+// (1 = not NULL).  out_values == nullptr: count only.  order / d_threshold as launch_emit.
+void launch_emit_columns(prism_gpu_ctx* ctx, bool dense, uint64_t capacity, const uint64_t* g_keys, const uint64_t* g_keys_hi,
+                         const int64_t* g_state, const EmitColumns& cols, int64_t* out_values, uint8_t* out_valid,
+                         uint64_t stride, unsigned long long* out_count, const TopKOrder* order, TopKState* d_threshold);
+
 // Merges groups exported from another table (packed keys + slot-major accumulators with
 // stride `n`) into a table: find-or-insert the key, then apply every accumulator with the
 // slot's merge rule (all "add" rules add, min and max stay min and max).

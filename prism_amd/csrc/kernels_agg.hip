@@ -539,6 +539,79 @@ __global__ __launch_bounds__(kBlock) void k_emit(int dense, uint64_t capacity, c
   }
 }
 
+__global__ __launch_bounds__(kBlock) void k_emit_columns(int dense, uint64_t capacity, const uint64_t* g_keys,
+                                                        const uint64_t* g_keys_hi, const long long* g_state,
+                                                        EmitColumns cols, long long* out_values, uint8_t* out_valid,
+                                                        uint64_t stride, unsigned long long* out_count, int filtered,
+                                                        TopKOrder order, TopKState* threshold) {
+  const uint64_t n = dense ? capacity : capacity + 1;
+  const uint64_t min_rank = filtered ? threshold->prefix : 0ull;
+  const bool exact = filtered && threshold->exact != 0;
+  const uint64_t ties_wanted = filtered ? threshold->k_rem : 0ull;
+  const int lane = threadIdx.x & 63;
+  for (uint64_t base = (uint64_t)blockIdx.x * kBlock; base < n; base += (uint64_t)gridDim.x * kBlock) {
+    const uint64_t i = base + threadIdx.x;
+    bool take = i < n && occupied(dense != 0, capacity, g_keys, g_state, i);
+    if (take && filtered) {
+      const uint64_t rank = topk_rank(order, dense != 0, capacity, g_keys, g_keys_hi, g_state, i);
+      take = rank >= min_rank;
+      bool tie = exact && rank == min_rank;
+      if (tie && __hip_atomic_load(&threshold->ties_taken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= ties_wanted) {
+        tie = false;
+        take = false;
+      }
+      const uint64_t tm = __ballot(tie);
+      if (tm) {
+        unsigned long long first_tie = 0;
+        if (lane == __ffsll((long long)tm) - 1) first_tie = atomicAdd(&threshold->ties_taken, (unsigned long long)__popcll(tm));
+        first_tie = __shfl(first_tie, __ffsll((long long)tm) - 1);
+        if (tie) take = first_tie + __popcll(tm & ((1ull << lane) - 1)) < ties_wanted;
+      }
+    }
+    const uint64_t m = __ballot(take);
+    if (m == 0) continue;
+    unsigned long long first = 0;
+    if (lane == __ffsll((long long)m) - 1) first = atomicAdd(out_count, (unsigned long long)__popcll(m));
+    first = __shfl(first, __ffsll((long long)m) - 1);
+    if (!take || out_values == nullptr) continue;
+    const unsigned long long pos = first + __popcll(m & ((1ull << lane) - 1));
+    if (pos >= stride) continue;  // cannot happen when stride >= occupied entries; never write outside
+    const uint64_t key_lo = dense ? i : (i == capacity ? kEmptyKey : g_keys[i]);
+    const uint64_t key_hi = g_keys_hi ? (i == capacity ? 0ull : g_keys_hi[i]) : 0ull;
+    int c = 0;
+    for (int k = 0; k < cols.n_keys; ++k, ++c) {
+      const EmitKey& ek = cols.keys[k];
+      const uint64_t packed = ek.word ? key_hi : key_lo;
+      const bool valid = ek.null_bit < 0 || ((packed >> ek.null_bit) & 1ull) == 0;
+      const uint64_t mask = ek.bits == 0 ? 0ull : (~0ull >> (64 - ek.bits));
+      long long v = (long long)((uint64_t)ek.bias + ((packed >> ek.bit_pos) & mask));
+      if (ek.date_bin) v = (long long)((uint64_t)ek.origin + (uint64_t)v * (uint64_t)ek.stride);
+      out_values[(uint64_t)c * stride + pos] = valid ? v : 0;
+      out_valid[(uint64_t)c * stride + pos] = valid ? 1 : 0;
+    }
+    for (int a = 0; a < cols.n_aggs; ++a, ++c) {
+      const EmitAgg& ea = cols.aggs[a];
+      const long long main = ea.main_slot >= 0 ? g_state[(uint64_t)ea.main_slot * (capacity + 1) + i] : 1;
+      const long long cnt = ea.count_slot >= 0 ? g_state[(uint64_t)ea.count_slot * (capacity + 1) + i] : 1;
+      long long v = main;
+      bool valid = true;
+      if (ea.kind == kEmitInt) {
+        valid = cnt > 0;
+      } else if (ea.kind == kEmitAvg) {
+        valid = cnt > 0;
+        v = __double_as_longlong(valid ? __longlong_as_double(main) / (double)cnt : 0.0);
+      } else if (ea.kind == kEmitF64) {
+        valid = cnt > 0;
+        v = valid ? main : 0;
+      } else {
+        v = 1;
+      }
+      out_values[(uint64_t)c * stride + pos] = v;
+      out_valid[(uint64_t)c * stride + pos] = valid ? 1 : 0;
+    }
+  }
+}
+
 uint32_t stream_grid(prism_gpu_ctx* ctx, uint64_t items) {
   uint64_t blocks = ceil_div(items, kBlock);
   uint64_t cap = (uint64_t)ctx->n_cus * 8;
@@ -625,6 +698,22 @@ void launch_emit(prism_gpu_ctx* ctx, bool dense, uint64_t capacity, const uint64
                                                                     (const long long*)g_state, n_slots, out_keys,
                                                                     out_keys_hi, (long long*)out_state, out_stride,
                                                                     out_count, order ? 1 : 0, o, d_threshold);
+  PRISM_HIP(hipGetLastError());
+}
+
+void launch_emit_columns(prism_gpu_ctx* ctx, bool dense, uint64_t capacity, const uint64_t* g_keys, const uint64_t* g_keys_hi,
+                         const int64_t* g_state, const EmitColumns& cols, int64_t* out_values, uint8_t* out_valid,
+                         uint64_t stride, unsigned long long* out_count, const TopKOrder* order, TopKState* d_threshold) {
+  uint64_t n = dense ? capacity : capacity + 1;
+  if (n == 0) return;
+  TopKOrder o{};
+  if (order) {
+    o = *order;
+    PRISM_HIP(hipMemsetAsync(&d_threshold->ties_taken, 0, sizeof(d_threshold->ties_taken), ctx->stream));
+  }
+  k_emit_columns<<<dim3(stream_grid(ctx, n)), dim3(kBlock), 0, ctx->stream>>>(
+      dense ? 1 : 0, capacity, g_keys, g_keys_hi, (const long long*)g_state, cols, (long long*)out_values, out_valid, stride,
+      out_count, order ? 1 : 0, o, d_threshold);
   PRISM_HIP(hipGetLastError());
 }
 
