@@ -222,3 +222,93 @@ def test_c4_generated_urls_like_and_compaction_variant(gpu_ctx, oracle):
         (QueryPlan([count_star()], predicate=col("URL").like("%/%") & ~col("URL").like("%google%")), 0),
         (workloads.c4g().query, 1),
     ])
+
+
+def test_full_size_c2_invariants(gpu_ctx):
+    """The headline configuration at its full size (10^9 rows, 64 partitions), checked through
+    properties that need no oracle: every row lands in exactly one group; the grouped sums and
+    maxima fold to the ungrouped ones; PARTIAL states of two halves merge to the same rows as
+    one pass; a filter and its complement split the rows."""
+    from prism_amd.engine import Plan
+
+    wl = workloads.c2()
+    rows, parts = 1_000_000_000, 64
+    table = workloads.build_gpu_table(gpu_ctx, wl, 0, rows, rows, parts)
+    try:
+        def run(q, partitions=None, mode=None):
+            plan = Plan(gpu_ctx, wl.schema, q if mode is None else q.with_mode(mode))
+            try:
+                return plan.execute(table, partitions)
+            finally:
+                plan.close()
+
+        full = run(wl.query)
+        counts = np.array(full.column("COUNT(*)").to_pylist(), dtype=np.int64)
+        sums = np.array(full.column("SUM(value)").to_pylist(), dtype=np.int64)
+        maxs = np.array(full.column("MAX(value)").to_pylist(), dtype=np.int64)
+        assert counts.sum() == rows and (counts > 0).all()
+        assert full.num_rows <= 1440 * 64 + 64
+        flat = run(QueryPlan([count_star(), sum_("value"), max_("value"), min_("value")]))
+        assert flat.column(0).to_pylist() == [rows]
+        assert flat.column(1).to_pylist() == [int(sums.sum())]
+        assert flat.column(2).to_pylist() == [int(maxs.max())]
+        assert 0 <= flat.column(3).to_pylist()[0] <= 5
+        # two halves -> PARTIAL -> merge == one pass (order-insensitive, bit exact)
+        plan = Plan(gpu_ctx, wl.schema, wl.query.with_mode(abi.MODE_PARTIAL))
+        try:
+            merged = plan.merge([plan.execute(table, range(0, 32)), plan.execute(table, range(32, 64))])
+        finally:
+            plan.close()
+        assert_tables_match(merged, full, 2)
+        # a predicate and its complement
+        a = run(QueryPlan([count_star()], predicate=col("value") >= 12_345)).column(0).to_pylist()[0]
+        b = run(QueryPlan([count_star()], predicate=col("value") < 12_345)).column(0).to_pylist()[0]
+        assert a + b == rows and abs(a / rows - (1 - 12_345 / 50_000)) < 1e-3
+    finally:
+        table.close()
+
+
+def test_full_size_c1_and_c3_invariants(gpu_ctx):
+    """C1 and C3 at their full sizes (10^8 rows): complementary filters split the rows; the
+    top-10 of the high-cardinality GROUP BY does not depend on how the partitions are cut,
+    and its counts are bounded by what the unlimited result holds."""
+    from prism_amd.engine import Plan
+
+    wl = workloads.c1()
+    rows = 100_000_000
+    table = workloads.build_gpu_table(gpu_ctx, wl, 0, rows, rows, 10)
+    try:
+        got = {}
+        for name, pred in [("ne", col("AdvEngineID") != 0), ("eq", col("AdvEngineID") == 0), ("gt", col("AdvEngineID") > 0)]:
+            plan = Plan(gpu_ctx, wl.schema, QueryPlan([count_star()], predicate=pred))
+            try:
+                got[name] = plan.execute(table).column(0).to_pylist()[0]
+            finally:
+                plan.close()
+        assert got["ne"] + got["eq"] == rows and got["ne"] == got["gt"]
+        assert abs(got["ne"] / rows - 0.0063) < 2e-4
+    finally:
+        table.close()
+
+    wl = workloads.c3()
+    tops = []
+    for parts in (100, 7):
+        table = workloads.build_gpu_table(gpu_ctx, wl, 0, rows, rows, parts)
+        try:
+            plan = Plan(gpu_ctx, wl.schema, wl.query)
+            try:
+                tops.append(plan.execute(table))
+            finally:
+                plan.close()
+            if parts == 7:
+                plan = Plan(gpu_ctx, wl.schema, QueryPlan([count_star()], keys=["UserID"], order_by=1, descending=True, limit=1000))
+                try:
+                    top1000 = plan.execute(table)
+                finally:
+                    plan.close()
+        finally:
+            table.close()
+    assert tops[0].column(1).to_pylist() == tops[1].column(1).to_pylist()
+    assert tops[0].column(1).to_pylist() == top1000.column(1).to_pylist()[:10]
+    c = top1000.column(1).to_pylist()
+    assert c == sorted(c, reverse=True) and len(set(top1000.column(0).to_pylist())) == 1000
