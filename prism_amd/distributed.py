@@ -165,6 +165,9 @@ def gather_rows(buf, n_groups: int, n_slots: int, dst: int = 0):
     return [(parts[r][: counts[r] * (1 + n_slots)].contiguous(), counts[r]) for r in range(world)]
 
 
+_AGREED_STATS: dict = {}
+
+
 def exchange_and_finish(plan, table, partitions, device, dst: int = 0):
     """One sharded GROUP BY query with the exchange done on device-resident group tables.
     Every rank aggregates its `partitions` of `table`; rank `dst` returns the final rows
@@ -187,9 +190,20 @@ def exchange_and_finish(plan, table, partitions, device, dst: int = 0):
     for c in key_cols:
         if pa.types.is_string(plan.schema.field(c).type) or pa.types.is_binary(plan.schema.field(c).type):
             digests.append(table.dictionary_digest(c)[0])
-    stats, same_dicts = agree_on_stats(plan.scan_stats(table, partitions), digests, comm_device)
-    if not same_dicts:
-        raise PrismGpuError(-2, "string key columns have different dictionaries on different ranks")
+    # The agreed statistics are metadata of (table contents, partitions): like a catalogue's
+    # column statistics they are exchanged once and reused until the table changes (every rank
+    # sees the same sequence of calls, so every rank takes the same branch here).
+    cache_key = (id(plan), id(table), table.num_rows, None if partitions is None else tuple(partitions), tuple(digests))
+    cached = _AGREED_STATS.get(cache_key)
+    if cached is None:
+        stats, same_dicts = agree_on_stats(plan.scan_stats(table, partitions), digests, comm_device)
+        if not same_dicts:
+            raise PrismGpuError(-2, "string key columns have different dictionaries on different ranks")
+        if len(_AGREED_STATS) > 64:
+            _AGREED_STATS.clear()
+        _AGREED_STATS[cache_key] = stats
+    else:
+        stats = cached
     state = plan.aggregate(table, partitions, stats)
     try:
         info = state.describe()
