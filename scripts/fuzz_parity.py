@@ -25,6 +25,9 @@ RANGES = {"value": (-50_000, 50_000), "i16": (0, 5), "i32": (-1000, 1000), "u16"
           "ts": (1_700_000_000_000, 1_700_000_000_000 + 3 * 3600 * 1000)}
 
 
+SCHEMA = helpers.random_table(100, seed=0).schema
+
+
 def rand_leaf(rng, t):
     kind = rng.integers(0, 10)
     if kind < 5:
@@ -119,7 +122,7 @@ def main():
         seed = seed0 * 100_000 + it
         rng = np.random.default_rng(seed)
         n = int(rng.choice([1, 63, 64, 65, 4095, 4096, 4097, 10_000, 40_000, 120_000]))
-        t = helpers.random_table(n, seed=seed, nulls=bool(rng.random() < 0.8))
+        t = helpers.random_table(n, seed=seed, nulls=bool(rng.random() < 0.8)).cast(SCHEMA)  # (an all-NULL column would be typed null)
         parts = int(rng.integers(1, 6))
         g = Table(ctx, t.schema)
         try:

@@ -312,3 +312,28 @@ def test_full_size_c1_and_c3_invariants(gpu_ctx):
     assert tops[0].column(1).to_pylist() == top1000.column(1).to_pylist()[:10]
     c = top1000.column(1).to_pylist()
     assert c == sorted(c, reverse=True) and len(set(top1000.column(0).to_pylist())) == 1000
+
+
+def test_hash_table_growth_and_frozen_lds_at_scale(gpu_ctx, oracle):
+    """Hundreds of thousands of groups with a far too small groups_hint: the HBM hash table overflows and
+    is regrown several times (each failed pass aborts early), the LDS tables freeze, and the
+    result still matches the oracle exactly; then the same plan again (the learned capacity)."""
+    from prism_amd.engine import Plan
+
+    wl = workloads.c3(id_bits=22)
+    rows = 4_000_000
+    table = workloads.build_gpu_table(gpu_ctx, wl, 0, rows, rows, 5)
+    st = oracle.SynthTable(wl.schema, wl.make_cols(), wl.seed, 0, rows, rows, n_parts=5)
+    try:
+        q = QueryPlan([count_star(), max_("UserID")], keys=["UserID"], groups_hint=500)
+        want, _ = st.execute(q)
+        assert want.num_rows > 500_000
+        plan = Plan(gpu_ctx, wl.schema, q)
+        try:
+            for _ in range(2):
+                assert_tables_match(plan.execute(table), want, 1)
+        finally:
+            plan.close()
+    finally:
+        st.close()
+        table.close()
