@@ -165,6 +165,48 @@ def gather_rows(buf, n_groups: int, n_slots: int, dst: int = 0):
     return [(parts[r][: counts[r] * (1 + n_slots)].contiguous(), counts[r]) for r in range(world)]
 
 
+def exchange_rows_all_to_all(buf, n_groups: int, n_slots: int):
+    """Exported hash-table rows ([n] packed keys then [n_slots][n] accumulators, int64) are
+    dealt to their owner ranks (hash(key) mod world) with one all-to-all; returns the rows this
+    rank owns, in the same column-major layout."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size()
+    width = 1 + n_slots
+    rows = buf.view(width, n_groups).t().contiguous() if n_groups else buf.new_empty((0, width))
+    # multiplicative hash of the packed key; the HBM tables use another one, so a rank's slice
+    # still spreads over its whole table
+    h = (rows[:, 0] * -7046029254386353131) >> 40 if n_groups else rows[:, 0]
+    owner = torch.remainder(h, world)
+    order = torch.argsort(owner, stable=True)
+    send = rows.index_select(0, order).contiguous()
+    send_counts = torch.bincount(owner, minlength=world).to(torch.int64)
+    recv_counts = torch.empty_like(send_counts)
+    dist.all_to_all_single(recv_counts, send_counts)
+    send_list = [int(x) for x in send_counts.tolist()]
+    recv_list = [int(x) for x in recv_counts.tolist()]
+    recv = send.new_empty((sum(recv_list), width))
+    dist.all_to_all_single(recv, send, output_split_sizes=recv_list, input_split_sizes=send_list)
+    return recv.t().contiguous().view(-1)
+
+
+def _concat_sort_limit(parts, query):
+    """Final rows of disjoint key slices -> one table, with the plan's ORDER BY / LIMIT applied
+    (NULLS FIRST when descending, NULLS LAST when ascending)."""
+    import pyarrow.compute as pc
+
+    out = pa.concat_tables([p for p in parts if p is not None])
+    if query.order_by is not None:
+        name = out.schema.names[query.order_by]
+        idx = pc.sort_indices(out, sort_keys=[(name, "descending" if query.descending else "ascending")],
+                              null_placement="at_start" if query.descending else "at_end")
+        out = out.take(idx)
+    if query.limit is not None:
+        out = out.slice(0, query.limit)
+    return out.combine_chunks()
+
+
 _AGREED_STATS: dict = {}
 
 
@@ -223,16 +265,25 @@ def exchange_and_finish(plan, table, partitions, device, dst: int = 0):
             torch.cuda.current_stream().synchronize()  # the library reads buf on its own stream
             state.import_from(buf.data_ptr(), info.export_bytes)
             return state.finish()
-        parts = gather_rows(comm[:n_words], info.entries, info.n_slots, dst)
-        if on_device:
-            torch.cuda.current_stream().synchronize()
+        if dist.get_world_size() == 1:
+            return state.finish()
+        # Large key space: hash-partitioned all-to-all.  Rank r becomes the owner of the keys
+        # with hash(key) mod world == r, receives every other rank's rows for them, merges
+        # them into an (initially empty) table of its own and finishes its slice; the slices
+        # (already cut to LIMIT rows each) meet on rank `dst`.
+        owned = plan.aggregate(table, [0xFFFFFFFF], stats)  # no such partition: an empty state, same key packing
+        try:
+            mine = exchange_rows_all_to_all(comm[:n_words], info.entries, info.n_slots)
+            if mine.numel():
+                rows = mine if on_device else mine.to(device)
+                torch.cuda.current_stream().synchronize()
+                owned.merge_from(rows.data_ptr(), rows.numel() // (1 + info.n_slots))
+            part = owned.finish()
+        finally:
+            owned.close()
+        parts = all_gather_tables(part, comm_device)
         if rank != dst:
             return None
-        for r, (rows, n) in enumerate(parts):
-            if r != dst and n:
-                rows = rows if on_device else rows.to(device)
-                torch.cuda.current_stream().synchronize()
-                state.merge_from(rows.data_ptr(), n)
-        return state.finish()
+        return _concat_sort_limit(parts, plan.query)
     finally:
         state.close()

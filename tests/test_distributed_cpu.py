@@ -114,8 +114,17 @@ def _collective_worker(rank: int, world: int, port: int, q):
         n = rank + 1
         rows = torch.cat([torch.arange(n) + 100 * rank, torch.full((n,), rank), torch.full((n,), -rank)]).to(torch.int64)
         parts = gather_rows(rows, n, 2, dst=0)
+        # all-to-all by key hash: every key must arrive at exactly one rank, with its slots
+        from prism_amd.distributed import exchange_rows_all_to_all
+
+        keys = torch.arange(50, dtype=torch.int64) * 1_000_003 + rank  # 50 keys per rank, disjoint
+        cols = torch.cat([keys, keys * 2, keys * 3])
+        got = exchange_rows_all_to_all(cols, 50, 2)
+        m = got.numel() // 3
+        gk, g1, g2 = got[:m], got[m:2 * m], got[2 * m:]
+        a2a_ok = bool((g1 == gk * 2).all() and (g2 == gk * 3).all())
         q.put((rank, stats.tolist(), same, differ, buf.tolist() if rank == 0 else None,
-               [(p.tolist(), k) for p, k in parts] if parts is not None else None))
+               [(p.tolist(), k) for p, k in parts] if parts is not None else None, gk.tolist(), a2a_ok))
     finally:
         dist.destroy_process_group()
 
@@ -151,3 +160,9 @@ def test_state_exchange_collectives_two_ranks():
     assert out[1][4] is None
     assert parts[0] == ([0, 0, 0], 1)
     assert parts[1] == ([100, 101, 1, 1, -1, -1], 2)
+    # all-to-all: the two ranks' slices are disjoint, cover all 100 keys, and rows stayed intact
+    k0, k1 = out[0][5], out[1][5]
+    assert out[0][6] and out[1][6]
+    assert not set(k0) & set(k1)
+    assert sorted(k0 + k1) == sorted([i * 1_000_003 + r for i in range(50) for r in (0, 1)])
+    assert len(k0) > 10 and len(k1) > 10

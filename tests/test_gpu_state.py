@@ -225,11 +225,15 @@ def _two_rank_worker(rank: int, world: int, port: int, q):
     ctx = Context(0)
     try:
         dev = torch.device("cuda", 0)
-        cases = [(workloads.c2(), 400_000, 2), (workloads.c3(id_bits=16), 300_000, 1)]
-        for wl, rows, n_keys in cases:
+        from prism_amd.plan import QueryPlan as Q, avg as avg_, count_star as cs, max_ as mx
+
+        c3 = workloads.c3(id_bits=16)
+        cases = [(workloads.c2(), workloads.c2().query, 400_000, 2), (c3, c3.query, 300_000, 1),
+                 (c3, Q([cs(), mx("UserID"), avg_("UserID")], keys=["UserID"]), 300_000, 1)]
+        for wl, query, rows, n_keys in cases:
             total = rows * world
             table = workloads.build_gpu_table(ctx, wl, rows * rank, rows, total, 4)
-            plan = Plan(ctx, wl.schema, wl.query)
+            plan = Plan(ctx, wl.schema, query)
             try:
                 got = exchange_and_finish(plan, table, None, dev)
             finally:
@@ -238,12 +242,12 @@ def _two_rank_worker(rank: int, world: int, port: int, q):
             if rank == 0:
                 st = pyoracle.SynthTable(wl.schema, wl.make_cols(), wl.seed, 0, total, total, n_parts=4)
                 try:
-                    want, _ = st.execute(wl.query)
+                    want, _ = st.execute(query)
                 finally:
                     st.close()
                 want = workloads.decode_dictionary_columns(wl, want)
-                if wl.query.limit is not None:
-                    assert_topk_match(got, want, wl.query.order_by)
+                if query.limit is not None:
+                    assert_topk_match(got, want, query.order_by)
                 else:
                     assert_tables_match(got, want, n_keys)
             else:
