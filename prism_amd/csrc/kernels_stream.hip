@@ -89,6 +89,13 @@ struct Lds {
   // a few groups are hot.  Replicas of a group are merged when the table is flushed.
   int replicas;
   uint32_t salt;
+  // Small key spaces (every packed key times a few replicas fits the table) skip hashing
+  // altogether: replica r = lane mod 2^direct_rep_log2 of key k lives at entry
+  // (r << key_bits) | ((k + 5 r) mod 2^key_bits).  The rotation by 5 r puts the replicas of
+  // one key, and different keys of one replica, in different LDS banks (an entry's bank is
+  // given by its low index bits).  -1: hashed.
+  int direct_rep_log2;
+  int direct_key_bits;
 };
 
 // K32 plans only ever use the low 32 bits of a key value, so they load only those: a
@@ -381,6 +388,15 @@ template <int NK, int NV, bool K32>
 __device__ __forceinline__ void consume(const AggParams& p, const Lds<K32>& t, bool insert, int* n_entries, uint32_t lane,
                                         const PackedRows<NK, NV, K32>& b) {
   const KeyT<K32> empty = (KeyT<K32>)~(KeyT<K32>)0;
+  int e[kU];
+  bool miss = false;
+  if (t.direct_rep_log2 >= 0) {
+    // directly indexed: no look-up at all
+    const uint32_t rep = lane & ((1u << t.direct_rep_log2) - 1u);
+    const uint32_t kmask = (1u << t.direct_key_bits) - 1u, base = rep << t.direct_key_bits, rot = rep * 5u;
+#pragma unroll
+    for (int u = 0; u < kU; ++u) e[u] = (int)(base | (((uint32_t)b.key[u] + rot) & kmask));
+  } else {
   // 1. the four candidate keys of every row's bucket (independent reads, issued together)
   int first[kU];
   uint32_t hash[kU];
@@ -398,8 +414,6 @@ __device__ __forceinline__ void consume(const AggParams& p, const Lds<K32>& t, b
     }
   }
   // 2. the matching way, or -1
-  int e[kU];
-  bool miss = false;
 #pragma unroll
   for (int u = 0; u < kU; ++u) {
     int way = -1;
@@ -418,6 +432,7 @@ __device__ __forceinline__ void consume(const AggParams& p, const Lds<K32>& t, b
       if (lane_bit(b.live[u]) && e[u] < 0 && (K32 || b.key[u] != empty))
         e[u] = lds_insert<K32>(t.keys, first[u], t.S - 1, b.key[u], n_entries, insert);
     }
+  }
   }
   // 3. byte offset of the entry to update: the row's, or the lane's scratch entry
   uint32_t off[kU];
@@ -528,8 +543,16 @@ template <bool K32>
 __device__ __forceinline__ void lds_flush(const AggParams& p, const Lds<K32>& t) {
   const KeyT<K32> empty = (KeyT<K32>)~(KeyT<K32>)0;
   for (int i = threadIdx.x; i < t.S; i += blockDim.x) {
-    KeyT<K32> key = t.keys[i];
-    if (key == empty) continue;
+    KeyT<K32> key;
+    if (t.direct_rep_log2 >= 0) {
+      if (t.state[i] == 0) continue;  // slot 0 counts the rows of the entry
+      const uint32_t kmask = (1u << t.direct_key_bits) - 1u, rep = (uint32_t)i >> t.direct_key_bits;
+      if (rep >> t.direct_rep_log2) continue;  // beyond the replicas in use
+      key = (KeyT<K32>)(((uint32_t)i - rep * 5u) & kmask);
+    } else {
+      key = t.keys[i];
+      if (key == empty) continue;
+    }
     uint64_t e = global_entry(p, (uint64_t)key);
     for (int s = 0; s < p.n_slots; ++s) {
       int op = p.slots[s].op;
@@ -553,6 +576,13 @@ __global__ __launch_bounds__(kStreamBlock) void k_group_by_stream(AggParams p) {
   t.keys = (KeyT<K32>*)(lds_raw + (size_t)p.n_slots * t.stride);
   t.replicas = kInitialReplicas;
   t.salt = (threadIdx.x & (uint32_t)(t.replicas - 1)) * kReplicaSalt;
+  {
+    const int log2_s = 31 - __builtin_clz((unsigned)t.S);
+    int rep = log2_s - p.key_bits;  // replicas that fit
+    if (rep > 4) rep = 4;
+    t.direct_rep_log2 = (K32 && NK > 0 && rep >= 2) ? rep : -1;
+    t.direct_key_bits = p.key_bits;
+  }
   if (threadIdx.x == 0) n_entries = 0;
   lds_clear<K32>(p, t);
   __syncthreads();
