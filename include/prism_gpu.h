@@ -11,7 +11,7 @@
  * the reference interface it replaces.  Data crosses the boundary as Arrow C
  * Data Interface structs (arrow_c_data.h), which arrow-rs exports/imports with
  * arrow::ffi, so a Rust `ExecutionPlan` shim needs nothing but these
- * declarations (INTEGRATION.md shows the binding).
+ * declarations.
  *
  * Conventions
  *  - every function returns 0 on success or a negative prism_gpu_status; the
