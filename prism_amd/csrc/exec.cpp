@@ -156,7 +156,19 @@ struct KeyCursor {
 
 // Packs the given key sources from `cur` on.
 void layout_keys(ScanSet& ss, const prism_gpu_table* t, const std::vector<KeySrc>& keys, KeyCursor& cur, KeyLayout& L) {
-  for (const KeySrc& k : keys) {
+  // Bits are handed out to the other keys first and to time keys (date_bin, timestamps)
+  // last, so that time ends up in the high bits of the packed key: over time-ordered input
+  // the packed keys of any short stretch of rows then fall in a narrow range, which the
+  // streaming kernel's window mode indexes directly.  specs / fields stay in key order.
+  auto is_time = [&](const KeySrc& k) { return k.date_bin || t->fields[k.column].logical == PRISM_COL_TIMESTAMP; };
+  std::vector<size_t> order;
+  for (size_t i = 0; i < keys.size(); ++i) if (!is_time(keys[i])) order.push_back(i);
+  for (size_t i = 0; i < keys.size(); ++i) if (is_time(keys[i])) order.push_back(i);
+  const size_t first_out = L.specs.size();
+  L.specs.resize(first_out + keys.size());
+  L.fields.resize(first_out + keys.size());
+  for (size_t ki : order) {
+    const KeySrc& k = keys[ki];
     const FieldType& f = t->fields[k.column];
     if (f.is_string && !t->dicts[k.column].alive)
       fail(PRISM_GPU_EUNSUPPORTED, "GROUP BY / DISTINCT on string column `" + f.name + "` with more than " +
@@ -209,8 +221,8 @@ void layout_keys(ScanSet& ss, const prism_gpu_table* t, const std::vector<KeySrc
     s.bit_pos = kf.bit_pos;
     s.null_bit = kf.null_bit;
     s.word = kf.word;
-    L.specs.push_back(s);
-    L.fields.push_back(kf);
+    L.specs[first_out + ki] = s;
+    L.fields[first_out + ki] = kf;
   }
   L.word_bits[0] = cur.bit[0];
   L.word_bits[1] = cur.bit[1];
@@ -1170,6 +1182,11 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
     ap.lds_slots = lds_slots_for(ap.n_slots);
     ap.key_bits = total_bits;
     ap.key_words = layout.words;
+    ap.window_hint = 0;
+    if (!plan->distinct_plan && !merge_input && keys.size() >= 1) {
+      for (const KeySrc& k : keys)
+        if (k.date_bin || table->fields[k.column].logical == PRISM_COL_TIMESTAMP) ap.window_hint = 1;
+    }
     uint64_t bound = selected;
     if (total_bits < 63) bound = std::min<uint64_t>(bound, 1ull << total_bits);
     GroupTable gt;

@@ -33,6 +33,9 @@
 #ifndef PRISM_STREAM_REPLICAS
 #define PRISM_STREAM_REPLICAS 16
 #endif
+#ifndef PRISM_WINDOW_REP_LOG2
+#define PRISM_WINDOW_REP_LOG2 2
+#endif
 #ifndef PRISM_STREAM_LDS_KB
 #define PRISM_STREAM_LDS_KB 72
 #endif
@@ -50,7 +53,8 @@ constexpr uint32_t kStepRows = kStreamBlock * kU;  // rows of the workgroup per 
 constexpr uint32_t kStepsPerTile = kTileRows / kStepRows;
 constexpr int kWays = 4;      // entries per LDS bucket
 constexpr int kScratchEntries = 64;  // one per lane, behind the table proper
-constexpr int kInitialReplicas = PRISM_STREAM_REPLICAS;  // halved whenever the table fills up
+constexpr int kInitialReplicas = PRISM_STREAM_REPLICAS;
+constexpr int kWindowRepLog2 = PRISM_WINDOW_REP_LOG2;    // log2 of the replicas of the window mode  // halved whenever the table fills up
 constexpr uint32_t kReplicaSalt = 0x7FEB352Du;
 
 // Pointers read from descriptor arrays are generic; telling the compiler that they
@@ -96,6 +100,12 @@ struct Lds {
   // given by its low index bits).  -1: hashed.
   int direct_rep_log2;
   int direct_key_bits;
+  // Window mode: the same direct indexing for a key space that is too large as a whole but
+  // narrow at any one time (a time bucket in the high bits of the key, input in time
+  // order): only keys in [win_base, win_base + 2^direct_key_bits) are indexed, the others
+  // go to the HBM table, and when too many do the table is flushed and the window moved.
+  uint32_t win_base;
+  bool windowed;
 };
 
 // K32 plans only ever use the low 32 bits of a key value, so they load only those: a
@@ -383,10 +393,16 @@ __device__ __forceinline__ void apply_slot(int op, char* base, const uint32_t (&
   }
 }
 
+// Block-shared bookkeeping of the window mode.
+struct WindowShared {
+  uint32_t misses;     // wave instructions' rows that fell outside the window since the last check
+  uint32_t candidate;  // the key of one such row
+};
+
 // Applies the kU rows of a lane.
 template <int NK, int NV, bool K32>
-__device__ __forceinline__ void consume(const AggParams& p, const Lds<K32>& t, bool insert, int* n_entries, uint32_t lane,
-                                        const PackedRows<NK, NV, K32>& b) {
+__device__ __forceinline__ void consume(const AggParams& p, const Lds<K32>& t, bool insert, int* n_entries, WindowShared* win,
+                                        uint32_t lane, const PackedRows<NK, NV, K32>& b) {
   const KeyT<K32> empty = (KeyT<K32>)~(KeyT<K32>)0;
   int e[kU];
   bool miss = false;
@@ -394,8 +410,28 @@ __device__ __forceinline__ void consume(const AggParams& p, const Lds<K32>& t, b
     // directly indexed: no look-up at all
     const uint32_t rep = lane & ((1u << t.direct_rep_log2) - 1u);
     const uint32_t kmask = (1u << t.direct_key_bits) - 1u, base = rep << t.direct_key_bits, rot = rep * 5u;
+    if (!t.windowed) {
+      // the whole key space is indexed
 #pragma unroll
-    for (int u = 0; u < kU; ++u) e[u] = (int)(base | (((uint32_t)b.key[u] + rot) & kmask));
+      for (int u = 0; u < kU; ++u) e[u] = (int)(base | (((uint32_t)b.key[u] + rot) & kmask));
+    } else {
+      bool outside = false;
+      uint32_t outside_key = 0;
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const uint32_t rel = (uint32_t)b.key[u] - t.win_base;
+        const bool in = rel <= kmask;
+        e[u] = in ? (int)(base | ((rel + rot) & kmask)) : -1;
+        if (!in && lane_bit(b.live[u])) { outside = true; outside_key = (uint32_t)b.key[u]; }
+      }
+      const uint64_t om = __ballot(outside);
+      if (om) {  // rare: note how many rows fell outside the window, and where one of them was
+        if (lane == (uint32_t)__ffsll((long long)om) - 1u) {
+          atomicAdd(&win->misses, (uint32_t)__popcll(om));
+          win->candidate = outside_key;
+        }
+      }
+    }
   } else {
   // 1. the four candidate keys of every row's bucket (independent reads, issued together)
   int first[kU];
@@ -548,7 +584,7 @@ __device__ __forceinline__ void lds_flush(const AggParams& p, const Lds<K32>& t)
       if (t.state[i] == 0) continue;  // slot 0 counts the rows of the entry
       const uint32_t kmask = (1u << t.direct_key_bits) - 1u, rep = (uint32_t)i >> t.direct_key_bits;
       if (rep >> t.direct_rep_log2) continue;  // beyond the replicas in use
-      key = (KeyT<K32>)(((uint32_t)i - rep * 5u) & kmask);
+      key = (KeyT<K32>)(t.win_base + (((uint32_t)i - rep * 5u) & kmask));
     } else {
       key = t.keys[i];
       if (key == empty) continue;
@@ -582,8 +618,16 @@ __global__ __launch_bounds__(kStreamBlock) void k_group_by_stream(AggParams p) {
     if (rep > 4) rep = 4;
     t.direct_rep_log2 = (K32 && NK > 0 && rep >= 2) ? rep : -1;
     t.direct_key_bits = p.key_bits;
+    t.win_base = 0;
+    t.windowed = false;
+    if (K32 && NK > 0 && t.direct_rep_log2 < 0 && p.window_hint && log2_s >= kWindowRepLog2 + 4) {
+      t.windowed = true;
+      t.direct_rep_log2 = kWindowRepLog2;
+      t.direct_key_bits = log2_s - kWindowRepLog2;
+    }
   }
-  if (threadIdx.x == 0) n_entries = 0;
+  __shared__ WindowShared win;
+  if (threadIdx.x == 0) { n_entries = 0; win.misses = 0; win.candidate = 0; }
   lds_clear<K32>(p, t);
   __syncthreads();
 
@@ -617,19 +661,53 @@ __global__ __launch_bounds__(kStreamBlock) void k_group_by_stream(AggParams p) {
       return;
     }
   }
+  int window_moves = 0;
+  uint64_t tiles_since_move = 0;
   for (uint64_t j = j0; j < j1; ++j) {
     convert<NK, NV, K32>(p, raw, rows);
+    if (t.windowed && j == j0) {
+      // the first window starts at the workgroup's first key
+      if (threadIdx.x == 0) win.candidate = (uint32_t)rows.key[0];
+      __syncthreads();
+      t.win_base = win.candidate & ~((1u << t.direct_key_bits) - 1u);
+      __syncthreads();
+    }
     // The scheduling barriers keep the next step's loads from being hoisted above the
     // conversion (which would make the conversion wait for them too) and from being
     // sunk into the hashing (which would shorten the time they have to land).
     __builtin_amdgcn_sched_barrier(0);
     if (j + 1 < j1) issue<NK, NV, K32>(p, j + 1, wave, lane, cur, raw);
     __builtin_amdgcn_sched_barrier(0);
-    consume<NK, NV, K32>(p, t, insert, &n_entries, lane, rows);
+    consume<NK, NV, K32>(p, t, insert, &n_entries, &win, lane, rows);
+    if (t.windowed && (j + 1) % kStepsPerTile == 0) {
+      // Window bookkeeping at the end of a tile.  Many rows outside: fold the table into
+      // HBM and move the window to where the rows are now.  Moving again and again means
+      // the keys are not narrow at any one time: fall back to the hashed table for good.
+      tiles_since_move += 1;
+      __syncthreads();
+      const uint32_t missed = win.misses, cand = win.candidate;
+      __syncthreads();
+      if (threadIdx.x == 0) win.misses = 0;
+      if (missed > kTileRows / 8) {
+        lds_flush<K32>(p, t);
+        __syncthreads();
+        window_moves = tiles_since_move <= 2 ? window_moves + 1 : 0;
+        tiles_since_move = 0;
+        if (window_moves >= 3) {
+          t.windowed = false;
+          t.direct_rep_log2 = -1;
+          t.win_base = 0;
+          lds_clear<K32>(p, t);
+        } else {
+          t.win_base = cand & ~((1u << t.direct_key_bits) - 1u);
+        }
+        __syncthreads();
+      }
+    }
     // frozen table = nearly every row goes to the HBM table: if that one turned out too
     // small the pass will be re-run with a larger one, so stop early
     if (!insert && (j + 1) % kStepsPerTile == 0 && table_gave_up(p)) break;
-    if (insert && (j + 1) % kStepsPerTile == 0) {
+    if (insert && t.direct_rep_log2 < 0 && (j + 1) % kStepsPerTile == 0) {
       // Block-wide bookkeeping at the end of a tile, when the LDS table is half full.
       // Keys that repeat a lot: fold the table into HBM and start over, with half as
       // many replicas per group if there was more than one.  Keys that
