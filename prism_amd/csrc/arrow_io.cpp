@@ -2,8 +2,11 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <type_traits>
+#include <utility>
 
 namespace prism {
 
@@ -42,7 +45,35 @@ std::vector<FieldType> parse_schema(const ArrowSchema* schema) {
   return out;
 }
 
+void OutColumn::borrow(std::shared_ptr<void> owner, const int64_t* vals, const uint8_t* valid_bytes, size_t n) {
+  if (rows() != 0) fail(PRISM_GPU_EINTERNAL, "only an empty output column can borrow rows");
+  ext_owner = std::move(owner);
+  ext_vals = vals;
+  ext_valid = valid_bytes;
+  ext_rows = n;
+}
+
+void OutColumn::materialise() {
+  if (!borrowed()) return;
+  const size_t n = ext_rows;
+  valid.assign(ext_valid, ext_valid + n);
+  if (type.is_string) {
+    codes.resize(n);
+    for (size_t i = 0; i < n; ++i) codes[i] = (uint32_t)ext_vals[i];
+  } else if (type.is_float) {
+    const double* f = (const double*)ext_vals;
+    f64.assign(f, f + n);
+  } else {
+    i64.assign(ext_vals, ext_vals + n);
+  }
+  ext_vals = nullptr;
+  ext_valid = nullptr;
+  ext_rows = 0;
+  ext_owner.reset();
+}
+
 void OutColumn::gather(const std::vector<size_t>& idx) {
+  materialise();
   auto take = [&](auto& v) {
     if (v.empty()) return;
     typename std::remove_reference<decltype(v)>::type out;
@@ -58,15 +89,16 @@ void OutColumn::gather(const std::vector<size_t>& idx) {
 }
 
 void OutColumn::push_null() {
+  materialise();
   valid.push_back(0);
   if (type.is_string && dict) codes.push_back(0);
   else if (type.is_string) str.emplace_back();
   else if (type.is_float) f64.push_back(0.0);
   else i64.push_back(0);
 }
-void OutColumn::push_int(int64_t v) { valid.push_back(1); i64.push_back(v); }
-void OutColumn::push_float(double v) { valid.push_back(1); f64.push_back(v); }
-void OutColumn::push_str(const std::string& s) { valid.push_back(1); str.push_back(s); }
+void OutColumn::push_int(int64_t v) { materialise(); valid.push_back(1); i64.push_back(v); }
+void OutColumn::push_float(double v) { materialise(); valid.push_back(1); f64.push_back(v); }
+void OutColumn::push_str(const std::string& s) { materialise(); valid.push_back(1); str.push_back(s); }
 
 OutColumn make_out_column(const std::string& name, const std::string& format, bool nullable) {
   OutColumn c;
@@ -78,21 +110,77 @@ OutColumn make_out_column(const std::string& name, const std::string& format, bo
 
 namespace {
 
+// Host blocks of exported batches are recycled: a fresh allocation of this size comes
+// from mmap and costs a page fault per 4 KiB when it is first written, which is most of
+// the time an export of ~10^5 rows takes.  Bounded: at most kKeepPerClass blocks per
+// power-of-two size class, none above kMaxPooledBytes.
+class HostBlockPool {
+ public:
+  static constexpr size_t kMinBytes = 4096, kMaxPooledBytes = 16ull << 20, kKeepPerClass = 8;
+  static HostBlockPool& get() {
+    static HostBlockPool* pool = new HostBlockPool();  // never destroyed: batches may outlive static destruction
+    return *pool;
+  }
+  uint8_t* take(size_t bytes, size_t* cls_out) {
+    size_t cls = kMinBytes;
+    while (cls < bytes) cls <<= 1;
+    *cls_out = cls;
+    if (cls <= kMaxPooledBytes) {
+      std::lock_guard<std::mutex> g(mu_);
+      auto& v = free_[cls];
+      if (!v.empty()) {
+        uint8_t* p = v.back();
+        v.pop_back();
+        return p;
+      }
+    }
+    return static_cast<uint8_t*>(std::malloc(cls));
+  }
+  void give(uint8_t* p, size_t cls) {
+    if (cls <= kMaxPooledBytes) {
+      std::lock_guard<std::mutex> g(mu_);
+      auto& v = free_[cls];
+      if (v.size() < kKeepPerClass) {
+        v.push_back(p);
+        return;
+      }
+    }
+    std::free(p);
+  }
+
+ private:
+  std::mutex mu_;
+  std::map<size_t, std::vector<uint8_t*>> free_;
+};
+
 struct BatchOwner {
-  std::vector<std::unique_ptr<uint8_t[]>> blocks;
+  std::vector<std::pair<uint8_t*, size_t>> blocks;
   // 8-byte columns are not copied: their vectors move in here and the Arrow buffers
   // point at them
   std::vector<std::vector<int64_t>> kept_i64;
   std::vector<std::vector<double>> kept_f64;
+  // blocks that borrowed columns point into
+  std::vector<std::shared_ptr<void>> leases;
   std::vector<std::vector<const void*>> buffer_lists;
   std::vector<ArrowArray> children;
   std::vector<ArrowArray*> child_ptrs;
   const void* struct_buffers[1] = {nullptr};
 
+  BatchOwner() = default;
+  BatchOwner(const BatchOwner&) = delete;
+  BatchOwner& operator=(const BatchOwner&) = delete;
+  ~BatchOwner() {
+    for (auto& b : blocks) HostBlockPool::get().give(b.first, b.second);
+  }
+
+  // `bytes` + 64 spare bytes
   uint8_t* block(size_t bytes, bool zero = true) {
-    blocks.emplace_back(new uint8_t[bytes + 64]);
-    if (zero) std::memset(blocks.back().get(), 0, bytes + 64);
-    return blocks.back().get();
+    size_t cls = 0;
+    uint8_t* p = HostBlockPool::get().take(bytes + 64, &cls);
+    if (!p) fail(PRISM_GPU_EOOM, "out of host memory while exporting a result batch");
+    blocks.emplace_back(p, cls);
+    if (zero) std::memset(p, 0, bytes + 64);
+    return p;
   }
 };
 
@@ -127,33 +215,88 @@ void export_record_batch(std::vector<OutColumn>& cols, ArrowArray* out) {
     std::memset(&a, 0, sizeof(a));
     int64_t nulls = 0;
     uint8_t* bits = nullptr;
-    if (n && std::memchr(col.valid.data(), 0, n) != nullptr) {  // bitmap only when there is a NULL
+    const uint8_t* valid = col.valid_data();
+    if (n && std::memchr(valid, 0, n) != nullptr) {  // bitmap only when there is a NULL
       bits = owner->block((n + 7) / 8);
       for (size_t i = 0; i < n; ++i) {
-        if (col.valid[i]) bits[i >> 3] |= (uint8_t)(1u << (i & 7));
+        if (valid[i]) bits[i >> 3] |= (uint8_t)(1u << (i & 7));
         else ++nulls;
       }
     }
     auto& bl = owner->buffer_lists[c];
     bl.push_back(nulls ? bits : nullptr);
     if (col.type.is_string) {
-      size_t total = 0;
-      for (size_t i = 0; i < n; ++i) total += col.valid[i] ? col.str_at(i).size() : 0;
-      if (total > 0x7fffffffull) fail(PRISM_GPU_EUNSUPPORTED, "string output exceeds 2 GiB");
       int32_t* off = (int32_t*)owner->block((n + 1) * 4, false);
       off[0] = 0;
-      uint8_t* data = owner->block(total, false);
-      size_t pos = 0;
-      for (size_t i = 0; i < n; ++i) {
-        if (col.valid[i]) {
-          const std::string& v = col.str_at(i);
-          std::memcpy(data + pos, v.data(), v.size());
-          pos += v.size();
+      uint8_t* data = nullptr;
+      if (col.dict) {
+        // dictionary-coded: the lengths come from a flat table, not one std::string per row
+        const std::vector<std::string>& d = *col.dict;
+        std::vector<uint32_t> len(d.size());
+        for (size_t v = 0; v < d.size(); ++v) len[v] = (uint32_t)d[v].size();
+        uint32_t max_len = 0;
+        for (uint32_t l : len) max_len = l > max_len ? l : max_len;
+        // borrowed codes come straight from the device: check them before they index anything
+        if (col.borrowed()) {
+          bool bad = false;
+          for (size_t i = 0; i < n; ++i) bad |= (valid[i] != 0) & ((uint64_t)col.ext_vals[i] >= d.size());
+          if (bad) fail(PRISM_GPU_EINTERNAL, "dictionary code out of range in result");
         }
-        off[i + 1] = (int32_t)pos;
+        if (max_len <= 32 && !d.empty() && d.size() * 8 <= n && (uint64_t)n * max_len <= 0x7fffffffull) {
+          // Few short values, many rows: one pass that copies a fixed 16 or 32 bytes per row
+          // from a flat copy of the dictionary (two or four moves instead of a call to
+          // memcpy with a run-time length) into a block sized for the longest value per row.
+          const size_t w = max_len <= 16 ? 16 : 32;
+          std::vector<uint8_t> flat(d.size() * w, 0);
+          for (size_t v = 0; v < d.size(); ++v) std::memcpy(&flat[v * w], d[v].data(), len[v]);
+          data = owner->block((size_t)n * max_len + w, false);
+          uint32_t pos = 0;
+          if (w == 16) {
+            for (size_t i = 0; i < n; ++i) {
+              const uint32_t code = valid[i] ? col.code_at(i) : 0u;
+              std::memcpy(data + pos, &flat[(size_t)code * 16], 16);
+              pos += valid[i] ? len[code] : 0u;
+              off[i + 1] = (int32_t)pos;
+            }
+          } else {
+            for (size_t i = 0; i < n; ++i) {
+              const uint32_t code = valid[i] ? col.code_at(i) : 0u;
+              std::memcpy(data + pos, &flat[(size_t)code * 32], 32);
+              pos += valid[i] ? len[code] : 0u;
+              off[i + 1] = (int32_t)pos;
+            }
+          }
+        } else {
+          uint64_t pos = 0;
+          for (size_t i = 0; i < n; ++i) {
+            pos += valid[i] ? len[col.code_at(i)] : 0u;
+            off[i + 1] = (int32_t)pos;
+            if (pos > 0x7fffffffull) fail(PRISM_GPU_EUNSUPPORTED, "string output exceeds 2 GiB");
+          }
+          data = owner->block((size_t)pos, false);
+          for (size_t i = 0; i < n; ++i)
+            if (valid[i]) std::memcpy(data + off[i], d[col.code_at(i)].data(), (size_t)(off[i + 1] - off[i]));
+        }
+      } else {
+        size_t total = 0;
+        for (size_t i = 0; i < n; ++i) total += valid[i] ? col.str[i].size() : 0;
+        if (total > 0x7fffffffull) fail(PRISM_GPU_EUNSUPPORTED, "string output exceeds 2 GiB");
+        data = owner->block(total, false);
+        size_t pos = 0;
+        for (size_t i = 0; i < n; ++i) {
+          if (valid[i]) {
+            const std::string& v = col.str[i];
+            std::memcpy(data + pos, v.data(), v.size());
+            pos += v.size();
+          }
+          off[i + 1] = (int32_t)pos;
+        }
       }
       bl.push_back(off);
       bl.push_back(data);
+    } else if (col.type.width == 8 && col.borrowed()) {
+      owner->leases.push_back(col.ext_owner);
+      bl.push_back(col.ext_vals);
     } else if (col.type.is_float) {
       owner->kept_f64.push_back(std::move(col.f64));
       bl.push_back(owner->kept_f64.back().data());
@@ -161,12 +304,14 @@ void export_record_batch(std::vector<OutColumn>& cols, ArrowArray* out) {
       owner->kept_i64.push_back(std::move(col.i64));
       bl.push_back(owner->kept_i64.back().data());
     } else if (col.type.width == 4) {
+      const int64_t* src = col.i64_data();
       int32_t* v = (int32_t*)owner->block(n * 4);
-      for (size_t i = 0; i < n; ++i) v[i] = (int32_t)col.i64[i];
+      for (size_t i = 0; i < n; ++i) v[i] = (int32_t)src[i];
       bl.push_back(v);
     } else {
+      const int64_t* src = col.i64_data();
       int16_t* v = (int16_t*)owner->block(n * 2);
-      for (size_t i = 0; i < n; ++i) v[i] = (int16_t)col.i64[i];
+      for (size_t i = 0; i < n; ++i) v[i] = (int16_t)src[i];
       bl.push_back(v);
     }
     a.length = (int64_t)n;

@@ -3,6 +3,7 @@
 #pragma once
 
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -44,12 +45,29 @@ struct OutColumn {
   const std::vector<std::string>* dict = nullptr;
   std::vector<uint32_t> codes;
   std::vector<uint8_t> valid;      // one byte per row
-  size_t rows() const { return valid.size(); }
+  // Borrowed rows: `ext_rows` 8-byte values (integers, doubles, or dictionary codes, by
+  // `type` and `dict`) and validity bytes in a block that `ext_owner` keeps alive (a pinned
+  // landing block the device wrote whole result columns into).  A column is either
+  // borrowed or held in the vectors above, never both; materialise() copies it over, and
+  // everything that edits rows does that first.  Export hands 8-byte borrowed values to
+  // Arrow as they are.
+  const int64_t* ext_vals = nullptr;
+  const uint8_t* ext_valid = nullptr;
+  size_t ext_rows = 0;
+  std::shared_ptr<void> ext_owner;
+  bool borrowed() const { return ext_vals != nullptr; }
+  void borrow(std::shared_ptr<void> owner, const int64_t* vals, const uint8_t* valid_bytes, size_t n);
+  void materialise();
+  size_t rows() const { return borrowed() ? ext_rows : valid.size(); }
+  const uint8_t* valid_data() const { return borrowed() ? ext_valid : valid.data(); }
+  const int64_t* i64_data() const { return borrowed() ? ext_vals : i64.data(); }
+  const double* f64_data() const { return borrowed() ? (const double*)ext_vals : f64.data(); }
+  uint32_t code_at(size_t i) const { return borrowed() ? (uint32_t)ext_vals[i] : codes[i]; }
   void push_null();
   void push_int(int64_t v);
   void push_float(double v);
   void push_str(const std::string& s);
-  const std::string& str_at(size_t i) const { return dict ? (*dict)[codes[i]] : str[i]; }
+  const std::string& str_at(size_t i) const { return dict ? (*dict)[code_at(i)] : str[i]; }
   // Keeps rows idx[0], idx[1], ... in that order.
   void gather(const std::vector<size_t>& idx);
 };

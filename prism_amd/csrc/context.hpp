@@ -5,11 +5,27 @@
 #include <chrono>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
 
 #include "common.hpp"
+
+namespace prism {
+
+// Pinned host blocks that result batches are built in.  A block is leased to one result,
+// whose Arrow buffers point into it, and comes back when the caller releases the batch
+// (possibly after the context is gone: the pool lives as long as any lease).
+struct PinnedPool {
+  std::mutex mu;
+  std::multimap<size_t, void*> free_blocks;
+  ~PinnedPool() {
+    for (auto& kv : free_blocks) (void)hipHostFree(kv.second);
+  }
+};
+
+}  // namespace prism
 
 struct prism_gpu_ctx {
   int device = 0;
@@ -36,6 +52,7 @@ struct prism_gpu_ctx {
   std::mutex result_mu;
   void* result_pinned = nullptr;
   size_t result_pinned_bytes = 0;
+  std::shared_ptr<prism::PinnedPool> result_pool = std::make_shared<prism::PinnedPool>();
 
   // ---- profiling ----
   bool profiling = false;

@@ -604,6 +604,7 @@ void append_agg_columns(const Lowered& L, const GroupRows& g, bool partial, std:
 
 void sort_and_limit(const prism_gpu_plan* p, std::vector<OutColumn>& cols) {
   if (p->order_by < 0 && p->limit < 0) return;
+  for (auto& c : cols) c.materialise();
   size_t n = cols.empty() ? 0 : cols[0].rows();
   std::vector<size_t> idx(n);
   std::iota(idx.begin(), idx.end(), 0);
@@ -795,6 +796,37 @@ int lds_slots_for(int n_slots) {
 }
 
 
+// Results up to this size land in a pinned block of their own that the exported batch
+// keeps; larger ones are copied out of the context's landing buffer.
+constexpr size_t kLeasedResultMaxBytes = 64ull << 20;
+
+// A pinned block of at least `bytes` from the context's pool; goes back when the last
+// reference is dropped.
+std::shared_ptr<void> lease_pinned(prism_gpu_ctx* ctx, size_t bytes) {
+  const size_t cls = pow2_ceil(bytes < 4096 ? 4096 : bytes);
+  std::shared_ptr<PinnedPool> pool = ctx->result_pool;
+  void* p = nullptr;
+  {
+    std::lock_guard<std::mutex> g(pool->mu);
+    auto it = pool->free_blocks.find(cls);
+    if (it != pool->free_blocks.end()) {
+      p = it->second;
+      pool->free_blocks.erase(it);
+    }
+  }
+  if (!p) PRISM_HIP(hipHostMalloc(&p, cls, hipHostMallocDefault));
+  return std::shared_ptr<void>(p, [pool, cls](void* q) {
+    {
+      std::lock_guard<std::mutex> g(pool->mu);
+      if (pool->free_blocks.size() < 8) {
+        pool->free_blocks.emplace(cls, q);
+        return;
+      }
+    }
+    (void)hipHostFree(q);
+  });
+}
+
 // Reads the groups of a finished table and appends them to `cols`; with ORDER BY ...
 // LIMIT only the leading groups leave the device.  The columns are assembled on the device
 // (launch_emit_columns) and arrive through pinned memory as whole columns.  Returns the
@@ -837,6 +869,7 @@ uint64_t emit_groups(prism_gpu_ctx* ctx, const prism_gpu_plan* plan, const prism
   const int64_t* h_vals = nullptr;
   const uint8_t* h_valid = nullptr;
   std::unique_lock<std::mutex> pinned_lock(ctx->result_mu, std::defer_lock);
+  std::shared_ptr<void> lease;
   {
     HostTimer ht(ctx, "host:read_groups");
     TopKOrder order;
@@ -880,17 +913,25 @@ uint64_t emit_groups(prism_gpu_ctx* ctx, const prism_gpu_plan* plan, const prism
     n = count;
     if (n) {
       // HBM -> pinned host memory, compacted to n entries per column on the way
-      pinned_lock.lock();
       const size_t need = (size_t)n * n_cols * 9;
-      if (ctx->result_pinned_bytes < need) {
-        if (ctx->result_pinned) (void)hipHostFree(ctx->result_pinned);
-        ctx->result_pinned = nullptr;
-        ctx->result_pinned_bytes = 0;
-        const size_t want = pow2_ceil(need);
-        PRISM_HIP(hipHostMalloc(&ctx->result_pinned, want, hipHostMallocDefault));
-        ctx->result_pinned_bytes = want;
+      bool fresh = need <= kLeasedResultMaxBytes;
+      for (const OutColumn& oc : cols) fresh = fresh && oc.rows() == 0;
+      uint8_t* pin = nullptr;
+      if (fresh) {
+        lease = lease_pinned(ctx, need);
+        pin = (uint8_t*)lease.get();
+      } else {
+        pinned_lock.lock();
+        if (ctx->result_pinned_bytes < need) {
+          if (ctx->result_pinned) (void)hipHostFree(ctx->result_pinned);
+          ctx->result_pinned = nullptr;
+          ctx->result_pinned_bytes = 0;
+          const size_t want = pow2_ceil(need);
+          PRISM_HIP(hipHostMalloc(&ctx->result_pinned, want, hipHostMallocDefault));
+          ctx->result_pinned_bytes = want;
+        }
+        pin = (uint8_t*)ctx->result_pinned;
       }
-      uint8_t* pin = (uint8_t*)ctx->result_pinned;
       PRISM_HIP(hipMemcpy2DAsync(pin, n * 8, d_vals.p, stride * 8, n * 8, n_cols, hipMemcpyDeviceToHost, ctx->stream));
       PRISM_HIP(hipMemcpy2DAsync(pin + (size_t)n * n_cols * 8, n, d_valid.p, stride, n, n_cols, hipMemcpyDeviceToHost, ctx->stream));
       PRISM_HIP(hipStreamSynchronize(ctx->stream));
@@ -903,18 +944,30 @@ uint64_t emit_groups(prism_gpu_ctx* ctx, const prism_gpu_plan* plan, const prism
     OutColumn& oc = cols[c];
     const int64_t* v = h_vals + c * n;
     const uint8_t* ok = h_valid + c * n;
-    oc.valid.insert(oc.valid.end(), ok, ok + n);
-    if (c < keys.size() && table->fields[keys[c].column].is_string) {
+    const bool is_dict = c < keys.size() && table->fields[keys[c].column].is_string;
+    uint64_t n_values = 0;
+    if (is_dict) {
       const ColumnDict& d = table->dicts[keys[c].column];
-      if (oc.codes.empty()) oc.dict = &d.values;
+      if (oc.rows() == 0) oc.dict = &d.values;
       if (oc.dict != &d.values) fail(PRISM_GPU_EINTERNAL, "string key column built from two dictionaries");
+      n_values = d.values.size();
+    }
+    if (lease) {
+      // the exported batch points into the block: no copy
+      oc.borrow(lease, v, ok, n);
+      continue;
+    }
+    oc.materialise();
+    oc.valid.insert(oc.valid.end(), ok, ok + n);
+    if (is_dict) {
       const size_t base = oc.codes.size();
       oc.codes.resize(base + n);
-      const uint64_t n_values = d.values.size();
+      bool bad = false;
       for (size_t r = 0; r < n; ++r) {
-        if (ok[r] && (uint64_t)v[r] >= n_values) fail(PRISM_GPU_EINTERNAL, "dictionary code out of range in result");
+        bad |= (ok[r] != 0) & ((uint64_t)v[r] >= n_values);
         oc.codes[base + r] = (uint32_t)v[r];
       }
+      if (bad) fail(PRISM_GPU_EINTERNAL, "dictionary code out of range in result");
     } else if (oc.type.is_float) {
       const double* f = (const double*)v;
       oc.f64.insert(oc.f64.end(), f, f + n);
