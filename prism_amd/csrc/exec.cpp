@@ -1236,6 +1236,9 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
     ap.key_bits = total_bits;
     ap.key_words = layout.words;
     ap.window_hint = 0;
+    // COUNT(DISTINCT)'s inner level is a set: with two-word keys (always a hash table, whose
+    // occupied entries are told by their keys) no accumulator is touched at all
+    ap.keys_only = (plan->distinct_plan && layout.words == 2) ? 1 : 0;
     if (!plan->distinct_plan && !merge_input && keys.size() >= 1) {
       for (const KeySrc& k : keys)
         if (k.date_bin || table->fields[k.column].logical == PRISM_COL_TIMESTAMP) ap.window_hint = 1;
@@ -1326,6 +1329,7 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       fp.g_keys = q.keys.as<uint64_t>();
       fp.g_state = q.state.as<int64_t>();
       fp.overflow = q.overflow.as<uint32_t>();
+      fp.k_bits = k_bits;
       GroupRows pairs;  // dense sets are folded on the host side of the emit: read them as rows
       if (gt.dense) {
         // a dense (k, x) set has no key array; materialise its occupied entries first

@@ -164,6 +164,7 @@ struct AggParams {
   uint64_t* g_keys;     // hash only: capacity + 1 entries (last = the all-ones key)
   uint64_t* g_keys_hi;  // second key word of every entry when key_words == 2
   int32_t key_words;    // 1, or 2 for packed keys of 65..127 bits (hash table only, no LDS stage)
+  int32_t keys_only;    // two-word keys: only the set of keys is wanted (COUNT(DISTINCT)'s inner level), no accumulators
   int64_t* g_state;     // n_slots arrays of (capacity + 1) entries
   uint32_t* overflow;   // set to 1 when the hash table is full
 };
@@ -195,6 +196,7 @@ struct DistinctFoldParams {
   uint64_t* g_keys;
   int64_t* g_state;          // slot 0 = existence count, slot 1 = distinct count
   uint32_t* overflow;
+  int32_t k_bits;            // bits of the group key (dense outer table: capacity = 2^k_bits)
 };
 void launch_distinct_fold(prism_gpu_ctx* ctx, const DistinctFoldParams& p);
 

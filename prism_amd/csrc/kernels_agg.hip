@@ -224,7 +224,7 @@ __global__ __launch_bounds__(kBlock) void k_group_by_wide(AggParams p) {
     RowVals rv;
     load_vals(p, seg, r, rv);
     uint64_t e = global_entry2(p, lo, hi);
-    if (e == ~0ull) return;
+    if (e == ~0ull || p.keys_only) return;
     for (int s = 0; s < p.n_slots; ++s) {
       long long x;
       if (slot_input(p, s, rv, x)) atomic_apply(&p.g_state[(uint64_t)s * (p.capacity + 1) + e], p.slots[s].op, x);
@@ -362,6 +362,70 @@ __global__ __launch_bounds__(kBlock) void k_distinct_fold(DistinctFoldParams q) 
     if (e == ~0ull) continue;
     atomicAdd((unsigned long long*)&q.g_state[e], 1ull);
     if (!x_null) atomicAdd((unsigned long long*)&q.g_state[(q.capacity + 1) + e], 1ull);
+  }
+}
+
+// The same fold for a small dense outer table, without a global atomic per pair: a
+// workgroup counts the pairs of kFoldRange consecutive groups in LDS (32-bit counters) and
+// adds its non-zero counters to the table at the end; the launcher runs one pass per
+// kFoldRange groups.  A pass of a two-word set whose x has no NULL reads the high words
+// only: an unused entry's high word is all ones, which no range contains.
+constexpr uint32_t kFoldRange = 16384;  // counters per workgroup: 64 KiB of LDS
+constexpr uint32_t kFoldBlock = 1024;
+
+__device__ __forceinline__ uint64_t fold_load(const uint64_t* p) {
+  return __builtin_nontemporal_load((const unsigned long long*)p);
+}
+
+__global__ __launch_bounds__(kFoldBlock) void k_distinct_fold_lds(DistinctFoldParams q, uint64_t k_first, uint32_t range, int with_nulls) {
+  extern __shared__ uint32_t fold_counts[];  // [range] pairs, then [range] pairs with a non-NULL x when with_nulls
+  for (uint32_t j = threadIdx.x; j < range * (with_nulls ? 2u : 1u); j += kFoldBlock) fold_counts[j] = 0;
+  __syncthreads();
+  const bool two = q.set_keys_hi != nullptr;
+  const uint64_t* words = two ? q.set_keys_hi : q.set_keys;
+  const uint64_t per = ceil_div(q.set_capacity, (uint64_t)gridDim.x);
+  const uint64_t lo = per * blockIdx.x, hi = lo + per < q.set_capacity ? lo + per : q.set_capacity;
+  constexpr int kInFlight = 4;
+  for (uint64_t base = lo; base < hi; base += (uint64_t)kInFlight * kFoldBlock) {
+    uint64_t w[kInFlight];
+#pragma unroll
+    for (int u = 0; u < kInFlight; ++u) {
+      const uint64_t i = base + (uint64_t)u * kFoldBlock + threadIdx.x;
+      w[u] = i < hi ? fold_load(&words[i]) : kEmptyKey;
+    }
+#pragma unroll
+    for (int u = 0; u < kInFlight; ++u) {
+      const uint64_t i = base + (uint64_t)u * kFoldBlock + threadIdx.x;
+      // all ones: an unused entry (both words start that way), or the slot past the end
+      if (w[u] == kEmptyKey) continue;
+      const uint64_t k = two ? w[u] : (q.x_bits >= 64 ? 0ull : w[u] >> q.x_bits);
+      const uint64_t rel = k - k_first;
+      if (rel >= range) continue;
+      atomicAdd(&fold_counts[rel], 1u);
+      if (with_nulls) {
+        const uint64_t x_word = two ? q.set_keys[i] : w[u];
+        if (((x_word >> q.x_null_bit) & 1ull) == 0) atomicAdd(&fold_counts[range + rel], 1u);
+      }
+    }
+  }
+  // the entry that stands for the all-ones key of a one-word set
+  if (!two && q.set_special != ~0ull && blockIdx.x == 0 && threadIdx.x == 0 && q.set_rowcount[q.set_special] != 0) {
+    const uint64_t k = q.x_bits >= 64 ? 0ull : kEmptyKey >> q.x_bits;
+    const uint64_t rel = k - k_first;
+    if (rel < range) {
+      atomicAdd(&fold_counts[rel], 1u);
+      if (with_nulls && ((kEmptyKey >> q.x_null_bit) & 1ull) == 0) atomicAdd(&fold_counts[range + rel], 1u);
+    }
+  }
+  __syncthreads();
+  for (uint32_t j = threadIdx.x; j < range; j += kFoldBlock) {
+    const uint32_t pairs = fold_counts[j];
+    if (pairs == 0) continue;
+    const uint64_t e = k_first + j;
+    if (e >= q.capacity) continue;
+    atomicAdd((unsigned long long*)&q.g_state[e], (unsigned long long)pairs);
+    const uint32_t counted = with_nulls ? fold_counts[range + j] : pairs;
+    if (counted) atomicAdd((unsigned long long*)&q.g_state[(q.capacity + 1) + e], (unsigned long long)counted);
   }
 }
 
@@ -664,6 +728,25 @@ void launch_group_by(prism_gpu_ctx* ctx, const AggParams& params, uint64_t algor
 }
 
 void launch_distinct_fold(prism_gpu_ctx* ctx, const DistinctFoldParams& p) {
+  // Small dense outer table: count in LDS, one pass per kFoldRange groups (each pass reads
+  // the set again, which is far cheaper than a global atomic per pair).  A workgroup sees
+  // fewer than 2^32 entries, so its 32-bit counters cannot wrap.
+  const bool with_nulls = p.x_null_bit >= 0;
+  const uint32_t range = with_nulls ? kFoldRange / 2 : kFoldRange;
+  if (p.dense && p.k_bits <= 18 && p.set_capacity >= (1ull << 16) && p.set_capacity < (1ull << 40)) {
+    const uint64_t groups = 1ull << p.k_bits;
+    const uint64_t words_per_entry = (with_nulls && p.set_keys_hi) ? 2 : 1;
+    const size_t lds = (size_t)kFoldRange * 4;
+    PRISM_HIP(hipFuncSetAttribute((const void*)k_distinct_fold_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(ceil_div(p.set_capacity, (uint64_t)kFoldBlock * 4), (uint64_t)ctx->n_cus * 2);
+    const uint64_t passes = ceil_div(groups, (uint64_t)range);
+    KernelTimer timer(ctx, "distinct_fold", p.set_capacity * 8 * words_per_entry * passes);
+    for (uint64_t k_first = 0; k_first < groups; k_first += range) {
+      k_distinct_fold_lds<<<dim3(grid), dim3(kFoldBlock), lds, ctx->stream>>>(p, k_first, range, with_nulls ? 1 : 0);
+      PRISM_HIP(hipGetLastError());
+    }
+    return;
+  }
   uint32_t grid = stream_grid(ctx, p.set_capacity);
   KernelTimer timer(ctx, "distinct_fold", p.set_capacity * 8);
   k_distinct_fold<<<dim3(grid), dim3(kBlock), 0, ctx->stream>>>(p);

@@ -205,6 +205,41 @@ def test_keys_wider_than_64_bits(gpu_ctx, oracle):
         g.close()
 
 
+def test_count_distinct_over_many_groups_and_large_sets(gpu_ctx, oracle):
+    """COUNT(DISTINCT x) GROUP BY g with 40 000 groups and sets of >= 2^16 entries: the second
+    level counts pairs per range of groups in LDS, several passes; x wide (two-word set, only
+    the keys are stored) or narrow (one-word set), with and without NULLs; PARTIAL states of
+    the wide case merge to the same answer."""
+    from prism_amd.engine import Plan, Table
+
+    rng = np.random.default_rng(15)
+    n = 300_000
+    g_col = rng.integers(0, 40_000, n).astype(np.int32)
+    wide = rng.integers(0, 50, n).astype(np.int64) * (2**62 // 50) - 2**61 + rng.integers(0, 3, n)
+    narrow = rng.integers(0, 1 << 20, n).astype(np.int64)
+    t = pa.table({"g": pa.array(g_col, mask=rng.random(n) < 0.01),
+                  "wide_nulls": pa.array(wide, mask=rng.random(n) < 0.1), "wide": pa.array(wide),
+                  "narrow_nulls": pa.array(narrow, mask=rng.random(n) < 0.1), "narrow": pa.array(narrow)})
+    table = Table(gpu_ctx, t.schema)
+    table.append_table(t, 3)
+    try:
+        for x in ("wide_nulls", "wide", "narrow_nulls", "narrow"):
+            q = QueryPlan([count_distinct(x)], keys=["g"])
+            plan = Plan(gpu_ctx, t.schema, q)
+            try:
+                want = oracle.execute(t, q)
+                assert_tables_match(plan.execute(table), want, 1)
+            finally:
+                plan.close()
+            pp = Plan(gpu_ctx, t.schema, q.with_mode(abi.MODE_PARTIAL))
+            try:
+                assert_tables_match(pp.merge([pp.execute(table, [p]) for p in range(3)]), want, 1)
+            finally:
+                pp.close()
+    finally:
+        table.close()
+
+
 def test_c4_generated_urls_like_and_compaction_variant(gpu_ctx, oracle):
     """C4 on device-generated URL-like strings (no dictionary: the raw-string kernels run),
     a middle slice of a larger table with ragged partitions; plus near-miss patterns and
