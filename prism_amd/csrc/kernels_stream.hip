@@ -24,6 +24,7 @@
 // planner found that the timestamps allow it).
 #include <algorithm>
 #include <type_traits>
+#include <utility>
 
 #include "agg_device.hpp"
 
@@ -520,49 +521,80 @@ __device__ __forceinline__ void consume(const AggParams& p, const Lds<K32>& t, b
 // lanes' accumulators are combined once, when the workgroup is done.
 constexpr int kUngroupedSlots = 8;
 
-template <int NV, bool K32>
-__device__ __forceinline__ void consume_ungrouped(const AggParams& p, const PackedRows<0, NV, K32>& b,
-                                                  long long (&acc)[kUngroupedSlots]) {
+// One slot of the ungrouped path.  The slot number is a template argument (and the
+// caller expands all of them) so that every accumulator stays a named register: left as a
+// loop over the slots, the compiler keeps the loop and indexes the accumulators at run time.
+template <int S, int NV, bool K32>
+__device__ __forceinline__ void consume_ungrouped_slot(const AggParams& p, const PackedRows<0, NV, K32>& b,
+                                                       long long (&acc)[kUngroupedSlots]) {
+  if (S >= p.n_slots) return;
+  const int op = p.slots[S].op, val = p.slots[S].val;
+  if (op == kSlotAddOne) {
 #pragma unroll
-  for (int s = 0; s < kUngroupedSlots; ++s) {
-    if (s >= p.n_slots) continue;
-    const int op = p.slots[s].op, val = p.slots[s].val;
-    if (op == kSlotAddOne) {
+    for (int u = 0; u < kU; ++u) acc[S] += lane_bit(b.live[u]) ? 1 : 0;
+    return;
+  }
 #pragma unroll
-      for (int u = 0; u < kU; ++u) acc[s] += lane_bit(b.live[u]) ? 1 : 0;
-      continue;
-    }
+  for (int v = 0; v < NV; ++v) {
+    if (v != val) continue;
+    const bool is_float = p.vals[v].is_float != 0;
+    if (op == kSlotAddValid) {
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      if (v != val) continue;
-      const bool is_float = p.vals[v].is_float != 0;
+      for (int u = 0; u < kU; ++u) acc[S] += lane_bit(b.live[u] & b.vok[v][u]) ? 1 : 0;
+    } else if (op == kSlotAddI64) {
+#pragma unroll
+      for (int u = 0; u < kU; ++u)
+        acc[S] = (long long)((unsigned long long)acc[S] + (unsigned long long)(lane_bit(b.live[u] & b.vok[v][u]) ? b.val[v][u] : 0ll));
+    } else if (op == kSlotMax) {
+#pragma unroll
+      for (int u = 0; u < kU; ++u) acc[S] = lane_bit(b.live[u] & b.vok[v][u]) && b.val[v][u] > acc[S] ? b.val[v][u] : acc[S];
+    } else if (op == kSlotMin) {
+#pragma unroll
+      for (int u = 0; u < kU; ++u) acc[S] = lane_bit(b.live[u] & b.vok[v][u]) && b.val[v][u] < acc[S] ? b.val[v][u] : acc[S];
+    } else {
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
-        const bool ok = lane_bit(b.live[u] & b.vok[v][u]);
         const long long x = b.val[v][u];
-        if (op == kSlotAddValid) acc[s] += ok ? 1 : 0;
-        else if (op == kSlotAddI64) acc[s] = (long long)((unsigned long long)acc[s] + (unsigned long long)(ok ? x : 0ll));
-        else if (op == kSlotMax) acc[s] = ok && x > acc[s] ? x : acc[s];
-        else if (op == kSlotMin) acc[s] = ok && x < acc[s] ? x : acc[s];
-        else acc[s] = __double_as_longlong(__longlong_as_double(acc[s]) + (ok ? (is_float ? __longlong_as_double(x) : (double)x) : 0.0));
+        const double add = lane_bit(b.live[u] & b.vok[v][u]) ? (is_float ? __longlong_as_double(x) : (double)x) : 0.0;
+        acc[S] = __double_as_longlong(__longlong_as_double(acc[S]) + add);
       }
     }
   }
 }
 
+template <int NV, bool K32, int... S>
+__device__ __forceinline__ void consume_ungrouped_slots(const AggParams& p, const PackedRows<0, NV, K32>& b,
+                                                        long long (&acc)[kUngroupedSlots], std::integer_sequence<int, S...>) {
+  (consume_ungrouped_slot<S, NV, K32>(p, b, acc), ...);
+}
+
+template <int NV, bool K32>
+__device__ __forceinline__ void consume_ungrouped(const AggParams& p, const PackedRows<0, NV, K32>& b,
+                                                  long long (&acc)[kUngroupedSlots]) {
+  consume_ungrouped_slots<NV, K32>(p, b, acc, std::make_integer_sequence<int, kUngroupedSlots>{});
+}
+
+template <int S>
+__device__ __forceinline__ void finish_ungrouped_slot(const AggParams& p, const long long (&acc)[kUngroupedSlots]) {
+  if (S >= p.n_slots) return;
+  const int op = p.slots[S].op;
+  long long v = acc[S];
+  if (op == kSlotMin) v = wave_min_i64(v);
+  else if (op == kSlotMax) v = wave_max_i64(v);
+  else if (op == kSlotAddF64) v = __double_as_longlong(wave_sum_f64(__longlong_as_double(v)));
+  else v = (long long)wave_sum_u64((unsigned long long)v);
+  if ((threadIdx.x & 63u) == 0 && v != slot_identity(op))
+    atomic_apply(&p.g_state[(uint64_t)S * (p.capacity + 1)], (op == kSlotAddOne || op == kSlotAddValid) ? kSlotAddI64 : op, v);
+}
+
+template <int... S>
+__device__ __forceinline__ void finish_ungrouped_slots(const AggParams& p, const long long (&acc)[kUngroupedSlots],
+                                                       std::integer_sequence<int, S...>) {
+  (finish_ungrouped_slot<S>(p, acc), ...);
+}
+
 __device__ __forceinline__ void finish_ungrouped(const AggParams& p, const long long (&acc)[kUngroupedSlots]) {
-#pragma unroll
-  for (int s = 0; s < kUngroupedSlots; ++s) {
-    if (s >= p.n_slots) continue;
-    const int op = p.slots[s].op;
-    long long v = acc[s];
-    if (op == kSlotMin) v = wave_min_i64(v);
-    else if (op == kSlotMax) v = wave_max_i64(v);
-    else if (op == kSlotAddF64) v = __double_as_longlong(wave_sum_f64(__longlong_as_double(v)));
-    else v = (long long)wave_sum_u64((unsigned long long)v);
-    if ((threadIdx.x & 63u) == 0 && v != slot_identity(op))
-      atomic_apply(&p.g_state[(uint64_t)s * (p.capacity + 1)], (op == kSlotAddOne || op == kSlotAddValid) ? kSlotAddI64 : op, v);
-  }
+  finish_ungrouped_slots(p, acc, std::make_integer_sequence<int, kUngroupedSlots>{});
 }
 
 template <bool K32>
