@@ -19,7 +19,9 @@
  *  - nothing throws or aborts across the boundary;
  *  - an ArrowArray passed as "moved" is released by the library; arrays and
  *    schemas written to `out` parameters are owned by the caller, who calls
- *    their `release`;
+ *    their `release`; a result array's buffers may lie in page-locked host
+ *    blocks of up to 64 MiB that go back to a small pool on release (they stay
+ *    valid after the ctx is destroyed), so copy results that are kept for long;
  *  - a ctx, table or plan may be used from several threads once created; a
  *    prism_gpu_part is used by one thread at a time.
  */
