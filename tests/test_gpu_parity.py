@@ -305,3 +305,31 @@ def test_chunks_outside_the_predicate_range_are_pruned(gpu_ctx, oracle):
             assert (pruned > 0) == expect_pruned, (pred, pruned)
     finally:
         g.close()
+
+
+def test_results_stay_valid_while_held_and_after_the_context_is_gone(oracle):
+    """GROUP BY results point into page-locked blocks leased from a pool: many results held
+    at once (more than the pool keeps), interleaved with further queries, must all keep their
+    contents, also after the plan, the table and the context have been destroyed."""
+    import gc
+
+    from prism_amd.engine import Context, Plan, Table
+
+    t = helpers.random_table(40_000, seed=21)
+    q = QueryPlan([count_star(), sum_("value"), avg("value"), max_("i32")], keys=[date_bin(1_000, "ts"), "service"])
+    want = oracle.execute(t, q)
+    ctx = Context(0)
+    table = Table(ctx, t.schema)
+    table.append_table(t, 3)
+    plan = Plan(ctx, t.schema, q)
+    held = [plan.execute(table) for _ in range(12)]
+    del held[3:7]  # blocks go back to the pool and are handed out again
+    gc.collect()
+    held += [plan.execute(table) for _ in range(6)]
+    plan.close()
+    table.close()
+    ctx.close()
+    for got in held:
+        assert_tables_match(got, want, 2)
+    del held
+    gc.collect()
