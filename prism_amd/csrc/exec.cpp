@@ -1239,9 +1239,17 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
     // COUNT(DISTINCT)'s inner level is a set: with two-word keys (always a hash table, whose
     // occupied entries are told by their keys) no accumulator is touched at all
     ap.keys_only = (plan->distinct_plan && layout.words == 2) ? 1 : 0;
-    if (!plan->distinct_plan && !merge_input && keys.size() >= 1) {
-      for (const KeySrc& k : keys)
-        if (k.date_bin || table->fields[k.column].logical == PRISM_COL_TIMESTAMP) ap.window_hint = 1;
+    if (!plan->distinct_plan && !merge_input && keys.size() >= 1 && layout.words == 1) {
+      // the lowest bit any time-typed key occupies: windows start at multiples of it, so
+      // that a window holds whole time buckets with all their other key values
+      int align = 64;
+      for (size_t i = 0; i < keys.size(); ++i) {
+        if (!(keys[i].date_bin || table->fields[keys[i].column].logical == PRISM_COL_TIMESTAMP)) continue;
+        const KeyField& kf = layout.fields[i];
+        if (kf.bits) align = std::min(align, kf.bit_pos);
+        if (kf.null_bit >= 0) align = std::min(align, kf.null_bit);
+      }
+      if (align < 32) ap.window_hint = 1 + align;
     }
     uint64_t bound = selected;
     if (total_bits < 63) bound = std::min<uint64_t>(bound, 1ull << total_bits);

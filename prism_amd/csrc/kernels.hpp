@@ -159,7 +159,7 @@ struct AggParams {
   int32_t dense;
   int32_t key_bits;     // bits of the packed key in use
   int32_t lds_slots;    // power of two; 0 = no LDS pre-aggregation
-  int32_t window_hint;  // the planner put a time bucket in the key's high bits: the keys may be narrow at any one time
+  int32_t window_hint;  // non-zero: time buckets sit in the key's bits from (window_hint - 1) up, so the keys may be narrow at any one time
   uint64_t capacity;    // dense: number of entries; hash: power of two
   uint64_t* g_keys;     // hash only: capacity + 1 entries (last = the all-ones key)
   uint64_t* g_keys_hi;  // second key word of every entry when key_words == 2

@@ -605,22 +605,47 @@ __device__ __forceinline__ void lds_clear(const AggParams& p, const Lds<K32>& t)
   }
 }
 
+// Two partial values of one slot into one.
+__device__ __forceinline__ long long merge_partials(int op, long long a, long long b) {
+  if (op == kSlotMin) return a < b ? a : b;
+  if (op == kSlotMax) return a > b ? a : b;
+  if (op == kSlotAddF64) return __double_as_longlong(__longlong_as_double(a) + __longlong_as_double(b));
+  return (long long)((unsigned long long)a + (unsigned long long)b);
+}
+
 // Folds the LDS table into the HBM table and empties it.  Block-wide; the caller
 // brackets it with barriers.
 template <bool K32>
 __device__ __forceinline__ void lds_flush(const AggParams& p, const Lds<K32>& t) {
   const KeyT<K32> empty = (KeyT<K32>)~(KeyT<K32>)0;
-  for (int i = threadIdx.x; i < t.S; i += blockDim.x) {
-    KeyT<K32> key;
-    if (t.direct_rep_log2 >= 0) {
-      if (t.state[i] == 0) continue;  // slot 0 counts the rows of the entry
-      const uint32_t kmask = (1u << t.direct_key_bits) - 1u, rep = (uint32_t)i >> t.direct_key_bits;
-      if (rep >> t.direct_rep_log2) continue;  // beyond the replicas in use
-      key = (KeyT<K32>)(t.win_base + (((uint32_t)i - rep * 5u) & kmask));
-    } else {
-      key = t.keys[i];
-      if (key == empty) continue;
+  if (t.direct_rep_log2 >= 0) {
+    // Directly indexed: the replicas of a key are merged here, in LDS, so that HBM takes one
+    // atomic per key and slot instead of one per replica (a global atomic is a fabric
+    // transaction; with 4 replicas they were 4 % of the headline kernel).
+    const uint32_t n_keys = 1u << t.direct_key_bits, kmask = n_keys - 1u, reps = 1u << t.direct_rep_log2;
+    for (uint32_t k = threadIdx.x; k < n_keys; k += blockDim.x) {
+      uint64_t e = ~0ull;
+      for (int s = 0; s < p.n_slots; ++s) {
+        const int op = p.slots[s].op;
+        const long long identity = slot_identity(op);
+        long long v = identity;
+        for (uint32_t r = 0; r < reps; ++r) {
+          const uint32_t i = (r << t.direct_key_bits) | ((k + r * 5u) & kmask);
+          v = merge_partials(op, v, t.state[s * t.stride + i]);
+          t.state[s * t.stride + i] = identity;
+        }
+        if (s == 0) {
+          if (v == 0) break;  // slot 0 counts the rows: none means the other slots are untouched too
+          e = global_entry(p, (uint64_t)(t.win_base + k));
+        }
+        if (e != ~0ull && v != identity) atomic_apply(&p.g_state[(uint64_t)s * (p.capacity + 1) + e], op, v);
+      }
     }
+    return;
+  }
+  for (int i = threadIdx.x; i < t.S; i += blockDim.x) {
+    const KeyT<K32> key = t.keys[i];
+    if (key == empty) continue;
     uint64_t e = global_entry(p, (uint64_t)key);
     for (int s = 0; s < p.n_slots; ++s) {
       int op = p.slots[s].op;
@@ -695,13 +720,16 @@ __global__ __launch_bounds__(kStreamBlock) void k_group_by_stream(AggParams p) {
   }
   int window_moves = 0;
   uint64_t tiles_since_move = 0;
+  // A window starts at the first key seen, rounded down to a whole time bucket (not to a
+  // multiple of the window size: time-ordered rows only move up from there).
+  const uint32_t win_align = p.window_hint > 0 ? ~((1u << (p.window_hint - 1)) - 1u) : ~0u;
   for (uint64_t j = j0; j < j1; ++j) {
     convert<NK, NV, K32>(p, raw, rows);
     if (t.windowed && j == j0) {
       // the first window starts at the workgroup's first key
       if (threadIdx.x == 0) win.candidate = (uint32_t)rows.key[0];
       __syncthreads();
-      t.win_base = win.candidate & ~((1u << t.direct_key_bits) - 1u);
+      t.win_base = win.candidate & win_align;
       __syncthreads();
     }
     // The scheduling barriers keep the next step's loads from being hoisted above the
@@ -731,7 +759,7 @@ __global__ __launch_bounds__(kStreamBlock) void k_group_by_stream(AggParams p) {
           t.win_base = 0;
           lds_clear<K32>(p, t);
         } else {
-          t.win_base = cand & ~((1u << t.direct_key_bits) - 1u);
+          t.win_base = cand & win_align;
         }
         __syncthreads();
       }
