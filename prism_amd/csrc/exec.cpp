@@ -838,7 +838,9 @@ uint64_t emit_groups(prism_gpu_ctx* ctx, const prism_gpu_plan* plan, const prism
   ec.n_keys = (int)keys.size();
   for (size_t i = 0; i < keys.size(); ++i) {
     const KeyField& kf = layout.fields[i];
-    ec.keys[i] = {kf.word, kf.bit_pos, kf.bits, kf.null_bit, kf.bias, keys[i].date_bin ? 1 : 0, keys[i].stride, keys[i].origin};
+    const bool is_dict = table->fields[keys[i].column].is_string;
+    ec.keys[i] = {kf.word, kf.bit_pos, kf.bits, kf.null_bit, kf.bias, keys[i].date_bin ? 1 : 0, keys[i].stride, keys[i].origin,
+                  is_dict ? (unsigned long long)table->dicts[keys[i].column].values.size() : 0ull};
   }
   auto add = [&](int kind, int main_slot, int count_slot) {
     if (ec.n_aggs >= kMaxEmitAggs) fail(PRISM_GPU_EUNSUPPORTED, "too many aggregate output columns in one plan");
@@ -868,6 +870,7 @@ uint64_t emit_groups(prism_gpu_ctx* ctx, const prism_gpu_plan* plan, const prism
   uint64_t n = 0;
   const int64_t* h_vals = nullptr;
   const uint8_t* h_valid = nullptr;
+  uint64_t h_stride = 0;  // rows between two columns in the host block
   std::unique_lock<std::mutex> pinned_lock(ctx->result_mu, std::defer_lock);
   std::shared_ptr<void> lease;
   {
@@ -883,39 +886,56 @@ uint64_t emit_groups(prism_gpu_ctx* ctx, const prism_gpu_plan* plan, const prism
       use_order = &order;
     }
     auto emit = [&](int64_t* vals, uint8_t* valid, uint64_t stride, unsigned long long* count) {
-      PRISM_HIP(hipMemsetAsync(count, 0, 8, ctx->stream));
+      PRISM_HIP(hipMemsetAsync(count, 0, 16, ctx->stream));
       launch_emit_columns(ctx, gt.dense, gt.capacity, gt.keys.as<uint64_t>(), gt.keys_hi.as<uint64_t>(), gt.state.as<int64_t>(),
                           ec, vals, valid, stride, count, use_order, d_topk.as<TopKState>());
     };
     Scratch d_count(ctx, 256), d_vals, d_valid;
-    unsigned long long count = 0;
+    unsigned long long count[2] = {0, 0};  // groups emitted, "a dictionary code was out of range"
+    unsigned long long recount[2] = {0, 0};  // the same from the second pass over a large table
     uint64_t stride = 0;
+    bool fresh = true;
+    for (const OutColumn& oc : cols) fresh = fresh && oc.rows() == 0;
     // A table with few entries is compacted in one pass into buffers sized for all of them;
     // a large one is counted first.
     if (!use_order && entries * n_cols * 9 <= (48ull << 20)) {
       stride = entries;
-      d_vals = Scratch(ctx, stride * n_cols * 8);
-      d_valid = Scratch(ctx, stride * n_cols);
-      emit(d_vals.as<int64_t>(), d_valid.as<uint8_t>(), stride, d_count.as<unsigned long long>());
-      PRISM_HIP(hipMemcpyAsync(&count, d_count.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-      PRISM_HIP(hipStreamSynchronize(ctx->stream));
-    } else {
-      emit(nullptr, nullptr, 0, d_count.as<unsigned long long>());
-      PRISM_HIP(hipMemcpyAsync(&count, d_count.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-      PRISM_HIP(hipStreamSynchronize(ctx->stream));
-      if (count) {
-        stride = count;
+      if (fresh) {
+        // straight into a page-locked host block that the exported batch will point into:
+        // the kernel's stores cross PCIe while it is still scanning the table
+        lease = lease_pinned(ctx, (size_t)stride * n_cols * 9);
+        int64_t* vals = (int64_t*)lease.get();
+        uint8_t* valid = (uint8_t*)lease.get() + (size_t)stride * n_cols * 8;
+        emit(vals, valid, stride, d_count.as<unsigned long long>());
+        PRISM_HIP(hipMemcpyAsync(count, d_count.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+        PRISM_HIP(hipStreamSynchronize(ctx->stream));
+        h_vals = vals;
+        h_valid = valid;
+        h_stride = stride;
+      } else {
         d_vals = Scratch(ctx, stride * n_cols * 8);
         d_valid = Scratch(ctx, stride * n_cols);
         emit(d_vals.as<int64_t>(), d_valid.as<uint8_t>(), stride, d_count.as<unsigned long long>());
+        PRISM_HIP(hipMemcpyAsync(count, d_count.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+        PRISM_HIP(hipStreamSynchronize(ctx->stream));
+      }
+    } else {
+      emit(nullptr, nullptr, 0, d_count.as<unsigned long long>());
+      PRISM_HIP(hipMemcpyAsync(count, d_count.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+      PRISM_HIP(hipStreamSynchronize(ctx->stream));
+      if (count[0]) {
+        stride = count[0];
+        d_vals = Scratch(ctx, stride * n_cols * 8);
+        d_valid = Scratch(ctx, stride * n_cols);
+        emit(d_vals.as<int64_t>(), d_valid.as<uint8_t>(), stride, d_count.as<unsigned long long>());
+        PRISM_HIP(hipMemcpyAsync(recount, d_count.p, 16, hipMemcpyDeviceToHost, ctx->stream));  // lands with the copies below
       }
     }
-    n = count;
-    if (n) {
+    n = count[0];
+    if (n && !h_vals) {
       // HBM -> pinned host memory, compacted to n entries per column on the way
       const size_t need = (size_t)n * n_cols * 9;
-      bool fresh = need <= kLeasedResultMaxBytes;
-      for (const OutColumn& oc : cols) fresh = fresh && oc.rows() == 0;
+      fresh = fresh && need <= kLeasedResultMaxBytes;
       uint8_t* pin = nullptr;
       if (fresh) {
         lease = lease_pinned(ctx, need);
@@ -937,13 +957,17 @@ uint64_t emit_groups(prism_gpu_ctx* ctx, const prism_gpu_plan* plan, const prism
       PRISM_HIP(hipStreamSynchronize(ctx->stream));
       h_vals = (const int64_t*)pin;
       h_valid = pin + (size_t)n * n_cols * 8;
+      h_stride = n;
     }
+    if (!h_vals) lease.reset();
+    if (n == 0) lease.reset();
+    if (count[1] || recount[1]) fail(PRISM_GPU_EINTERNAL, "dictionary code out of range in result");
   }
   HostTimer ht(ctx, "host:assemble");
   for (size_t c = 0; c < n_cols && n; ++c) {
     OutColumn& oc = cols[c];
-    const int64_t* v = h_vals + c * n;
-    const uint8_t* ok = h_valid + c * n;
+    const int64_t* v = h_vals + c * h_stride;
+    const uint8_t* ok = h_valid + c * h_stride;
     const bool is_dict = c < keys.size() && table->fields[keys[c].column].is_string;
     uint64_t n_values = 0;
     if (is_dict) {
@@ -951,6 +975,8 @@ uint64_t emit_groups(prism_gpu_ctx* ctx, const prism_gpu_plan* plan, const prism
       if (oc.rows() == 0) oc.dict = &d.values;
       if (oc.dict != &d.values) fail(PRISM_GPU_EINTERNAL, "string key column built from two dictionaries");
       n_values = d.values.size();
+      // (the device has checked the codes against the dictionary size, unless there is no dictionary at all)
+      if (n_values == 0 && std::memchr(ok, 1, n) != nullptr) fail(PRISM_GPU_EINTERNAL, "dictionary code out of range in result");
     }
     if (lease) {
       // the exported batch points into the block: no copy

@@ -238,6 +238,9 @@ struct EmitKey {
   long long bias;
   int date_bin;
   long long stride, origin;
+  // dictionary-coded string key: the number of dictionary values (0 = not a code).  A
+  // non-NULL code at or above it sets out_count[1], so the host need not check every row.
+  unsigned long long n_values;
 };
 enum EmitAggKind {
   kEmitInt = 0,  // the main slot; NULL when a count slot is given and it is 0
@@ -257,6 +260,8 @@ struct EmitColumns {
 };
 // out_values: [n_keys + n_aggs][stride] 8-byte values, out_valid: the same shape in bytes
 // (1 = not NULL).  out_values == nullptr: count only.  order / d_threshold as launch_emit.
+// out_count points at two words: [0] the number of groups emitted, [1] set to 1 on a
+// dictionary code out of range.  The outputs may be page-locked host memory.
 void launch_emit_columns(prism_gpu_ctx* ctx, bool dense, uint64_t capacity, const uint64_t* g_keys, const uint64_t* g_keys_hi,
                          const int64_t* g_state, const EmitColumns& cols, int64_t* out_values, uint8_t* out_valid,
                          uint64_t stride, unsigned long long* out_count, const TopKOrder* order, TopKState* d_threshold);

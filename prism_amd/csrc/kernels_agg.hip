@@ -650,6 +650,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_columns(int dense, uint64_t cap
       const uint64_t mask = ek.bits == 0 ? 0ull : (~0ull >> (64 - ek.bits));
       long long v = (long long)((uint64_t)ek.bias + ((packed >> ek.bit_pos) & mask));
       if (ek.date_bin) v = (long long)((uint64_t)ek.origin + (uint64_t)v * (uint64_t)ek.stride);
+      if (ek.n_values && valid && (unsigned long long)v >= ek.n_values) out_count[1] = 1ull;
       out_values[(uint64_t)c * stride + pos] = valid ? v : 0;
       out_valid[(uint64_t)c * stride + pos] = valid ? 1 : 0;
     }
