@@ -657,8 +657,14 @@ __device__ __forceinline__ void lds_flush(const AggParams& p, const Lds<K32>& t)
   }
 }
 
+#ifdef PRISM_STREAM_WAVES_PER_EU
+#define PRISM_STREAM_OCCUPANCY __attribute__((amdgpu_waves_per_eu(PRISM_STREAM_WAVES_PER_EU, PRISM_STREAM_WAVES_PER_EU)))
+#else
+#define PRISM_STREAM_OCCUPANCY
+#endif
+
 template <int NK, int NV, bool K32>
-__global__ __launch_bounds__(kStreamBlock) void k_group_by_stream(AggParams p) {
+__global__ __launch_bounds__(kStreamBlock) PRISM_STREAM_OCCUPANCY void k_group_by_stream(AggParams p) {
   extern __shared__ __align__(16) unsigned long long lds_raw[];
   __shared__ int n_entries;
   Lds<K32> t;
