@@ -1030,6 +1030,44 @@ namespace {
 }  // namespace
 
 namespace {
+
+// WHERE inside the aggregation kernel.  The predicate qualifies when it is one leaf, or a
+// conjunction or a disjunction of at most kMaxFusedLeaves leaves, each a comparison of a
+// fixed-width integer column with a literal or an IS [NOT] NULL on such a column (NOT has
+// been pushed into the leaves at plan time, so the TRUE rows of AND / OR are the
+// intersection / union of the leaves' TRUE rows).  Collects the leaves; `is_or` tells how
+// they combine.
+// Share of the rows a leaf is expected to keep, from the column's min / max / NULL count
+// over the scan and a uniform distribution in between.
+double leaf_selectivity(const ScanSet& ss, const PredNode& n) {
+  const ColInfo ci = col_info(ss, n.column);
+  const double rows = (double)std::max<uint64_t>(1, ss.rows);
+  const double not_null = 1.0 - std::min(1.0, (double)ci.nulls / rows);
+  if (n.kind == PredNode::IS_NULL) return 1.0 - not_null;
+  if (n.kind == PredNode::IS_NOT_NULL) return not_null;
+  if (ci.min > ci.max) return 0.0;
+  const double lo = (double)ci.min, hi = (double)ci.max, lit = (double)n.lit_i64, range = hi - lo + 1.0;
+  auto clamp01 = [](double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); };
+  double f = 0.0;
+  if (n.cmp_mask & kLt) f += clamp01((lit - lo) / range);
+  if (n.cmp_mask & kEq) f += (lit >= lo && lit <= hi) ? 1.0 / range : 0.0;
+  if (n.cmp_mask & kGt) f += clamp01((hi - lit) / range);
+  return clamp01(f) * not_null;
+}
+
+bool fusable_leaves(const prism_gpu_plan* p, const prism_gpu_table* t, int node, int combiner, std::vector<int>& leaves) {
+  const PredNode& n = p->pred[node];
+  if (n.kind == PredNode::AND || n.kind == PredNode::OR) {
+    if (combiner >= 0 && combiner != (int)n.kind) return false;
+    return fusable_leaves(p, t, n.lhs, (int)n.kind, leaves) && fusable_leaves(p, t, n.rhs, (int)n.kind, leaves);
+  }
+  if (n.kind != PredNode::CMP && n.kind != PredNode::IS_NULL && n.kind != PredNode::IS_NOT_NULL) return false;
+  const FieldType& f = t->fields[n.column];
+  if (f.is_string || f.is_float || (f.is_unsigned && f.width == 8)) return false;
+  leaves.push_back(node);
+  return leaves.size() <= (size_t)kMaxFusedLeaves;
+}
+
 void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions,
                   bool merge_input, ArrowArray* out, const prism_gpu_col_stats* stats_override, prism_gpu_state** capture);
 }
@@ -1126,7 +1164,53 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
                     plan->aggs[0].func == PRISM_AGG_COUNT_STAR && plan->pred[plan->pred_root].kind == PredNode::CMP &&
                     !table->fields[plan->pred[plan->pred_root].column].is_string;
   if (has_pred && count_only) ss.use(plan->pred[plan->pred_root].column, false);
-  if (has_pred && !count_only) {
+  // Simple predicates are evaluated by the aggregation kernel itself: no bitmap pass, and
+  // a predicate on a column the aggregates read anyway costs no memory traffic at all.
+  bool fused = false;
+  if (has_pred && !count_only && !plan->distinct_plan && layout.words == 1) {
+    std::vector<int> leaves;
+    if (fusable_leaves(plan, table, plan->pred_root, -1, leaves)) {
+      AggParams trial = ap;
+      trial.n_keys = (int)layout.specs.size();
+      for (size_t i = 0; i < layout.specs.size(); ++i) trial.keys[i] = layout.specs[i];
+      trial.key_bits = plan->keys.empty() ? 0 : layout.total_bits;
+      trial.key_words = 1;
+      trial.lds_slots = lds_slots_for(trial.n_slots);
+      trial.row_mode = kRowsAll;
+      trial.n_pred = (int)leaves.size();
+      trial.pred_or = plan->pred[plan->pred_root].kind == PredNode::OR ? 1 : 0;
+      bool fits = true;
+      for (size_t l = 0; l < leaves.size() && fits; ++l) {
+        const PredNode& n = plan->pred[leaves[l]];
+        const FieldType& f = table->fields[n.column];
+        const int col = ss.use(n.column, false);
+        int v = 0;
+        while (v < trial.n_vals && trial.vals[v].col != col) ++v;
+        if (v == trial.n_vals) {
+          if (trial.n_vals >= kMaxVals) { fits = false; break; }
+          trial.vals[v] = {col, f.width, f.is_unsigned ? 1 : 0, 0};
+          trial.n_vals += 1;
+        }
+        trial.pred[l] = {v, n.kind == PredNode::CMP ? kLeafCmp : (n.kind == PredNode::IS_NULL ? kLeafIsNull : kLeafIsNotNull),
+                         n.cmp_mask, 0, (long long)n.lit_i64};
+      }
+      // Few expected survivors: the bitmap pass followed by a gather of only those rows is
+      // cheaper than streaming every column of every row through the aggregation kernel.
+      double keep = trial.pred_or ? 0.0 : 1.0;
+      for (int leaf : leaves) {
+        const double f = leaf_selectivity(ss, plan->pred[leaf]);
+        keep = trial.pred_or ? 1.0 - (1.0 - keep) * (1.0 - f) : keep * f;
+      }
+      if (fits && keep >= 1.0 / 16 && group_by_streams(trial)) {
+        const int n_keys = ap.n_keys, key_bits = ap.key_bits, key_words = ap.key_words, lds_slots = ap.lds_slots;
+        ap = trial;
+        // (the branches below set these for their own shape)
+        ap.n_keys = n_keys; ap.key_bits = key_bits; ap.key_words = key_words; ap.lds_slots = lds_slots;
+        fused = true;
+      }
+    }
+  }
+  if (has_pred && !count_only && !fused) {
     // register every column the predicate touches before the upload
     for (const PredNode& n : plan->pred)
       if (n.column >= 0) ss.use(n.column, leaf_uses_codes(table, ss, n));
@@ -1161,7 +1245,12 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
     return;
   }
   Scratch selvec;
-  if (has_pred) {
+  unsigned long long fused_selected = 0;  // filled in by the kernel, valid after the next stream synchronisation
+  if (fused) {
+    ap.row_mode = kRowsAll;
+    ap.selected_out = d_scalar.as<unsigned long long>();
+  }
+  if (has_pred && !fused) {
     sel.all = false;
     sel.bits = pe.eval(plan->pred_root);
     PRISM_HIP(hipMemsetAsync(d_scalar.p, 0, 8, ctx->stream));
@@ -1194,19 +1283,20 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
   for (int j = 0; j < ap.n_vals; ++j) value_bytes += ap.vals[j].width;
   for (auto& s : layout.specs) value_bytes += s.width;
 
-  if ((ss.chunks.empty() || selected == 0) && !capture) {
-    // no input rows: an ungrouped aggregate still yields one row
-    if (plan->keys.empty()) {
-      size_t c = 0;
-      if (partial && plan->distinct_plan) cols[c++].push_null();
-      else for (const AggPlan& a : plan->aggs) {
-        bool is_count = a.func == PRISM_AGG_COUNT_STAR || a.func == PRISM_AGG_COUNT || a.func == PRISM_AGG_COUNT_DISTINCT;
-        if (is_count) cols[c++].push_int(0);
-        else if (a.func == PRISM_AGG_AVG && partial) { cols[c++].push_int(0); cols[c++].push_null(); }
-        else cols[c++].push_null();
-      }
-      groups_out = 1;
+  // no input rows: an ungrouped aggregate still yields one row
+  auto empty_input_row = [&]() {
+    size_t c = 0;
+    if (partial && plan->distinct_plan) cols[c++].push_null();
+    else for (const AggPlan& a : plan->aggs) {
+      bool is_count = a.func == PRISM_AGG_COUNT_STAR || a.func == PRISM_AGG_COUNT || a.func == PRISM_AGG_COUNT_DISTINCT;
+      if (is_count) cols[c++].push_int(0);
+      else if (a.func == PRISM_AGG_AVG && partial) { cols[c++].push_int(0); cols[c++].push_null(); }
+      else cols[c++].push_null();
     }
+    groups_out = 1;
+  };
+  if ((ss.chunks.empty() || selected == 0) && !capture) {
+    if (plan->keys.empty()) empty_input_row();
   } else if (plan->keys.empty() && !plan->distinct_plan) {
     // ---- ungrouped aggregates ----
     GroupRows g;
@@ -1231,11 +1321,14 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       ap.g_keys_hi = nullptr;
       ap.g_state = gt.state.as<int64_t>();
       ap.overflow = gt.overflow.as<uint32_t>();
+      if (fused) PRISM_HIP(hipMemsetAsync(d_scalar.p, 0, 8, ctx->stream));
       launch_group_by(ctx, ap, agg_bytes, "agg_global");
       std::vector<int64_t> both((size_t)ap.n_slots * 2);  // entry 0 and the unused extra entry of every slot
       PRISM_HIP(hipMemcpyAsync(both.data(), gt.state.p, both.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+      if (fused) PRISM_HIP(hipMemcpyAsync(&fused_selected, d_scalar.p, 8, hipMemcpyDeviceToHost, ctx->stream));
       PRISM_HIP(hipStreamSynchronize(ctx->stream));
       for (int s = 0; s < ap.n_slots; ++s) g.state[s] = both[(size_t)s * 2];
+      if (fused) selected = fused_selected;
     } else {
       // a selection vector of few rows: gather them
       std::vector<int64_t> init(ap.n_slots);
@@ -1249,7 +1342,9 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       PRISM_HIP(hipMemcpyAsync(g.state.data(), d_out.p, g.state.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
       PRISM_HIP(hipStreamSynchronize(ctx->stream));
     }
-    append_agg_columns(low, g, partial, cols, 0);
+    // (a predicate evaluated in the kernel may turn out to select nothing)
+    if (selected == 0) empty_input_row();
+    else append_agg_columns(low, g, partial, cols, 0);
     groups_out = 1;
   } else {
     // ---- GROUP BY ----
@@ -1306,12 +1401,15 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       ap.g_keys_hi = gt.keys_hi.as<uint64_t>();
       ap.g_state = gt.state.as<int64_t>();
       ap.overflow = gt.overflow.as<uint32_t>();
+      if (fused) PRISM_HIP(hipMemsetAsync(d_scalar.p, 0, 8, ctx->stream));
       launch_group_by(ctx, ap, (ap.row_mode == kRowsSelvec ? selected : ss.rows) * value_bytes);
       if (dense || !table_overflowed(ctx, gt)) break;
       if (capacity >= max_capacity) fail(PRISM_GPU_EINTERNAL, "group table overflow at maximum capacity");
       capacity = std::min(max_capacity, capacity * 4);  // more groups than expected: grow and redo the pass
     }
     if (!dense) plan->learned_capacity.store(capacity, std::memory_order_relaxed);
+    // lands with the next synchronisation of the stream (every path below has one before the statistics)
+    if (fused) PRISM_HIP(hipMemcpyAsync(&fused_selected, d_scalar.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     if (capture) {
       if (layout.words != 1) fail(PRISM_GPU_EUNSUPPORTED, "device-resident aggregate state needs a packed key of at most 64 bits");
       PRISM_HIP(hipStreamSynchronize(ctx->stream));
@@ -1324,6 +1422,7 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       st->low = low;
       st->gt = std::move(gt);
       st->slot_ops = slot_ops;
+      if (fused) selected = fused_selected;
       {
         std::lock_guard<std::mutex> g(ctx->mu);
         ctx->stats.rows_scanned += ss.rows;
@@ -1401,6 +1500,7 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
   }
   PRISM_HIP(hipStreamSynchronize(ctx->stream));
   collect_timings(ctx);
+  if (fused && !plan->keys.empty()) selected = fused_selected;
   if (!partial) sort_and_limit(plan, cols);
   {
     std::lock_guard<std::mutex> g(ctx->mu);

@@ -127,6 +127,18 @@ struct ValSpec {
   int32_t is_float;  // values are f64 bit patterns (PARTIAL AVG sums)
 };
 
+// One leaf of a predicate evaluated inside the aggregation kernel, on a column that is
+// loaded as one of the plan's values.  A NULL input never makes a leaf TRUE, except IS NULL.
+enum FusedLeafKind { kLeafCmp = 0, kLeafIsNull = 1, kLeafIsNotNull = 2 };
+struct FusedLeaf {
+  int32_t val;       // index into AggParams::vals
+  int32_t kind;      // FusedLeafKind
+  int32_t cmp_mask;  // CmpMask of a comparison with `lit`
+  int32_t pad;
+  long long lit;
+};
+constexpr int kMaxFusedLeaves = 4;
+
 enum SlotOp {
   kSlotAddOne = 0,   // += 1 per row
   kSlotAddValid = 1, // += 1 per non-NULL value
@@ -165,6 +177,12 @@ struct AggParams {
   uint64_t* g_keys_hi;  // second key word of every entry when key_words == 2
   int32_t key_words;    // 1, or 2 for packed keys of 65..127 bits (hash table only, no LDS stage)
   int32_t keys_only;    // two-word keys: only the set of keys is wanted (COUNT(DISTINCT)'s inner level), no accumulators
+  // WHERE evaluated in the kernel (streaming kernel only): a row counts when all
+  // (pred_or = 0) or any (pred_or = 1) of the leaves are TRUE; the rows that pass are
+  // counted into *selected_out
+  int32_t n_pred, pred_or;
+  FusedLeaf pred[kMaxFusedLeaves];
+  unsigned long long* selected_out;
   int64_t* g_state;     // n_slots arrays of (capacity + 1) entries
   uint32_t* overflow;   // set to 1 when the hash table is full
 };
@@ -180,6 +198,9 @@ GroupByKernel pick_stream_kernel(const AggParams& p, size_t* lds_bytes, uint32_t
 // Ungrouped aggregates: out[n_slots] must hold the slot identities on entry.
 void launch_agg_global(prism_gpu_ctx* ctx, const AggParams& p, int64_t* out);
 // GROUP BY: accumulates into p.g_keys / p.g_state.
+// Whether launch_group_by would run the plan on the streaming kernel (the only one that
+// evaluates AggParams::pred).  Looks at n_keys, keys, key_bits, key_words, n_vals, lds_slots, row_mode.
+bool group_by_streams(const AggParams& p);
 void launch_group_by(prism_gpu_ctx* ctx, const AggParams& p, uint64_t algorithmic_bytes, const char* stat_name = "group_by");
 // Second level of COUNT(DISTINCT x) GROUP BY k: every occupied entry of the
 // (k, x) set adds 1 (when its x field is not NULL) to group k of table `q`.

@@ -693,8 +693,17 @@ void launch_agg_global(prism_gpu_ctx* ctx, const AggParams& p, int64_t* out) {
   PRISM_HIP(hipGetLastError());
 }
 
+bool group_by_streams(const AggParams& p) {
+  if (p.key_words == 2 || p.row_mode == kRowsSelvec || p.lds_slots <= 0) return false;
+  size_t lds = 0;
+  uint32_t block = 0;
+  int slots = 0;
+  return pick_stream_kernel(p, &lds, &block, &slots) != nullptr;
+}
+
 void launch_group_by(prism_gpu_ctx* ctx, const AggParams& params, uint64_t algorithmic_bytes, const char* stat_name) {
   AggParams p = params;
+  if (p.n_pred > 0 && !group_by_streams(p)) fail(PRISM_GPU_EINTERNAL, "in-kernel predicate on a plan the streaming kernel does not run");
   uint64_t work = p.row_mode == kRowsSelvec ? ceil_div(p.n_sel, (uint64_t)kBlock * 16) : p.sd.n_tiles;
   if (work == 0) return;
   size_t lds = (size_t)p.lds_slots * 8 * (1 + p.n_slots);

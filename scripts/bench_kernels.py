@@ -30,6 +30,7 @@ def main():
         ("C2", wl.query),
         ("C2 + AVG MIN", QueryPlan([count_star(), sum_("value"), max_("value"), min_("value"), avg("value")],
                                    keys=[date_bin(60_000, "timestamp"), "service"])),
+        ("C2 WHERE value >= 0 (100 %)", QueryPlan(wl.query.aggs, keys=wl.query.keys, predicate=col("value") >= 0)),
         ("C2 WHERE value >= 25000 (50 %)", QueryPlan(wl.query.aggs, keys=wl.query.keys, predicate=col("value") >= 25_000)),
         ("C2 WHERE value >= 49900 (0.2 %)", QueryPlan(wl.query.aggs, keys=wl.query.keys, predicate=col("value") >= 49_900)),
         ("C2 WHERE service LIKE '%-0%'", QueryPlan(wl.query.aggs, keys=wl.query.keys, predicate=col("service").like("%-0%"))),
