@@ -937,7 +937,9 @@ __global__ __launch_bounds__(kStreamBlock) PRISM_STREAM_OCCUPANCY void k_group_b
 template <int NK, bool K32, bool PRED>
 GroupByKernel pick_nv(int nv) {
   switch (nv) {
-    case 0: return PRED ? nullptr : k_group_by_stream<NK, 0, K32, false>;  // a predicate reads at least one value column
+    case 0:  // a predicate reads at least one value column
+      if constexpr (PRED) return nullptr;
+      else return k_group_by_stream<NK, 0, K32, false>;
     case 1: return k_group_by_stream<NK, 1, K32, PRED>;
     case 2: return k_group_by_stream<NK, 2, K32, PRED>;
     case 3: return k_group_by_stream<NK, 3, K32, PRED>;
@@ -960,6 +962,16 @@ GroupByKernel pick_nk(int nk, int nv) {
 
 }  // namespace
 
+// The kernels that evaluate a predicate are instantiated in a translation unit of their
+// own (kernels_stream_pred.hip includes this file with PRISM_STREAM_PRED_TU defined), so
+// that the two halves compile in parallel.
+GroupByKernel pick_stream_kernel_pred(bool k32, int n_keys, int n_vals);
+
+#ifdef PRISM_STREAM_PRED_TU
+GroupByKernel pick_stream_kernel_pred(bool k32, int n_keys, int n_vals) {
+  return k32 ? pick_nk<true, true>(n_keys, n_vals) : pick_nk<false, true>(n_keys, n_vals);
+}
+#else
 GroupByKernel pick_stream_kernel(const AggParams& p, size_t* lds_bytes, uint32_t* block, int* lds_slots) {
   bool k32 = p.key_bits <= 31;
   for (int k = 0; k < p.n_keys; ++k) k32 = k32 && p.keys[k].fast32 != 0;
@@ -971,9 +983,9 @@ GroupByKernel pick_stream_kernel(const AggParams& p, size_t* lds_bytes, uint32_t
   *lds_slots = S;
   *block = kStreamBlock;
   *lds_bytes = (size_t)(S + kScratchEntries) * 8 * (size_t)p.n_slots + (size_t)S * (k32 ? 4 : 8);
-  if (p.n_pred > 0)
-    return k32 ? pick_nk<true, true>(p.n_keys, p.n_vals) : pick_nk<false, true>(p.n_keys, p.n_vals);
+  if (p.n_pred > 0) return pick_stream_kernel_pred(k32, p.n_keys, p.n_vals);
   return k32 ? pick_nk<true, false>(p.n_keys, p.n_vals) : pick_nk<false, false>(p.n_keys, p.n_vals);
 }
+#endif
 
 }  // namespace prism
