@@ -1180,9 +1180,26 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       trial.n_pred = (int)leaves.size();
       trial.pred_or = plan->pred[plan->pred_root].kind == PredNode::OR ? 1 : 0;
       bool fits = true;
+      // the kernel variant with 32-bit keys (the same test pick_stream_kernel makes)
+      bool k32 = trial.key_bits <= 31;
+      for (int k = 0; k < trial.n_keys; ++k) k32 = k32 && trial.keys[k].fast32 != 0;
       for (size_t l = 0; l < leaves.size() && fits; ++l) {
         const PredNode& n = plan->pred[leaves[l]];
         const FieldType& f = table->fields[n.column];
+        const int kind = n.kind == PredNode::CMP ? kLeafCmp : (n.kind == PredNode::IS_NULL ? kLeafIsNull : kLeafIsNotNull);
+        // A column that is a GROUP BY key is loaded already: read it from there (WHERE on the
+        // timestamp that is also bucketed is the everyday query).  The 32-bit-key kernel holds
+        // the low word only, which is enough: value - base is below 2^32 for every row.
+        int from_key = -1;
+        for (size_t i = 0; i < keys.size() && from_key < 0; ++i)
+          if (keys[i].column == n.column && (k32 ? trial.keys[i].width >= 4 : trial.keys[i].width == 8)) from_key = (int)i;
+        if (from_key >= 0) {
+          const KeySpec& ks = trial.keys[from_key];
+          const __int128 rel = (__int128)n.lit_i64 - (__int128)ks.base;
+          const long long lit_k32 = rel < -1 ? -1ll : (rel > ((__int128)1 << 32) ? (1ll << 32) : (long long)rel);
+          trial.pred[l] = {-(from_key + 1), kind, n.cmp_mask, (uint32_t)(uint64_t)ks.base, (long long)n.lit_i64, lit_k32};
+          continue;
+        }
         const int col = ss.use(n.column, false);
         int v = 0;
         while (v < trial.n_vals && trial.vals[v].col != col) ++v;
@@ -1191,8 +1208,7 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
           trial.vals[v] = {col, f.width, f.is_unsigned ? 1 : 0, 0};
           trial.n_vals += 1;
         }
-        trial.pred[l] = {v, n.kind == PredNode::CMP ? kLeafCmp : (n.kind == PredNode::IS_NULL ? kLeafIsNull : kLeafIsNotNull),
-                         n.cmp_mask, 0, (long long)n.lit_i64};
+        trial.pred[l] = {v, kind, n.cmp_mask, 0u, (long long)n.lit_i64, 0ll};
       }
       // Few expected survivors: the bitmap pass followed by a gather of only those rows is
       // cheaper than streaming every column of every row through the aggregation kernel.

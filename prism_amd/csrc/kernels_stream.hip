@@ -269,7 +269,7 @@ __device__ __forceinline__ uint32_t fast_div32(uint32_t n, uint32_t magic, int p
 // atomics of the step before (measured: +25 % on the headline shape).
 struct FusedRegs {
   int n, is_or;
-  int val[kMaxFusedLeaves], kind[kMaxFusedLeaves], cmp_mask[kMaxFusedLeaves];
+  int val[kMaxFusedLeaves], kind[kMaxFusedLeaves], cmp_mask[kMaxFusedLeaves], base32[kMaxFusedLeaves];
   long long lit[kMaxFusedLeaves];
 };
 
@@ -279,6 +279,7 @@ __device__ __forceinline__ int pin_scalar(int v) {
   return v;
 }
 
+template <bool K32>
 __device__ __forceinline__ void load_fused_regs(const AggParams& p, FusedRegs& r) {
   r.n = pin_scalar(p.n_pred);
   r.is_or = pin_scalar(p.pred_or);
@@ -287,64 +288,88 @@ __device__ __forceinline__ void load_fused_regs(const AggParams& p, FusedRegs& r
     r.val[l] = pin_scalar(p.pred[l].val);
     r.kind[l] = pin_scalar(p.pred[l].kind);
     r.cmp_mask[l] = pin_scalar(p.pred[l].cmp_mask);
-    const int lo = pin_scalar((int)(uint32_t)(unsigned long long)p.pred[l].lit);
-    const int hi = pin_scalar((int)(uint32_t)((unsigned long long)p.pred[l].lit >> 32));
+    r.base32[l] = pin_scalar((int)p.pred[l].key_base32);
+    // a leaf on a key of a 32-bit-key kernel compares in the key's 32-bit domain
+    const long long lit = (K32 && p.pred[l].val < 0) ? p.pred[l].lit_k32 : p.pred[l].lit;
+    const int lo = pin_scalar((int)(uint32_t)(unsigned long long)lit);
+    const int hi = pin_scalar((int)(uint32_t)((unsigned long long)lit >> 32));
     r.lit[l] = (long long)(((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo);
   }
 }
 
 template <int L, int NK, int NV, bool K32>
-__device__ __forceinline__ void fused_leaf(const FusedRegs& r, const PackedRows<NK, NV, K32>& rows, uint64_t (&mask)[kU]) {
+__device__ __forceinline__ void fused_leaf(const FusedRegs& r, const RowBatch<NK, NV, K32>& raw, const PackedRows<NK, NV, K32>& rows,
+                                           uint64_t (&mask)[kU]) {
   if (L >= r.n) return;
   const long long lit = r.lit[L];
-  uint64_t m[kU];
+  // the leaf's input: kU values and the lanes where it is not NULL
+  long long x[kU];
+  uint64_t ok[kU];
 #pragma unroll
-  for (int u = 0; u < kU; ++u) m[u] = 0;
+  for (int u = 0; u < kU; ++u) { x[u] = 0; ok[u] = 0; }
+  if (r.val[L] >= 0) {
 #pragma unroll
-  for (int v = 0; v < NV; ++v) {
-    if (v != r.val[L]) continue;
-    // one scalar branch per leaf and step picks the comparison; the rows are then one v_cmp each
-    if (r.kind[L] == kLeafIsNull) {
+    for (int v = 0; v < NV; ++v) {
+      if (v != r.val[L]) continue;
 #pragma unroll
-      for (int u = 0; u < kU; ++u) m[u] = ~rows.vok[v][u];
-    } else if (r.kind[L] == kLeafIsNotNull) {
-#pragma unroll
-      for (int u = 0; u < kU; ++u) m[u] = rows.vok[v][u];
-    } else {
-      switch (r.cmp_mask[L]) {
-        case kLt:
-#pragma unroll
-          for (int u = 0; u < kU; ++u) m[u] = __ballot(rows.val[v][u] < lit);
-          break;
-        case kLt | kEq:
-#pragma unroll
-          for (int u = 0; u < kU; ++u) m[u] = __ballot(rows.val[v][u] <= lit);
-          break;
-        case kEq:
-#pragma unroll
-          for (int u = 0; u < kU; ++u) m[u] = __ballot(rows.val[v][u] == lit);
-          break;
-        case kLt | kGt:
-#pragma unroll
-          for (int u = 0; u < kU; ++u) m[u] = __ballot(rows.val[v][u] != lit);
-          break;
-        case kGt | kEq:
-#pragma unroll
-          for (int u = 0; u < kU; ++u) m[u] = __ballot(rows.val[v][u] >= lit);
-          break;
-        case kGt:
-#pragma unroll
-          for (int u = 0; u < kU; ++u) m[u] = __ballot(rows.val[v][u] > lit);
-          break;
-        case kLt | kEq | kGt:
-#pragma unroll
-          for (int u = 0; u < kU; ++u) m[u] = ~0ull;
-          break;
-        default: break;  // no ordering satisfies it: never TRUE
-      }
-#pragma unroll
-      for (int u = 0; u < kU; ++u) m[u] &= rows.vok[v][u];
+      for (int u = 0; u < kU; ++u) { x[u] = rows.val[v][u]; ok[u] = rows.vok[v][u]; }
     }
+  } else {
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      if (k != -r.val[L] - 1) continue;
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        if (K32) x[u] = (long long)(unsigned long long)(uint32_t)((uint32_t)raw.kraw[k][u] - (uint32_t)r.base32[L]);
+        else x[u] = (long long)raw.kraw[k][u];
+        ok[u] = raw.knull[k] ? uniform_u64(raw.kokw[k][u]) : ~0ull;
+      }
+    }
+  }
+  uint64_t m[kU];
+  // one scalar branch per leaf and step picks the comparison; the rows are then one v_cmp each
+  if (r.kind[L] == kLeafIsNull) {
+#pragma unroll
+    for (int u = 0; u < kU; ++u) m[u] = ~ok[u];
+  } else if (r.kind[L] == kLeafIsNotNull) {
+#pragma unroll
+    for (int u = 0; u < kU; ++u) m[u] = ok[u];
+  } else {
+#pragma unroll
+    for (int u = 0; u < kU; ++u) m[u] = 0;
+    switch (r.cmp_mask[L]) {
+      case kLt:
+#pragma unroll
+        for (int u = 0; u < kU; ++u) m[u] = __ballot(x[u] < lit);
+        break;
+      case kLt | kEq:
+#pragma unroll
+        for (int u = 0; u < kU; ++u) m[u] = __ballot(x[u] <= lit);
+        break;
+      case kEq:
+#pragma unroll
+        for (int u = 0; u < kU; ++u) m[u] = __ballot(x[u] == lit);
+        break;
+      case kLt | kGt:
+#pragma unroll
+        for (int u = 0; u < kU; ++u) m[u] = __ballot(x[u] != lit);
+        break;
+      case kGt | kEq:
+#pragma unroll
+        for (int u = 0; u < kU; ++u) m[u] = __ballot(x[u] >= lit);
+        break;
+      case kGt:
+#pragma unroll
+        for (int u = 0; u < kU; ++u) m[u] = __ballot(x[u] > lit);
+        break;
+      case kLt | kEq | kGt:
+#pragma unroll
+        for (int u = 0; u < kU; ++u) m[u] = ~0ull;
+        break;
+      default: break;  // no ordering satisfies it: never TRUE
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) m[u] &= ok[u];
   }
   if (r.is_or) {
 #pragma unroll
@@ -356,18 +381,19 @@ __device__ __forceinline__ void fused_leaf(const FusedRegs& r, const PackedRows<
 }
 
 template <int NK, int NV, bool K32, int... L>
-__device__ __forceinline__ void fused_predicate_leaves(const FusedRegs& r, const PackedRows<NK, NV, K32>& rows, uint64_t (&mask)[kU],
+__device__ __forceinline__ void fused_predicate_leaves(const FusedRegs& r, const RowBatch<NK, NV, K32>& raw,
+                                                       const PackedRows<NK, NV, K32>& rows, uint64_t (&mask)[kU],
                                                        std::integer_sequence<int, L...>) {
-  (fused_leaf<L, NK, NV, K32>(r, rows, mask), ...);
+  (fused_leaf<L, NK, NV, K32>(r, raw, rows, mask), ...);
 }
 
 // Clears the rows that fail the predicate from rows.live and returns how many remain.
 template <int NK, int NV, bool K32>
-__device__ __forceinline__ uint32_t fused_predicate(const FusedRegs& r, PackedRows<NK, NV, K32>& rows) {
+__device__ __forceinline__ uint32_t fused_predicate(const FusedRegs& r, const RowBatch<NK, NV, K32>& raw, PackedRows<NK, NV, K32>& rows) {
   uint64_t mask[kU];
 #pragma unroll
   for (int u = 0; u < kU; ++u) mask[u] = r.is_or ? 0ull : ~0ull;
-  fused_predicate_leaves<NK, NV, K32>(r, rows, mask, std::make_integer_sequence<int, kMaxFusedLeaves>{});
+  fused_predicate_leaves<NK, NV, K32>(r, raw, rows, mask, std::make_integer_sequence<int, kMaxFusedLeaves>{});
   uint32_t n = 0;
 #pragma unroll
   for (int u = 0; u < kU; ++u) {
@@ -783,8 +809,18 @@ __device__ __forceinline__ void lds_flush(const AggParams& p, const Lds<K32>& t)
 #define PRISM_STREAM_OCCUPANCY
 #endif
 
+// Two 512-thread workgroups share a CU only when a wave needs at most 128 registers.  The
+// variants that come out a little above that are told to fit; the wider ones would spill.
+constexpr int stream_min_waves(int nk, int nv, bool k32) {
+#ifdef PRISM_STREAM_FIT_ALL
+  return PRISM_STREAM_FIT_ALL;
+#else
+  return (nv <= 2 && (k32 || nk + nv <= 2)) ? 4 : 1;
+#endif
+}
+
 template <int NK, int NV, bool K32, bool PRED>
-__global__ __launch_bounds__(kStreamBlock) PRISM_STREAM_OCCUPANCY void k_group_by_stream(AggParams p) {
+__global__ __launch_bounds__(kStreamBlock, stream_min_waves(NK, NV, K32)) PRISM_STREAM_OCCUPANCY void k_group_by_stream(AggParams p) {
   extern __shared__ __align__(16) unsigned long long lds_raw[];
   __shared__ int n_entries;
   Lds<K32> t;
@@ -824,7 +860,7 @@ __global__ __launch_bounds__(kStreamBlock) PRISM_STREAM_OCCUPANCY void k_group_b
   uint64_t rows_since_flush = 0;
   uint64_t n_selected = 0;  // rows that passed the in-kernel predicate (wave-uniform)
   FusedRegs fused;
-  if constexpr (PRED) load_fused_regs(p, fused);
+  if constexpr (PRED) load_fused_regs<K32>(p, fused);
   bool insert = true;  // false once the table is frozen
 
   SegCursor<NK, NV> cur;
@@ -838,7 +874,7 @@ __global__ __launch_bounds__(kStreamBlock) PRISM_STREAM_OCCUPANCY void k_group_b
       for (int s = 0; s < kUngroupedSlots; ++s) acc[s] = s < p.n_slots ? slot_identity(p.slots[s].op) : 0;
       for (uint64_t j = j0; j < j1; ++j) {
         convert<NK, NV, K32>(p, raw, rows);
-        if constexpr (PRED) n_selected += fused_predicate<NK, NV, K32>(fused, rows);
+        if constexpr (PRED) n_selected += fused_predicate<NK, NV, K32>(fused, raw, rows);
         __builtin_amdgcn_sched_barrier(0);
         if (j + 1 < j1) issue<NK, NV, K32>(p, j + 1, wave, lane, cur, raw);
         __builtin_amdgcn_sched_barrier(0);
@@ -856,7 +892,7 @@ __global__ __launch_bounds__(kStreamBlock) PRISM_STREAM_OCCUPANCY void k_group_b
   const uint32_t win_align = p.window_hint > 0 ? ~((1u << (p.window_hint - 1)) - 1u) : ~0u;
   for (uint64_t j = j0; j < j1; ++j) {
     convert<NK, NV, K32>(p, raw, rows);
-    if constexpr (PRED) n_selected += fused_predicate<NK, NV, K32>(fused, rows);
+    if constexpr (PRED) n_selected += fused_predicate<NK, NV, K32>(fused, raw, rows);
     if (t.windowed && j == j0) {
       // the first window starts at the workgroup's first key
       if (threadIdx.x == 0) win.candidate = (uint32_t)rows.key[0];
@@ -937,9 +973,9 @@ __global__ __launch_bounds__(kStreamBlock) PRISM_STREAM_OCCUPANCY void k_group_b
 template <int NK, bool K32, bool PRED>
 GroupByKernel pick_nv(int nv) {
   switch (nv) {
-    case 0:  // a predicate reads at least one value column
-      if constexpr (PRED) return nullptr;
-      else return k_group_by_stream<NK, 0, K32, false>;
+    case 0:  // a predicate without value columns reads keys only
+      if constexpr (PRED && NK == 0) return nullptr;
+      else return k_group_by_stream<NK, 0, K32, PRED>;
     case 1: return k_group_by_stream<NK, 1, K32, PRED>;
     case 2: return k_group_by_stream<NK, 2, K32, PRED>;
     case 3: return k_group_by_stream<NK, 3, K32, PRED>;

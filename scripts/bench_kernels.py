@@ -24,6 +24,8 @@ def main():
     table = workloads.build_gpu_table(ctx, wl, 0, rows, rows, 32)
     queries = [
         ("COUNT(*) WHERE value >= 49000", QueryPlan([count_star()], predicate=col("value") >= 49_000)),
+        ("COUNT(*) WHERE 10000 <= value < 30000", QueryPlan([count_star()], predicate=(col("value") >= 10_000) & (col("value") < 30_000))),
+        ("SUM(value) WHERE timestamp >= noon + 1 h", QueryPlan([sum_("value")], predicate=col("timestamp") >= workloads.T0_MS + 13 * 3_600_000)),
         ("SUM MIN MAX(value) ungrouped", QueryPlan([sum_("value"), min_("value"), max_("value")])),
         ("AVG(value) ungrouped", QueryPlan([avg("value")])),
         ("GROUP BY service: COUNT SUM", QueryPlan([count_star(), sum_("value")], keys=["service"])),
@@ -33,6 +35,8 @@ def main():
         ("C2 WHERE value >= 0 (100 %)", QueryPlan(wl.query.aggs, keys=wl.query.keys, predicate=col("value") >= 0)),
         ("C2 WHERE value >= 25000 (50 %)", QueryPlan(wl.query.aggs, keys=wl.query.keys, predicate=col("value") >= 25_000)),
         ("C2 WHERE value >= 49900 (0.2 %)", QueryPlan(wl.query.aggs, keys=wl.query.keys, predicate=col("value") >= 49_900)),
+        ("C2 WHERE timestamp >= noon + 1 h (zone maps)", QueryPlan(wl.query.aggs, keys=wl.query.keys,
+                                                               predicate=col("timestamp") >= workloads.T0_MS + 13 * 3_600_000)),
         ("C2 WHERE service LIKE '%-0%'", QueryPlan(wl.query.aggs, keys=wl.query.keys, predicate=col("service").like("%-0%"))),
         ("GROUP BY value (50k groups)", QueryPlan([count_star()], keys=["value"])),
         ("GROUP BY date_bin(1s) (86k groups)", QueryPlan([count_star(), max_("value")], keys=[date_bin(1000, "timestamp")])),

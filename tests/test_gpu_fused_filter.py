@@ -74,6 +74,19 @@ def test_fused_predicates_match_the_oracle(gpu_ctx, oracle, nulls):
             (QueryPlan([count_star(), max_("i32")], keys=["service"], predicate=col("value").is_null() | (col("value") > 20_000)), 1),
             # timestamps compare as 64-bit integers; 64-bit keys (user) take the wide-key kernel variant
             (QueryPlan([count_star(), sum_("value")], keys=["user"], predicate=col("ts") >= 1_700_000_000_000 + 3_600_000), 1),
+            # leaves on GROUP BY key columns read the key's own load: bucketed timestamp (32-bit key form),
+            # plain timestamp key, 8-byte and 4-byte integer keys, a 2-byte key (loaded again as a value),
+            # a key column and a value column in one conjunction, literals outside the key's range
+            (QueryPlan([count_star(), sum_("value")], keys=keys2, predicate=col("ts") >= 1_700_000_000_000 + 4_000_000), 2),
+            (QueryPlan([count_star()], keys=keys2, predicate=(col("ts") >= 1_700_000_000_000 + 1_000_000)
+                       & (col("ts") < 1_700_000_000_000 + 9_000_000)), 2),
+            (QueryPlan([count_star(), max_("value")], keys=["ts"], predicate=col("ts") < 1_700_000_000_000 + 5_000_000), 1),
+            (QueryPlan([count_star(), sum_("value")], keys=["user"], predicate=(col("user") > 20_000_000) | (col("user") < 0)), 1),
+            (QueryPlan([count_star(), sum_("value")], keys=["i32", "service"], predicate=(col("i32") >= -300) & (col("value") < 10_000)), 2),
+            (QueryPlan([count_star()], keys=["i16"], predicate=col("i16") != 0), 1),
+            (QueryPlan([count_star(), sum_("value")], keys=keys2, predicate=col("ts") >= 0), 2),
+            (QueryPlan([count_star(), sum_("value")], keys=keys2, predicate=col("ts") <= 2_000_000_000_000_000), 2),
+            (QueryPlan([count_star(), min_("value")], keys=["user"], predicate=col("user").is_not_null() & (col("value") > -45_000)), 1),
             # ungrouped
             (QueryPlan([count_star(), sum_("value"), min_("value"), max_("u16"), avg("i32")],
                        predicate=(col("value") >= -10_000) & (col("value") < 30_000)), 0),
@@ -90,6 +103,27 @@ def test_fused_predicates_match_the_oracle(gpu_ctx, oracle, nulls):
             (QueryPlan([sum_("value"), sum_("i32"), sum_("u16"), sum_("user")], keys=keys2, predicate=col("i16") < 4), 2),
         ]:
             _run(gpu_ctx, oracle, t, table, q, nk, expect_fused=False)
+    finally:
+        table.close()
+
+
+def test_fused_predicate_on_a_wide_key(gpu_ctx, oracle):
+    """A key whose range needs the 64-bit key kernel: the leaf compares the raw 8-byte value."""
+    from prism_amd.engine import Table
+
+    rng = np.random.default_rng(9)
+    n = 40_000
+    wide = rng.integers(0, 400, n).astype(np.int64) * (2**62 // 400) - 2**61
+    t = pa.table({"wide": pa.array(wide, mask=rng.random(n) < 0.05), "g": pa.array(rng.integers(0, 9, n).astype(np.int32)),
+                  "value": pa.array(rng.integers(-100, 100, n).astype(np.int64))})
+    table = Table(gpu_ctx, t.schema)
+    table.append_table(t, 2)
+    try:
+        for q, nk in [(QueryPlan([count_star(), sum_("value")], keys=["wide"], predicate=col("wide") >= 0), 1),
+                      (QueryPlan([count_star(), sum_("value")], keys=["wide"],
+                                 predicate=(col("wide") < 2**60) & (col("wide") > -2**60) & (col("value") != 0) & (col("g") > 1)), 1),
+                      (QueryPlan([count_star()], keys=["wide"], predicate=col("wide").is_null() | (col("wide") > 2**60)), 1)]:
+            _run(gpu_ctx, oracle, t, table, q, nk, expect_fused=True)
     finally:
         table.close()
 
