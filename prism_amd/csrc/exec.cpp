@@ -355,6 +355,27 @@ bool leaf_uses_codes(const prism_gpu_table* t, const ScanSet& ss, const PredNode
   return t->dicts[n.column].alive;
 }
 
+// A string predicate (comparison or LIKE) decided for every value of the column's
+// dictionary: lut[code] = 1 when a row with that code passes (one spare entry at the end).
+std::vector<uint8_t> dict_lut(const PredNode& n, const ColumnDict& dict) {
+  std::vector<uint8_t> lut(dict.values.size() + 1, 0);
+  std::vector<LikeToken> toks;
+  if (n.kind == PredNode::LIKE) toks = like_compile(n.lit_str);
+  for (size_t i = 0; i < dict.values.size(); ++i) {
+    const std::string& v = dict.values[i];
+    bool t;
+    if (n.kind == PredNode::LIKE) {
+      t = like_match_host(toks, v, n.case_insensitive) != n.negated;
+    } else {
+      int c = std::memcmp(v.data(), n.lit_str.data(), std::min(v.size(), n.lit_str.size()));
+      if (c == 0) c = v.size() < n.lit_str.size() ? -1 : (v.size() > n.lit_str.size() ? 1 : 0);
+      t = (c < 0 && (n.cmp_mask & kLt)) || (c == 0 && (n.cmp_mask & kEq)) || (c > 0 && (n.cmp_mask & kGt));
+    }
+    lut[i] = t ? 1 : 0;
+  }
+  return lut;
+}
+
 struct Selection {
   bool all = true;      // no predicate: every row
   Scratch bits;         // TRUE rows, one bit per padded row id
@@ -384,21 +405,7 @@ struct PredEval {
   // String predicate through the column's dictionary: evaluated once per distinct
   // value on the host, then a code -> bit lookup on the device.
   Scratch lut_leaf(const PredNode& n, const ColumnDict& dict) {
-    std::vector<uint8_t> lut(dict.values.size() + 1, 0);
-    std::vector<LikeToken> toks;
-    if (n.kind == PredNode::LIKE) toks = like_compile(n.lit_str);
-    for (size_t i = 0; i < dict.values.size(); ++i) {
-      const std::string& v = dict.values[i];
-      bool t;
-      if (n.kind == PredNode::LIKE) {
-        t = like_match_host(toks, v, n.case_insensitive) != n.negated;
-      } else {
-        int c = std::memcmp(v.data(), n.lit_str.data(), std::min(v.size(), n.lit_str.size()));
-        if (c == 0) c = v.size() < n.lit_str.size() ? -1 : (v.size() > n.lit_str.size() ? 1 : 0);
-        t = (c < 0 && (n.cmp_mask & kLt)) || (c == 0 && (n.cmp_mask & kEq)) || (c > 0 && (n.cmp_mask & kGt));
-      }
-      lut[i] = t ? 1 : 0;
-    }
+    std::vector<uint8_t> lut = dict_lut(n, dict);
     const uint8_t* d_lut = to_device(lut.data(), lut.size());
     Scratch bits = new_bits(false);
     KernelTimer timer(ctx, "pred_lut", ss.rows * 4);
@@ -1031,20 +1038,20 @@ namespace {
 
 namespace {
 
-// WHERE inside the aggregation kernel.  The predicate qualifies when it is one leaf, or a
-// conjunction or a disjunction of at most kMaxFusedLeaves leaves, each a comparison of a
-// fixed-width integer column with a literal or an IS [NOT] NULL on such a column (NOT has
-// been pushed into the leaves at plan time, so the TRUE rows of AND / OR are the
-// intersection / union of the leaves' TRUE rows).  Collects the leaves; `is_or` tells how
-// they combine.
 // Share of the rows a leaf is expected to keep, from the column's min / max / NULL count
 // over the scan and a uniform distribution in between.
-double leaf_selectivity(const ScanSet& ss, const PredNode& n) {
+double leaf_selectivity(const ScanSet& ss, const PredNode& n, const ColumnDict* dict) {
   const ColInfo ci = col_info(ss, n.column);
   const double rows = (double)std::max<uint64_t>(1, ss.rows);
   const double not_null = 1.0 - std::min(1.0, (double)ci.nulls / rows);
   if (n.kind == PredNode::IS_NULL) return 1.0 - not_null;
   if (n.kind == PredNode::IS_NOT_NULL) return not_null;
+  if (dict) {  // a string predicate: the share of the dictionary's values that pass
+    const std::vector<uint8_t> lut = dict_lut(n, *dict);
+    size_t pass = 0;
+    for (size_t c = 0; c + 1 < lut.size(); ++c) pass += lut[c] != 0;
+    return not_null * (double)pass / (double)std::max<size_t>(1, lut.size() - 1);
+  }
   if (ci.min > ci.max) return 0.0;
   const double lo = (double)ci.min, hi = (double)ci.max, lit = (double)n.lit_i64, range = hi - lo + 1.0;
   auto clamp01 = [](double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); };
@@ -1055,15 +1062,28 @@ double leaf_selectivity(const ScanSet& ss, const PredNode& n) {
   return clamp01(f) * not_null;
 }
 
+// WHERE inside the aggregation kernel.  The predicate qualifies when it is one leaf, or a
+// conjunction or a disjunction of at most kMaxFusedLeaves leaves, each a comparison of a
+// fixed-width integer column with a literal, an IS [NOT] NULL, or a string comparison / LIKE
+// on a column whose dictionary has at most 64 values (NOT has
+// been pushed into the leaves at plan time, so the TRUE rows of AND / OR are the
+// intersection / union of the leaves' TRUE rows).  Collects the leaves; `is_or` tells how
+// they combine.
 bool fusable_leaves(const prism_gpu_plan* p, const prism_gpu_table* t, int node, int combiner, std::vector<int>& leaves) {
   const PredNode& n = p->pred[node];
   if (n.kind == PredNode::AND || n.kind == PredNode::OR) {
     if (combiner >= 0 && combiner != (int)n.kind) return false;
     return fusable_leaves(p, t, n.lhs, (int)n.kind, leaves) && fusable_leaves(p, t, n.rhs, (int)n.kind, leaves);
   }
-  if (n.kind != PredNode::CMP && n.kind != PredNode::IS_NULL && n.kind != PredNode::IS_NOT_NULL) return false;
   const FieldType& f = t->fields[n.column];
-  if (f.is_string || f.is_float || (f.is_unsigned && f.width == 8)) return false;
+  if (f.is_string) {
+    // through the dictionary, when its codes fit one 64-bit set
+    const ColumnDict& d = t->dicts[n.column];
+    if (!d.alive || d.values.size() > 64) return false;
+  } else {
+    if (n.kind != PredNode::CMP && n.kind != PredNode::IS_NULL && n.kind != PredNode::IS_NOT_NULL) return false;
+    if (f.is_float || (f.is_unsigned && f.width == 8)) return false;
+  }
   leaves.push_back(node);
   return leaves.size() <= (size_t)kMaxFusedLeaves;
 }
@@ -1186,7 +1206,15 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       for (size_t l = 0; l < leaves.size() && fits; ++l) {
         const PredNode& n = plan->pred[leaves[l]];
         const FieldType& f = table->fields[n.column];
-        const int kind = n.kind == PredNode::CMP ? kLeafCmp : (n.kind == PredNode::IS_NULL ? kLeafIsNull : kLeafIsNotNull);
+        int kind = n.kind == PredNode::CMP ? kLeafCmp : (n.kind == PredNode::IS_NULL ? kLeafIsNull : kLeafIsNotNull);
+        long long lit = (long long)n.lit_i64;
+        if (f.is_string && n.kind != PredNode::IS_NULL && n.kind != PredNode::IS_NOT_NULL) {
+          kind = kLeafLut;
+          const std::vector<uint8_t> lut = dict_lut(n, table->dicts[n.column]);
+          uint64_t set = 0;
+          for (size_t c = 0; c + 1 < lut.size() && c < 64; ++c) set |= (uint64_t)(lut[c] != 0) << c;
+          lit = (long long)set;
+        }
         // A column that is a GROUP BY key is loaded already: read it from there (WHERE on the
         // timestamp that is also bucketed is the everyday query).  The 32-bit-key kernel holds
         // the low word only, which is enough: value - base is below 2^32 for every row.
@@ -1195,26 +1223,29 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
           if (keys[i].column == n.column && (k32 ? trial.keys[i].width >= 4 : trial.keys[i].width == 8)) from_key = (int)i;
         if (from_key >= 0) {
           const KeySpec& ks = trial.keys[from_key];
-          const __int128 rel = (__int128)n.lit_i64 - (__int128)ks.base;
-          const long long lit_k32 = rel < -1 ? -1ll : (rel > ((__int128)1 << 32) ? (1ll << 32) : (long long)rel);
-          trial.pred[l] = {-(from_key + 1), kind, n.cmp_mask, (uint32_t)(uint64_t)ks.base, (long long)n.lit_i64, lit_k32};
+          const __int128 rel = (__int128)lit - (__int128)ks.base;
+          long long lit_k32 = rel < -1 ? -1ll : (rel > ((__int128)1 << 32) ? (1ll << 32) : (long long)rel);
+          // (codes of the scan start at base: the set moves down with them)
+          if (kind == kLeafLut) lit_k32 = ks.base >= 0 && ks.base < 64 ? (long long)((uint64_t)lit >> ks.base) : 0ll;
+          trial.pred[l] = {-(from_key + 1), kind, n.cmp_mask, (uint32_t)(uint64_t)ks.base, lit, lit_k32};
           continue;
         }
-        const int col = ss.use(n.column, false);
+        const int col = ss.use(n.column, f.is_string);  // strings: their dictionary codes
         int v = 0;
         while (v < trial.n_vals && trial.vals[v].col != col) ++v;
         if (v == trial.n_vals) {
           if (trial.n_vals >= kMaxVals) { fits = false; break; }
-          trial.vals[v] = {col, f.width, f.is_unsigned ? 1 : 0, 0};
+          trial.vals[v] = {col, f.is_string ? 4 : f.width, (f.is_string || f.is_unsigned) ? 1 : 0, 0};
           trial.n_vals += 1;
         }
-        trial.pred[l] = {v, kind, n.cmp_mask, 0u, (long long)n.lit_i64, 0ll};
+        trial.pred[l] = {v, kind, n.cmp_mask, 0u, lit, 0ll};
       }
       // Few expected survivors: the bitmap pass followed by a gather of only those rows is
       // cheaper than streaming every column of every row through the aggregation kernel.
       double keep = trial.pred_or ? 0.0 : 1.0;
       for (int leaf : leaves) {
-        const double f = leaf_selectivity(ss, plan->pred[leaf]);
+        const PredNode& ln = plan->pred[leaf];
+        const double f = leaf_selectivity(ss, ln, table->fields[ln.column].is_string ? &table->dicts[ln.column] : nullptr);
         keep = trial.pred_or ? 1.0 - (1.0 - keep) * (1.0 - f) : keep * f;
       }
       if (fits && keep >= 1.0 / 16 && group_by_streams(trial)) {

@@ -129,13 +129,14 @@ struct ValSpec {
 
 // One leaf of a predicate evaluated inside the aggregation kernel, on a column that is
 // loaded as one of the plan's values or keys.  A NULL input never makes a leaf TRUE, except IS NULL.
-enum FusedLeafKind { kLeafCmp = 0, kLeafIsNull = 1, kLeafIsNotNull = 2 };
+// kLeafLut: the input is a dictionary code below 64 and the literal a bit set of the codes that pass
+enum FusedLeafKind { kLeafCmp = 0, kLeafIsNull = 1, kLeafIsNotNull = 2, kLeafLut = 3 };
 struct FusedLeaf {
   // >= 0: index into AggParams::vals.  < 0: the leaf reads GROUP BY key -(val + 1), whose
   // column is loaded anyway (a second, nontemporal load of the same bytes would fetch them
   // from HBM twice): a kernel with 64-bit keys compares the raw value with `lit`, one with
   // 32-bit keys compares (low 32 bits - key_base32), which is the value minus the key's base
-  // exactly, with `lit_k32` = lit - base clamped to [-1, 2^32].
+  // exactly, with `lit_k32` = lit - base clamped to [-1, 2^32] (kLeafLut: the bit set shifted down by base).
   int32_t val;
   int32_t kind;      // FusedLeafKind
   int32_t cmp_mask;  // CmpMask of a comparison with the literal

@@ -334,6 +334,11 @@ __device__ __forceinline__ void fused_leaf(const FusedRegs& r, const RowBatch<NK
   } else if (r.kind[L] == kLeafIsNotNull) {
 #pragma unroll
     for (int u = 0; u < kU; ++u) m[u] = ok[u];
+  } else if (r.kind[L] == kLeafLut) {
+    // a string predicate, decided per dictionary value on the host: bit `code` of the literal
+#pragma unroll
+    for (int u = 0; u < kU; ++u)
+      m[u] = __ballot((unsigned long long)x[u] < 64ull && (((unsigned long long)lit >> ((unsigned)x[u] & 63u)) & 1ull) != 0) & ok[u];
   } else {
 #pragma unroll
     for (int u = 0; u < kU; ++u) m[u] = 0;

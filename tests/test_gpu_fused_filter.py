@@ -87,6 +87,13 @@ def test_fused_predicates_match_the_oracle(gpu_ctx, oracle, nulls):
             (QueryPlan([count_star(), sum_("value")], keys=keys2, predicate=col("ts") >= 0), 2),
             (QueryPlan([count_star(), sum_("value")], keys=keys2, predicate=col("ts") <= 2_000_000_000_000_000), 2),
             (QueryPlan([count_star(), min_("value")], keys=["user"], predicate=col("user").is_not_null() & (col("value") > -45_000)), 1),
+            # string predicates on a dictionary of at most 64 values are a bit set of codes: on a key column,
+            # on a column that is not a key, negated LIKE, IS NULL on the string column, mixed with integers
+            (QueryPlan([count_star(), sum_("value")], keys=keys2, predicate=col("service").like("%-0%")), 2),
+            (QueryPlan([count_star(), sum_("value")], keys=["i16"], predicate=col("service") == "svc-00"), 1),
+            (QueryPlan([count_star(), max_("value")], keys=["service"], predicate=~col("service").like("svc-0_") & (col("value") > -30_000)), 1),
+            (QueryPlan([count_star()], keys=keys2, predicate=(col("service") >= "svc-03") | col("service").is_null()), 2),
+            (QueryPlan([count_star(), sum_("value")], predicate=(col("service") != "svc-01") & (col("i32") < 800)), 0),
             # ungrouped
             (QueryPlan([count_star(), sum_("value"), min_("value"), max_("u16"), avg("i32")],
                        predicate=(col("value") >= -10_000) & (col("value") < 30_000)), 0),
@@ -94,11 +101,12 @@ def test_fused_predicates_match_the_oracle(gpu_ctx, oracle, nulls):
         ]
         for q, nk in cases:
             _run(gpu_ctx, oracle, t, table, q, nk, expect_fused=True)
-        # shapes that must take the bitmap path: mixed AND / OR, a string leaf, few expected survivors,
+        # shapes that must take the bitmap path: mixed AND / OR, a string leaf without a small dictionary, few
+        # expected survivors,
         # more than four columns to load
         for q, nk in [
             (QueryPlan(aggs, keys=keys2, predicate=((col("value") > 0) & (col("i32") < 0)) | (col("u16") > 65_000)), 2),
-            (QueryPlan(aggs, keys=keys2, predicate=(col("value") > 0) & (col("service") == "svc-01")), 2),
+            (QueryPlan(aggs, keys=keys2, predicate=(col("value") > 0) & col("url").like("%google%")), 2),
             (QueryPlan(aggs, keys=keys2, predicate=col("value") >= 49_000), 2),
             (QueryPlan([sum_("value"), sum_("i32"), sum_("u16"), sum_("user")], keys=keys2, predicate=col("i16") < 4), 2),
         ]:
