@@ -1306,6 +1306,22 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
     PRISM_HIP(hipMemcpyAsync(&c, d_scalar.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     PRISM_HIP(hipStreamSynchronize(ctx->stream));
     sel.count = selected = c;
+    // COUNT(*) alone is the number of TRUE rows: nothing left to aggregate
+    bool only_count_star = plan->keys.empty() && !plan->distinct_plan && !capture && !plan->aggs.empty();
+    for (const AggPlan& a : plan->aggs) only_count_star = only_count_star && a.func == PRISM_AGG_COUNT_STAR;
+    if (only_count_star) {
+      collect_timings(ctx);
+      std::vector<OutColumn> count_cols = make_columns(partial ? plan->partial_fields : plan->final_fields);
+      for (OutColumn& oc : count_cols) oc.push_int((int64_t)selected);
+      {
+        std::lock_guard<std::mutex> g(ctx->mu);
+        ctx->stats.rows_scanned += ss.rows;
+        ctx->stats.rows_selected += selected;
+        ctx->stats.groups_out += 1;
+      }
+      export_record_batch(count_cols, out);
+      return;
+    }
     ap.row_mode = kRowsBitmap;
     ap.sel_bits = sel.bits.as<uint64_t>();
     // Few survivors: compact them into a selection vector so that the aggregation

@@ -70,7 +70,10 @@ struct ContainsSeg {
   uint64_t tile_base;
   uint64_t chunk_base;  // chunks of kContainsChunkBytes before this segment
 };
-constexpr uint64_t kContainsChunkBytes = 16384;
+#ifndef PRISM_CONTAINS_CHUNK_BYTES
+#define PRISM_CONTAINS_CHUNK_BYTES 16384
+#endif
+constexpr uint64_t kContainsChunkBytes = PRISM_CONTAINS_CHUNK_BYTES;
 bool launch_contains_all(prism_gpu_ctx* ctx, const ContainsSeg* d_segs, uint32_t n_segs, uint64_t n_chunks,
                          const uint8_t* d_needle, uint32_t needle_len, uint64_t* d_matches, uint64_t match_capacity,
                          unsigned long long* d_n_matches, uint64_t* bits);

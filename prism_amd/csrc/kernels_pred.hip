@@ -388,7 +388,16 @@ void launch_str_leaf(prism_gpu_ctx* ctx, const ScanDesc& sd, const ColPtr* col, 
 namespace {
 
 // Pass 1: every workgroup walks a contiguous share of 16-KiB chunks of the concatenated
-// segments; a lane tests the 16 byte positions of each of its four 16-byte pieces.
+// segments; a lane tests the 16 byte positions of each of its four 16-byte pieces.  The
+// four bytes a lane needs beyond its own piece come from its neighbour's registers; only
+// those after the wave's last lane are loaded.  (Measured and dropped: a second register
+// buffer to have the next chunk's loads in flight during the search, 40 % slower.)
+struct ContainsChunk {
+  uint32_t seg;
+  const uint8_t* bytes;
+  uint64_t total, base;
+};
+
 __global__ __launch_bounds__(kBlock) void k_contains_find(const ContainsSeg* segs, uint32_t n_segs, uint64_t n_chunks,
                                                          const uint8_t* needle, uint32_t L, uint64_t* matches,
                                                          uint64_t capacity, unsigned long long* n_matches) {
@@ -399,7 +408,7 @@ __global__ __launch_bounds__(kBlock) void k_contains_find(const ContainsSeg* seg
   const uint32_t nmask = k == 4 ? 0xffffffffu : ((1u << (8 * k)) - 1u);
   const uint64_t per = uniform_u64(ceil_div(n_chunks, (uint64_t)gridDim.x));
   const uint64_t c0 = per * blockIdx.x, c1 = c0 + per < n_chunks ? c0 + per : n_chunks;
-  uint32_t seg = 0;
+  uint32_t seg_cursor = 0;
   const int lane = threadIdx.x & 63;
   // Occurrences are collected in LDS and moved to the list a few hundred at a time: one
   // atomic on the list's counter per occurrence would serialise on that one address.
@@ -419,45 +428,92 @@ __global__ __launch_bounds__(kBlock) void k_contains_find(const ContainsSeg* seg
     if (threadIdx.x == 0) buf_n = 0;
     __syncthreads();
   };
-  for (uint64_t c = c0; c < c1; ++c) {
-    while (seg + 1 < n_segs && segs[seg + 1].chunk_base <= c) ++seg;
-    seg = __builtin_amdgcn_readfirstlane(seg);
-    const uint8_t* bytes = (const uint8_t*)uniform_u64((uint64_t)segs[seg].bytes);
-    const uint64_t total = uniform_u64(segs[seg].n_bytes);
-    const uint64_t base = (c - uniform_u64(segs[seg].chunk_base)) * kContainsChunkBytes;
-    uint32_t d[K][5];
-#pragma unroll
-    for (int q = 0; q < K; ++q) {
-      const uint64_t p = base + (uint64_t)q * (kBlock * 16) + (uint64_t)threadIdx.x * 16;
-      if (p < total) {
-        // the buffer is padded by the loader, so these 20 bytes are always readable
-        const uint4 own = stream16(bytes + p);
-        d[q][0] = own.x; d[q][1] = own.y; d[q][2] = own.z; d[q][3] = own.w;
-        d[q][4] = *(const uint32_t*)(bytes + p + 16);
-      } else {
-        d[q][0] = d[q][1] = d[q][2] = d[q][3] = d[q][4] = 0;
-      }
+  // The segment's description stays in scalar registers until the chunks move on to the next
+  // segment: read from memory for every chunk, its loads (each waiting for the one before)
+  // stood in front of the chunk's data loads.
+  ContainsChunk cur_seg{};
+  uint64_t seg_chunk_base = 0, next_chunk_base = 0;  // next_chunk_base = 0 forces the first look-up
+  auto locate = [&](uint64_t c) {
+    if (c >= next_chunk_base) {
+      while (seg_cursor + 1 < n_segs && segs[seg_cursor + 1].chunk_base <= c) ++seg_cursor;
+      seg_cursor = __builtin_amdgcn_readfirstlane(seg_cursor);
+      cur_seg.seg = seg_cursor;
+      cur_seg.bytes = (const uint8_t*)uniform_u64((uint64_t)segs[seg_cursor].bytes);
+      cur_seg.total = uniform_u64(segs[seg_cursor].n_bytes);
+      seg_chunk_base = uniform_u64(segs[seg_cursor].chunk_base);
+      next_chunk_base = seg_cursor + 1 < n_segs ? uniform_u64(segs[seg_cursor + 1].chunk_base) : ~0ull;
     }
+    ContainsChunk cc = cur_seg;
+    cc.base = (c - seg_chunk_base) * kContainsChunkBytes;
+    return cc;
+  };
+  // d[q][0..3]: the lane's 16 bytes of piece q; d[q][4]: the 4 bytes after the wave's last
+  // lane (one address per wave).  Every load is unconditional, on the global address space,
+  // at an address clamped into the buffer (pieces beyond the end are discarded by the
+  // search): behind a per-lane branch the compiler waited for each piece before loading the
+  // next, and through a generic pointer the loads were flat_loads.
+  auto issue = [&](const ContainsChunk& cc, uint32_t (&d)[K][5]) {
+    typedef const __attribute__((address_space(1))) u32x4_t* gvec_t;
+    typedef const __attribute__((address_space(1))) uint32_t* gword_t;
+    const uint64_t gb = (uint64_t)cc.bytes;
 #pragma unroll
     for (int q = 0; q < K; ++q) {
-      const uint64_t p = base + (uint64_t)q * (kBlock * 16) + (uint64_t)threadIdx.x * 16;
+      const uint64_t p = cc.base + (uint64_t)q * (kBlock * 16) + (uint64_t)threadIdx.x * 16;
+      const uint64_t wave_end = cc.base + (uint64_t)q * (kBlock * 16) + (uint64_t)((threadIdx.x >> 6) + 1) * 1024;
+      const u32x4_t own = __builtin_nontemporal_load((gvec_t)(gb + (p < cc.total ? p : 0)));
+      d[q][0] = own.x; d[q][1] = own.y; d[q][2] = own.z; d[q][3] = own.w;
+      // the buffer is padded by the loader, so the 4 bytes after the last piece are readable
+      d[q][4] = *(gword_t)(gb + (wave_end <= cc.total ? wave_end : 0));
+    }
+  };
+  // Prefilter, four byte positions per instruction: a position is a candidate when its byte
+  // equals the needle's first byte and the next byte the needle's second.  "Is some byte of
+  // x zero" is (x - 0x01010101) & ~x & 0x80808080 (exact for the lowest zero byte, possibly
+  // also set above one: a filter may say yes too often).  About 10 vector instructions per
+  // 4 positions, against 5 per position for comparing four needle bytes at every position.
+  const uint32_t n0 = (first & 0xffu) * 0x01010101u, n1 = ((first >> 8) & 0xffu) * 0x01010101u;
+  const bool two = L >= 2;
+  auto search = [&](const ContainsChunk& cc, uint32_t (&d)[K][5]) {
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+      const uint64_t p = cc.base + (uint64_t)q * (kBlock * 16) + (uint64_t)threadIdx.x * 16;
+      const uint32_t from_next = (uint32_t)__shfl_down((int)d[q][0], 1);
+      const uint32_t after = lane == 63 ? d[q][4] : from_next;
+      uint32_t z[4];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const uint32_t lo = d[q][w], hi = w == 3 ? after : d[q][w + 1];
+        const uint32_t x0 = lo ^ n0;
+        z[w] = (x0 - 0x01010101u) & ~x0 & 0x80808080u;
+        if (two) {
+          const uint32_t x1 = __builtin_amdgcn_alignbyte(hi, lo, 1) ^ n1;
+          z[w] &= (x1 - 0x01010101u) & ~x1 & 0x80808080u;
+        }
+      }
+      const bool inside = p < cc.total;  // (a piece beyond the end holds what a clamped load brought in)
+      if (__ballot(inside && (z[0] | z[1] | z[2] | z[3]) != 0u) == 0ull) continue;
+      // bit 7 of byte b of z[w] -> bit 4 w + b
       uint32_t cand = 0;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const uint32_t w = __builtin_amdgcn_alignbyte(d[q][(j >> 2) + 1], d[q][j >> 2], j & 3);
-        cand |= (((w & nmask) == first) ? 1u : 0u) << j;
+      for (int w = 0; w < 4; ++w) {
+        const uint32_t y = z[w] >> 7;
+        cand |= ((y | (y >> 7) | (y >> 14) | (y >> 21)) & 0xfu) << (4 * w);
       }
-      if (p >= total) cand = 0;
-      // rare from here on: verify the rest of the needle, then append the position
+      if (!inside) cand = 0;
+      // per candidate: the needle's first four bytes against the registers, the rest against memory
       while (__ballot(cand != 0) != 0ull) {
         bool hit = false;
         uint64_t pos = 0;
         if (cand) {
           const int j = __ffs(cand) - 1;
           cand &= cand - 1;
+          const int wj = j >> 2;
+          const uint32_t lo = wj == 0 ? d[q][0] : (wj == 1 ? d[q][1] : (wj == 2 ? d[q][2] : d[q][3]));
+          const uint32_t hi = wj == 0 ? d[q][1] : (wj == 1 ? d[q][2] : (wj == 2 ? d[q][3] : after));
+          const uint32_t four = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(j & 3));
           pos = p + j;
-          hit = pos + L <= total;
-          for (uint32_t i = 4; i < L && hit; ++i) hit = bytes[pos + i] == needle[i];
+          hit = (four & nmask) == first && pos + L <= cc.total;
+          for (uint32_t i = 4; i < L && hit; ++i) hit = cc.bytes[pos + i] == needle[i];
         }
         const uint64_t m = __ballot(hit);
         if (m) {
@@ -466,7 +522,7 @@ __global__ __launch_bounds__(kBlock) void k_contains_find(const ContainsSeg* seg
           at = __shfl(at, __ffsll((long long)m) - 1);
           if (hit) {
             at += __popcll(m & ((1ull << lane) - 1));
-            const uint64_t rec = ((uint64_t)seg << 32) | pos;  // pos < 2^31: offsets are i32
+            const uint64_t rec = ((uint64_t)cc.seg << 32) | pos;  // pos < 2^31: offsets are i32
             if (at < kBuf) {
               buf[at] = rec;
             } else {
@@ -481,6 +537,14 @@ __global__ __launch_bounds__(kBlock) void k_contains_find(const ContainsSeg* seg
     __syncthreads();
     if (buf_n > kBuf / 2) flush();  // uniform: every thread reads the same counter after the barrier
     else __syncthreads();
+  };
+  // (A barrier per chunk also keeps the waves of a workgroup in step; looking at the buffer
+  // only every fourth chunk, so that waves may run ahead, measured 20 % slower.)
+  uint32_t da[K][5];
+  for (uint64_t c = c0; c < c1; ++c) {
+    const ContainsChunk ca = locate(c);
+    issue(ca, da);
+    search(ca, da);
   }
   __syncthreads();
   flush();
