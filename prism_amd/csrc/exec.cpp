@@ -903,10 +903,13 @@ uint64_t emit_groups(prism_gpu_ctx* ctx, const prism_gpu_plan* plan, const prism
     uint64_t stride = 0;
     bool fresh = true;
     for (const OutColumn& oc : cols) fresh = fresh && oc.rows() == 0;
-    // A table with few entries is compacted in one pass into buffers sized for all of them;
-    // a large one is counted first.
-    if (!use_order && entries * n_cols * 9 <= (48ull << 20)) {
-      stride = entries;
+    // A table with few entries is compacted in one pass into buffers sized for all of them,
+    // and so are the leading groups of ORDER BY ... LIMIT (at most the limit plus the entries
+    // of the last radix bin pass the device's threshold); any other large table is counted first.
+    const uint64_t topk_room = use_order ? (uint64_t)std::max<int64_t>(1, plan->limit) + 4096 : 0;
+    bool one_pass = use_order ? topk_room < entries : entries * n_cols * 9 <= (48ull << 20);
+    if (one_pass) {
+      stride = use_order ? topk_room : entries;
       if (fresh) {
         // straight into a page-locked host block that the exported batch will point into:
         // the kernel's stores cross PCIe while it is still scanning the table
@@ -926,10 +929,20 @@ uint64_t emit_groups(prism_gpu_ctx* ctx, const prism_gpu_plan* plan, const prism
         PRISM_HIP(hipMemcpyAsync(count, d_count.p, 16, hipMemcpyDeviceToHost, ctx->stream));
         PRISM_HIP(hipStreamSynchronize(ctx->stream));
       }
-    } else {
-      emit(nullptr, nullptr, 0, d_count.as<unsigned long long>());
-      PRISM_HIP(hipMemcpyAsync(count, d_count.p, 16, hipMemcpyDeviceToHost, ctx->stream));
-      PRISM_HIP(hipStreamSynchronize(ctx->stream));
+      if (count[0] > stride) {
+        // more groups passed than there was room for (the kernel wrote none of the extra ones): count known, do it again
+        one_pass = false;
+        h_vals = nullptr;
+        h_valid = nullptr;
+        lease.reset();
+      }
+    }
+    if (!one_pass) {
+      if (count[0] == 0) {
+        emit(nullptr, nullptr, 0, d_count.as<unsigned long long>());
+        PRISM_HIP(hipMemcpyAsync(count, d_count.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+        PRISM_HIP(hipStreamSynchronize(ctx->stream));
+      }
       if (count[0]) {
         stride = count[0];
         d_vals = Scratch(ctx, stride * n_cols * 8);
