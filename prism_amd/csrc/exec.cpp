@@ -346,6 +346,22 @@ long long slot_identity_host(int op) {
 
 // ---- predicate evaluation -------------------------------------------------------------
 
+// Is node `i` a comparison of a fixed-width column, or the AND of two such comparisons of
+// one column (a range)?  Those are one pass of the comparison kernel.
+bool one_column_range(const prism_gpu_plan* p, const prism_gpu_table* t, int i, const PredNode** a, const PredNode** b) {
+  const PredNode& n = p->pred[i];
+  auto plain_cmp = [&](const PredNode& x) {
+    return x.kind == PredNode::CMP && !t->fields[x.column].is_string && !t->fields[x.column].is_float;
+  };
+  if (plain_cmp(n)) { *a = &n; *b = nullptr; return true; }
+  if (n.kind != PredNode::AND) return false;
+  const PredNode &l = p->pred[n.lhs], &r = p->pred[n.rhs];
+  if (!plain_cmp(l) || !plain_cmp(r) || l.column != r.column) return false;
+  *a = &l;
+  *b = &r;
+  return true;
+}
+
 // Which representation of its column a predicate leaf reads: dictionary codes or
 // the raw values / offsets + bytes.
 bool leaf_uses_codes(const prism_gpu_table* t, const ScanSet& ss, const PredNode& n) {
@@ -418,6 +434,16 @@ struct PredEval {
     switch (n.kind) {
       case PredNode::AND:
       case PredNode::OR: {
+        const PredNode *ra = nullptr, *rb = nullptr;
+        if (n.kind == PredNode::AND && one_column_range(plan, table, i, &ra, &rb) && rb) {
+          // lo <= x AND x < hi: both comparisons in one pass over the column
+          const FieldType& f = table->fields[ra->column];
+          Scratch bits = new_bits(false);
+          KernelTimer timer(ctx, "pred_cmp", ss.rows * f.width);
+          launch_cmp_leaf(ctx, ss.desc, ss.col(ss.use(ra->column, false)), f.width, f.is_unsigned, ra->cmp_mask, ra->lit_i64,
+                          bits.as<uint64_t>(), nullptr, rb->cmp_mask, rb->lit_i64);
+          return bits;
+        }
         Scratch a = eval(n.lhs), b = eval(n.rhs);
         if (n.kind == PredNode::AND) launch_bitmap_and(ctx, a.as<uint64_t>(), b.as<uint64_t>(), a.as<uint64_t>(), n_words);
         else launch_bitmap_or(ctx, a.as<uint64_t>(), b.as<uint64_t>(), a.as<uint64_t>(), n_words);
@@ -1193,10 +1219,11 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
   PredEval pe{plan, table, ss, ctx, n_words, {}};
   const bool has_pred = plan->pred_root >= 0 && !merge_input && !ss.chunks.empty();
   // The common "COUNT(*) WHERE col <op> literal" shape needs no bitmap at all.
+  const PredNode *range_a = nullptr, *range_b = nullptr;
   bool count_only = has_pred && plan->keys.empty() && !plan->distinct_plan && plan->aggs.size() == 1 &&
-                    plan->aggs[0].func == PRISM_AGG_COUNT_STAR && plan->pred[plan->pred_root].kind == PredNode::CMP &&
-                    !table->fields[plan->pred[plan->pred_root].column].is_string;
-  if (has_pred && count_only) ss.use(plan->pred[plan->pred_root].column, false);
+                    plan->aggs[0].func == PRISM_AGG_COUNT_STAR &&
+                    one_column_range(plan, table, plan->pred_root, &range_a, &range_b);
+  if (has_pred && count_only) ss.use(range_a->column, false);
   // Simple predicates are evaluated by the aggregation kernel itself: no bitmap pass, and
   // a predicate on a column the aggregates read anyway costs no memory traffic at all.
   bool fused = false;
@@ -1281,13 +1308,14 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
 
   Scratch d_scalar(ctx, 256);
   if (has_pred && count_only) {
-    const PredNode& n = plan->pred[plan->pred_root];
+    const PredNode& n = *range_a;
     const FieldType& f = table->fields[n.column];
     PRISM_HIP(hipMemsetAsync(d_scalar.p, 0, 8, ctx->stream));
     {
       KernelTimer timer(ctx, "filter_count", ss.rows * f.width);
       launch_cmp_leaf(ctx, ss.desc, ss.col(ss.use(n.column, false)), f.width, f.is_unsigned, n.cmp_mask, n.lit_i64, nullptr,
-                      d_scalar.as<unsigned long long>());
+                      d_scalar.as<unsigned long long>(), range_b ? range_b->cmp_mask : (kLt | kEq | kGt),
+                      range_b ? range_b->lit_i64 : 0);
     }
     unsigned long long c = 0;
     PRISM_HIP(hipMemcpyAsync(&c, d_scalar.p, 8, hipMemcpyDeviceToHost, ctx->stream));

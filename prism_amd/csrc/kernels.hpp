@@ -35,9 +35,11 @@ struct ScanDesc {
 enum CmpMask { kLt = 1, kEq = 2, kGt = 4 };  // which orderings satisfy the comparison
 
 // column <op> literal over a fixed-width column -> selection bits (TRUE rows) and/or
-// their count.  `bits` and `count` may each be nullptr.
+// their count.  `bits` and `count` may each be nullptr.  (cmp_mask2, literal2): a second
+// comparison of the same column, AND-ed in; the default accepts every value.
 void launch_cmp_leaf(prism_gpu_ctx* ctx, const ScanDesc& sd, const ColPtr* col, int width, bool is_unsigned,
-                     int cmp_mask, int64_t literal, uint64_t* bits, unsigned long long* count);
+                     int cmp_mask, int64_t literal, uint64_t* bits, unsigned long long* count,
+                     int cmp_mask2 = kLt | kEq | kGt, int64_t literal2 = 0);
 // bits = rows whose dictionary code c has lut[c] != 0 (and are not NULL).
 void launch_lut_leaf(prism_gpu_ctx* ctx, const ScanDesc& sd, const ColPtr* col, const uint8_t* lut, uint32_t lut_len,
                      uint64_t* bits);

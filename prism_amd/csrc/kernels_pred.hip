@@ -174,14 +174,17 @@ __device__ __forceinline__ void leaf_body(const ScanDesc& sd, const ColPtr* col,
 }
 
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_cmp_leaf(ScanDesc sd, const ColPtr* col, int cmp_mask, long long lit,
-                                                    uint64_t* bits, unsigned long long* count) {
+__global__ __launch_bounds__(kBlock) void k_cmp_leaf(ScanDesc sd, const ColPtr* col, int cmp_mask, long long lit, int cmp_mask2,
+                                                    long long lit2, uint64_t* bits, unsigned long long* count) {
   const bool want_lt = cmp_mask & kLt, want_eq = cmp_mask & kEq, want_gt = cmp_mask & kGt;
+  // a second comparison on the same column, AND-ed in (a range in one pass); all orderings = none
+  const bool want_lt2 = cmp_mask2 & kLt, want_eq2 = cmp_mask2 & kEq, want_gt2 = cmp_mask2 & kGt;
   leaf_body<T>(
       sd, col,
       [=](T x) {
         long long v = (long long)x;
-        return (v < lit && want_lt) || (v == lit && want_eq) || (v > lit && want_gt);
+        return ((v < lit && want_lt) || (v == lit && want_eq) || (v > lit && want_gt)) &&
+               ((v < lit2 && want_lt2) || (v == lit2 && want_eq2) || (v > lit2 && want_gt2));
       },
       bits, count);
 }
@@ -341,14 +344,15 @@ __global__ __launch_bounds__(kBlock) void k_bitmap_count(const uint64_t* bits, u
 }  // namespace
 
 void launch_cmp_leaf(prism_gpu_ctx* ctx, const ScanDesc& sd, const ColPtr* col, int width, bool is_unsigned,
-                     int cmp_mask, int64_t literal, uint64_t* bits, unsigned long long* count) {
+                     int cmp_mask, int64_t literal, uint64_t* bits, unsigned long long* count, int cmp_mask2, int64_t literal2) {
   if (sd.n_tiles == 0) return;
   dim3 grid(leaf_grid(ctx, sd.n_tiles)), block(kBlock);
-  if (width == 2 && !is_unsigned) k_cmp_leaf<int16_t><<<grid, block, 0, ctx->stream>>>(sd, col, cmp_mask, literal, bits, count);
-  else if (width == 2) k_cmp_leaf<uint16_t><<<grid, block, 0, ctx->stream>>>(sd, col, cmp_mask, literal, bits, count);
-  else if (width == 4 && !is_unsigned) k_cmp_leaf<int32_t><<<grid, block, 0, ctx->stream>>>(sd, col, cmp_mask, literal, bits, count);
-  else if (width == 4) k_cmp_leaf<uint32_t><<<grid, block, 0, ctx->stream>>>(sd, col, cmp_mask, literal, bits, count);
-  else if (width == 8 && !is_unsigned) k_cmp_leaf<int64_t><<<grid, block, 0, ctx->stream>>>(sd, col, cmp_mask, literal, bits, count);
+  const long long l1 = literal, l2 = literal2;
+  if (width == 2 && !is_unsigned) k_cmp_leaf<int16_t><<<grid, block, 0, ctx->stream>>>(sd, col, cmp_mask, l1, cmp_mask2, l2, bits, count);
+  else if (width == 2) k_cmp_leaf<uint16_t><<<grid, block, 0, ctx->stream>>>(sd, col, cmp_mask, l1, cmp_mask2, l2, bits, count);
+  else if (width == 4 && !is_unsigned) k_cmp_leaf<int32_t><<<grid, block, 0, ctx->stream>>>(sd, col, cmp_mask, l1, cmp_mask2, l2, bits, count);
+  else if (width == 4) k_cmp_leaf<uint32_t><<<grid, block, 0, ctx->stream>>>(sd, col, cmp_mask, l1, cmp_mask2, l2, bits, count);
+  else if (width == 8 && !is_unsigned) k_cmp_leaf<int64_t><<<grid, block, 0, ctx->stream>>>(sd, col, cmp_mask, l1, cmp_mask2, l2, bits, count);
   else fail(PRISM_GPU_EUNSUPPORTED, "comparison on this column type is not supported");
   PRISM_HIP(hipGetLastError());
 }
