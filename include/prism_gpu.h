@@ -191,6 +191,16 @@ typedef struct prism_gpu_plan_desc {
 int prism_gpu_init(int device_ordinal, prism_gpu_ctx** out);
 void prism_gpu_ctx_free(prism_gpu_ctx* ctx);
 
+/* Execution knobs of a context, the counterpart of DataFusion's SessionConfig options
+ * (the reference sets none: SessionContext::new() at src/prism-query/src/main.rs:82 runs
+ * with the defaults).  Names:
+ *   "part_min_rows"  a GROUP BY over fewer selected rows is never partitioned by key
+ *                    before it is aggregated (default 4194304)
+ *   "part_force"     1: partition whenever the plan's shape allows it, without waiting for
+ *                    the streaming kernel to report that its rows scatter (default 0)
+ * Unknown names are PRISM_GPU_EINVAL. */
+int prism_gpu_set_option(prism_gpu_ctx* ctx, const char* name, int64_t value);
+
 /* Thread-local message for the last failing call on this thread. */
 const char* prism_gpu_last_error(void);
 

@@ -293,6 +293,16 @@ int prism_gpu_table_dictionary_digest(prism_gpu_table* table, int32_t column, ui
   });
 }
 
+int prism_gpu_set_option(prism_gpu_ctx* ctx, const char* name, int64_t value) {
+  return guarded([&] {
+    require(ctx && name, "null argument");
+    const std::string n(name);
+    if (n == "part_min_rows") { require(value >= 0, "part_min_rows must not be negative"); ctx->part_min_rows.store((uint64_t)value); }
+    else if (n == "part_force") ctx->part_force.store(value != 0 ? 1 : 0);
+    else prism::fail(PRISM_GPU_EINVAL, "unknown option `" + n + "`");
+  });
+}
+
 int prism_gpu_set_profiling(prism_gpu_ctx* ctx, int enabled) {
   return guarded([&] {
     require(ctx != nullptr, "ctx is null");

@@ -2,6 +2,7 @@
 // in HBM, a pinned host staging ring, and HIP-event kernel timing.
 #pragma once
 
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <map>
@@ -53,6 +54,10 @@ struct prism_gpu_ctx {
   void* result_pinned = nullptr;
   size_t result_pinned_bytes = 0;
   std::shared_ptr<prism::PinnedPool> result_pool = std::make_shared<prism::PinnedPool>();
+
+  // ---- tuning (prism_gpu_set_option) ----
+  std::atomic<uint64_t> part_min_rows{1ull << 22};  // fewer selected rows: never partition a GROUP BY
+  std::atomic<int> part_force{0};                    // 1: partition whenever the plan shape allows it
 
   // ---- profiling ----
   bool profiling = false;

@@ -113,6 +113,12 @@ struct prism_gpu_plan {
   // capacity the GROUP BY hash table ended up with the last time this plan ran: the next
   // run starts there instead of growing into it again (0: no run yet)
   std::atomic<uint64_t> learned_capacity{0};
+  // What earlier runs of this plan found out about its groups.  part_mode 1: the rows mostly
+  // missed the workgroups' LDS tables (the streaming kernel said so and stopped), so GROUP BY
+  // partitions the rows by key first; part_groups: the number of groups the last partitioned
+  // run produced (sizes the buckets and the result list of the next).
+  std::atomic<int> part_mode{0};
+  std::atomic<uint64_t> part_groups{0};
 };
 
 struct prism_gpu_part {

@@ -4,6 +4,7 @@
 // after prism's TableProvider::scan
 // (src/prism-query/src/providers/table_provider.rs:73-132) has produced the scan.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -668,6 +669,10 @@ constexpr int kDenseMaxBitsLarge = 28;
 
 struct GroupTable {
   bool dense = false;
+  // A list rather than a hash table: the arrays are laid out like a hash table's, but the
+  // groups sit in the leading entries in no particular order (the partitioned GROUP BY's
+  // output).  Everything that walks the entries works as is; nothing may be inserted by hashing.
+  bool list = false;
   uint64_t capacity = 0;
   int n_slots = 0;
   int key_words = 1;
@@ -700,12 +705,16 @@ void table_alloc(prism_gpu_ctx* ctx, GroupTable& g, bool dense, uint64_t capacit
   }
 }
 
-bool table_overflowed(prism_gpu_ctx* ctx, const GroupTable& g) {
+// The table's flag word: 0, 1 (an insertion found the table full), 2 (a merged key fell
+// outside a dense table) or 3 (the streaming kernel stopped because its rows scatter).
+uint32_t table_flag(prism_gpu_ctx* ctx, const GroupTable& g) {
   uint32_t flag = 0;
   PRISM_HIP(hipMemcpyAsync(&flag, g.overflow.p, 4, hipMemcpyDeviceToHost, ctx->stream));
   PRISM_HIP(hipStreamSynchronize(ctx->stream));
-  return flag != 0;
+  return flag;
 }
+
+bool table_overflowed(prism_gpu_ctx* ctx, const GroupTable& g) { return table_flag(ctx, g) != 0; }
 
 // Reads the occupied entries of a table; with `order`, only those whose rank reaches the
 // threshold launch_topk_threshold left in d_threshold.
@@ -1050,6 +1059,140 @@ uint64_t emit_groups(prism_gpu_ctx* ctx, const prism_gpu_plan* plan, const prism
   return n;
 }
 
+
+// ---- partitioned GROUP BY ------------------------------------------------------------------
+// (kernels_part.hip: rows partitioned by key hash in HBM, every bucket aggregated in LDS.)
+
+// Scans of fewer selected rows than ctx->part_min_rows stay on the streaming kernels: below
+// that the partitioned path's fixed cost (five launches, a histogram per workgroup) is not
+// repaid.  ctx->part_force partitions every plan shape that can be partitioned without
+// waiting for the streaming kernel's verdict (tests and experiments; prism_gpu_set_option).
+uint64_t part_min_rows(const prism_gpu_ctx* ctx) { return ctx->part_min_rows; }
+bool part_forced(const prism_gpu_ctx* ctx) { return ctx->part_force != 0; }
+
+// GROUP BY of the scan described by `ap` (keys, values, slots, row mode; no in-kernel
+// predicate) through partitioning.  `gt` becomes a list of the groups; returns their number.
+uint64_t partitioned_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, AggParams ap, uint64_t selected, uint64_t scan_rows,
+                              uint64_t key_bytes, uint64_t value_bytes, bool vals_nullable, const std::vector<int>& slot_ops,
+                              GroupTable& gt) {
+  const int words = part_record_words(ap, vals_nullable);
+  if (words <= 0) fail(PRISM_GPU_EINTERNAL, "plan shape cannot be partitioned");
+  const uint32_t p_max = part_max_buckets(words);
+  const uint32_t lds_entries = part_lds_entries(ap);
+  const uint32_t lds_limit = lds_entries / 4 * 3;
+  uint64_t groups_est = plan->part_groups.load(std::memory_order_relaxed);
+  if (!groups_est) groups_est = plan->groups_hint;
+  // a bucket should hold at most two thirds of what the LDS table takes; unknown: as many buckets as there are
+  uint64_t want = groups_est ? pow2_ceil(ceil_div(groups_est * 3, (uint64_t)lds_limit * 2)) : p_max;
+  // many rows: at least two buckets per CU, whatever the number of groups
+  if (selected >= (1ull << 22)) want = std::max<uint64_t>(want, 512);
+  const uint32_t P = (uint32_t)std::min<uint64_t>(p_max, std::max<uint64_t>(64, want));
+  int p_bits = 0;
+  while ((1u << p_bits) < P) ++p_bits;
+
+  PartParams q;
+  std::memset(&q, 0, sizeof(q));
+  q.p_bits = p_bits;
+  q.n_buckets = P;
+  q.n_wg = part_scan_workgroups(ctx, ap, &q.tiles_per_wg);
+  q.chunk_rows = (uint32_t)std::min<uint64_t>(1u << 30, std::max<uint64_t>(65536, 2 * ceil_div(selected, P)));
+  q.max_items = (uint32_t)(P + selected / q.chunk_rows + 2);
+  q.lds_entries = lds_entries;
+  q.lds_limit = lds_limit;
+  q.rec_capacity = std::max<uint64_t>(1, selected);
+
+  Scratch rec[4], d_hist(ctx, (size_t)q.n_wg * P * 4), d_totals(ctx, (size_t)P * 4), d_base(ctx, (size_t)(P + 1) * 8),
+      d_items(ctx, (size_t)q.max_items * sizeof(PartItem)), d_small(ctx, 256);
+  for (int w = 0; w < words; ++w) {
+    rec[w] = Scratch(ctx, q.rec_capacity * 8 + 256);
+    q.rec[w] = rec[w].as<uint64_t>();
+  }
+  q.hist = d_hist.as<uint32_t>();
+  q.totals = d_totals.as<uint32_t>();
+  q.bucket_base = d_base.as<uint64_t>();
+  q.items = d_items.as<PartItem>();
+  // one small block: [0] the list cursor (8 bytes), [8] the item count, [16] the two flags
+  q.list_cursor = d_small.as<unsigned long long>();
+  q.n_items = (uint32_t*)(d_small.as<uint8_t>() + 8);
+  q.flags = (uint32_t*)(d_small.as<uint8_t>() + 16);
+
+  uint64_t list_cap = groups_est ? groups_est + groups_est / 16 + 1024 : std::min<uint64_t>(selected, 1ull << 25);
+  list_cap = std::max<uint64_t>(1, std::min(list_cap, selected));
+  // the HBM table behind the LDS tables: groups of buckets that were aggregated in slices, and stragglers
+  uint64_t fb_cap = std::max<uint64_t>(1ull << 16, plan->learned_capacity.load(std::memory_order_relaxed));
+  const uint64_t fb_max = pow2_ceil(std::max<uint64_t>(1024, 2 * selected));
+  fb_cap = std::min(fb_cap, fb_max);
+  const int n_slots = (int)slot_ops.size();
+  const uint64_t rec_bytes = selected * 8 * (uint64_t)words;
+  uint64_t groups = 0;
+  for (;;) {
+    GroupTable fb;
+    table_alloc(ctx, fb, false, fb_cap, slot_ops, ap.key_words);
+    GroupTable list;
+    list.list = true;
+    list.capacity = list_cap;
+    list.n_slots = n_slots;
+    list.key_words = ap.key_words;
+    list.keys = Scratch(ctx, (list_cap + 1) * 8);
+    PRISM_HIP(hipMemsetAsync(list.keys.p, 0xff, (list_cap + 1) * 8, ctx->stream));
+    if (ap.key_words == 2) {
+      list.keys_hi = Scratch(ctx, (list_cap + 1) * 8);
+      PRISM_HIP(hipMemsetAsync(list.keys_hi.p, 0xff, (list_cap + 1) * 8, ctx->stream));
+    }
+    list.state = Scratch(ctx, (list_cap + 1) * 8 * (size_t)n_slots);
+    // slot 0 counts a group's rows: zero marks the entries past the end (and the extra entry)
+    PRISM_HIP(hipMemsetAsync(list.state.p, 0, (list_cap + 1) * 8, ctx->stream));
+    list.overflow = Scratch(ctx, 256);
+    PRISM_HIP(hipMemsetAsync(list.overflow.p, 0, 4, ctx->stream));
+    PRISM_HIP(hipMemsetAsync(d_small.p, 0, 64, ctx->stream));
+    q.list_keys = list.keys.as<uint64_t>();
+    q.list_keys_hi = list.keys_hi.as<uint64_t>();
+    q.list_state = list.state.as<int64_t>();
+    q.list_capacity = list_cap;
+    ap.dense = 0;
+    ap.capacity = fb_cap;
+    ap.g_keys = fb.keys.as<uint64_t>();
+    ap.g_keys_hi = fb.keys_hi.as<uint64_t>();
+    ap.g_state = fb.state.as<int64_t>();
+    ap.overflow = fb.overflow.as<uint32_t>();
+    {
+      // the whole path under the name the one-kernel GROUP BY reports, so that callers price it the same way
+      KernelTimer timer(ctx, "group_by", scan_rows * value_bytes);
+      launch_partitioned_group_by(ctx, ap, q, vals_nullable, scan_rows * key_bytes, scan_rows * value_bytes + rec_bytes, rec_bytes);
+    }
+    struct { unsigned long long cursor; uint32_t n_items, pad; uint32_t flags[2]; } h{};
+    uint32_t fb_flag = 0;
+    PRISM_HIP(hipMemcpyAsync(&h, d_small.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    PRISM_HIP(hipMemcpyAsync(&fb_flag, fb.overflow.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    PRISM_HIP(hipStreamSynchronize(ctx->stream));
+    if (fb_flag) {
+      if (fb_cap >= fb_max) fail(PRISM_GPU_EINTERNAL, "group table overflow at maximum capacity");
+      fb_cap = std::min(fb_max, fb_cap * 4);
+      continue;
+    }
+    groups = h.cursor;
+    if (h.flags[1]) {
+      // groups that went through the HBM table join the list
+      launch_emit(ctx, false, fb.capacity, fb.keys.as<uint64_t>(), fb.keys_hi.as<uint64_t>(), fb.state.as<int64_t>(), n_slots,
+                  list.keys.as<uint64_t>(), list.keys_hi.as<uint64_t>(), list.state.as<int64_t>(), list_cap + 1, q.list_cursor,
+                  nullptr, nullptr, list_cap);
+      PRISM_HIP(hipMemcpyAsync(&h, d_small.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+      PRISM_HIP(hipStreamSynchronize(ctx->stream));
+      groups = h.cursor;
+    }
+    if (groups > list_cap) {
+      // the list was too short (the count is exact now): once more
+      list_cap = groups + 1024;
+      continue;
+    }
+    if (h.flags[1]) plan->learned_capacity.store(fb_cap, std::memory_order_relaxed);
+    gt = std::move(list);
+    break;
+  }
+  plan->part_groups.store(std::max<uint64_t>(1, groups), std::memory_order_relaxed);
+  return groups;
+}
+
 }  // namespace
 
 }  // namespace prism
@@ -1227,7 +1370,10 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
   // Simple predicates are evaluated by the aggregation kernel itself: no bitmap pass, and
   // a predicate on a column the aggregates read anyway costs no memory traffic at all.
   bool fused = false;
-  if (has_pred && !count_only && !plan->distinct_plan && layout.words == 1) {
+  // A plan that partitions its rows evaluates the predicate as a bitmap (the partitioning
+  // kernels take a selection, not a predicate).
+  const bool prefers_part = !plan->keys.empty() && (plan->part_mode.load(std::memory_order_relaxed) == 1 || part_forced(ctx));
+  if (has_pred && !count_only && !plan->distinct_plan && layout.words == 1 && !prefers_part) {
     std::vector<int> leaves;
     if (fusable_leaves(plan, table, plan->pred_root, -1, leaves)) {
       AggParams trial = ap;
@@ -1367,7 +1513,8 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
     ap.sel_bits = sel.bits.as<uint64_t>();
     // Few survivors: compact them into a selection vector so that the aggregation
     // gathers only those rows instead of streaming every column in full.
-    if (selected * 8 < ss.rows && selected > 0) {
+    const bool part_likely = (prefers_part || layout.words == 2 || plan->distinct_plan) && !plan->keys.empty() && selected >= part_min_rows(ctx);
+    if (selected * 8 < ss.rows && selected > 0 && !part_likely) {
       Scratch tile_offsets(ctx, (ss.n_tiles + 1) * 4);
       KernelTimer timer(ctx, "compact_selvec", n_words * 8 + selected * 4);
       launch_compact(ctx, sel.bits.as<uint64_t>(), ss.n_tiles, tile_offsets.as<uint32_t>(), nullptr,
@@ -1479,6 +1626,18 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
     uint64_t bound = selected;
     if (total_bits < 63) bound = std::min<uint64_t>(bound, 1ull << total_bits);
     GroupTable gt;
+    // ---- can, and should, the rows be partitioned by key first? ----
+    bool vals_nullable = false;
+    for (int j = 0; j < ap.n_vals; ++j)
+      for (const Chunk* ch : ss.chunks) vals_nullable = vals_nullable || ch->cols[ss.uses[ap.vals[j].col].column].validity != nullptr;
+    bool part_ok = ap.row_mode != kRowsSelvec && ap.n_pred == 0 && selected >= part_min_rows(ctx) && part_record_words(ap, vals_nullable) > 0;
+    for (const Chunk* ch : ss.chunks) part_ok = part_ok && ch->rows < (1ull << 31);
+    uint64_t key_bytes = 0;
+    for (auto& sp : layout.specs) key_bytes += sp.width;
+    // two-word keys have no LDS stage on the streaming side: every row would be an HBM atomic
+    const bool use_part = part_ok && (layout.words == 2 || prefers_part);
+    // otherwise the streaming kernel runs, and reports it when its rows scatter
+    ap.stop_if_scattered = (!use_part && part_ok && plan->part_mode.load(std::memory_order_relaxed) == 0) ? 1 : 0;
     // The packed key indexes the table directly when the key space is small, or when it is
     // not much larger than the number of rows (say GROUP BY a timestamp in ms over sorted
     // data: neighbouring rows then update neighbouring entries, where a hash table would
@@ -1494,7 +1653,11 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       const uint64_t learned = plan->learned_capacity.load(std::memory_order_relaxed);
       if (learned > capacity) capacity = std::min(learned, max_capacity);
     }
-    for (;;) {
+    if (use_part) {
+      partitioned_group_by(ctx, plan, ap, selected, ss.rows, key_bytes, value_bytes, vals_nullable, slot_ops, gt);
+      dense = false;
+    }
+    while (!use_part) {
       {
         HostTimer ht(ctx, "host:table_alloc");
         table_alloc(ctx, gt, dense, capacity, slot_ops, layout.words);
@@ -1507,11 +1670,26 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       ap.overflow = gt.overflow.as<uint32_t>();
       if (fused) PRISM_HIP(hipMemsetAsync(d_scalar.p, 0, 8, ctx->stream));
       launch_group_by(ctx, ap, (ap.row_mode == kRowsSelvec ? selected : ss.rows) * value_bytes);
-      if (dense || !table_overflowed(ctx, gt)) break;
+      if (dense && !ap.stop_if_scattered) break;
+      const uint32_t flag = table_flag(ctx, gt);
+      if (flag == 3u && ap.stop_if_scattered) {
+        // The rows mostly missed the LDS tables: this plan partitions its rows from now on.
+        // Start over (the predicate may have been evaluated inside the kernel that just
+        // stopped; the partitioning kernels want it as a bitmap).
+        plan->part_mode.store(1, std::memory_order_relaxed);
+        gt = GroupTable();
+        sel.bits.reset();
+        selvec.reset();
+        PRISM_HIP(hipStreamSynchronize(ctx->stream));
+        collect_timings(ctx);
+        execute_impl(plan, table, partition_ids, n_partitions, merge_input, out, stats_override, capture);
+        return;
+      }
+      if (dense || flag == 0u) break;
       if (capacity >= max_capacity) fail(PRISM_GPU_EINTERNAL, "group table overflow at maximum capacity");
       capacity = std::min(max_capacity, capacity * 4);  // more groups than expected: grow and redo the pass
     }
-    if (!dense) plan->learned_capacity.store(capacity, std::memory_order_relaxed);
+    if (!dense && !use_part) plan->learned_capacity.store(capacity, std::memory_order_relaxed);
     // lands with the next synchronisation of the stream (every path below has one before the statistics)
     if (fused) PRISM_HIP(hipMemcpyAsync(&fused_selected, d_scalar.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     if (capture) {
@@ -1744,7 +1922,7 @@ void state_merge(prism_gpu_state* st, const void* device_src, uint64_t n_groups)
     // room for every incoming group being new; otherwise rebuild a larger table first
     state_compact(st);
     const uint64_t need = st->c_n + n_groups;
-    if (need * 2 > st->gt.capacity) {
+    if (st->gt.list || need * 2 > st->gt.capacity) {
       GroupTable bigger;
       table_alloc(ctx, bigger, false, pow2_ceil(std::max<uint64_t>(1024, need * 2)), st->slot_ops, 1);
       MergeParams own = merge_params(st, bigger);

@@ -183,6 +183,7 @@ struct AggParams {
   int32_t dense;
   int32_t key_bits;     // bits of the packed key in use
   int32_t lds_slots;    // power of two; 0 = no LDS pre-aggregation
+  int32_t stop_if_scattered;  // non-zero: a workgroup whose rows keep missing its LDS table sets *overflow = 3 and the launch winds down
   int32_t window_hint;  // non-zero: time buckets sit in the key's bits from (window_hint - 1) up, so the keys may be narrow at any one time
   uint64_t capacity;    // dense: number of entries; hash: power of two
   uint64_t* g_keys;     // hash only: capacity + 1 entries (last = the all-ones key)
@@ -214,6 +215,50 @@ void launch_agg_global(prism_gpu_ctx* ctx, const AggParams& p, int64_t* out);
 // evaluates AggParams::pred).  Looks at n_keys, keys, key_bits, key_words, n_vals, lds_slots, row_mode.
 bool group_by_streams(const AggParams& p);
 void launch_group_by(prism_gpu_ctx* ctx, const AggParams& p, uint64_t algorithmic_bytes, const char* stat_name = "group_by");
+// ---- partitioned GROUP BY (kernels_part.hip) ----------------------------------------------
+// Rows are partitioned by a hash of their packed key into n_buckets buckets in HBM, then
+// every bucket is aggregated in LDS and its groups appended to a compact list; the
+// AggParams' HBM hash table only takes the groups of buckets too large for one workgroup
+// and rows that found the LDS table full.
+struct PartItem {
+  uint32_t bucket, exclusive;  // exclusive: the item is a whole bucket
+  uint64_t lo, hi;             // records [lo, hi)
+};
+struct PartParams {
+  int32_t p_bits;          // log2(n_buckets)
+  uint32_t n_buckets;
+  uint32_t n_wg;           // workgroups of the histogram and scatter passes (the same rows in both)
+  uint32_t tiles_per_wg;   // scan tiles per workgroup, a multiple of 4
+  uint32_t* hist;          // [n_wg][n_buckets]
+  uint32_t* totals;        // [n_buckets]
+  uint64_t* bucket_base;   // [n_buckets + 1]
+  uint64_t* rec[4];        // record words, one array per word
+  uint64_t rec_capacity;   // records each array holds
+  PartItem* items;
+  uint32_t* n_items;
+  uint32_t max_items;
+  uint32_t chunk_rows;     // a bucket with more rows is aggregated in slices
+  uint32_t lds_entries;    // entries of the aggregation pass' LDS table
+  uint32_t lds_limit;      // entries it may fill
+  // the list: entry i of [0, *list_cursor) is a group; arrays are laid out like a hash
+  // table's with list_capacity entries (slot s of entry i at s * (list_capacity + 1) + i)
+  uint64_t* list_keys;
+  uint64_t* list_keys_hi;
+  int64_t* list_state;
+  uint64_t list_capacity;
+  unsigned long long* list_cursor;
+  uint32_t* flags;         // [0]: the list overflowed, [1]: rows / groups sent to the HBM table
+};
+// 8-byte words of a row's record for this plan shape (key words + value columns + one word
+// of validity bits when a value column has NULLs); 0: the shape has no partitioned kernels.
+int part_record_words(const AggParams& p, bool vals_nullable);
+uint32_t part_max_buckets(int words);
+uint32_t part_lds_entries(const AggParams& p);
+uint32_t part_scan_workgroups(prism_gpu_ctx* ctx, const AggParams& p, uint32_t* tiles_per_wg);
+// (hist_bytes, scatter_bytes, agg_bytes: algorithmic bytes of the three passes, for the statistics)
+void launch_partitioned_group_by(prism_gpu_ctx* ctx, const AggParams& p, const PartParams& q, bool vals_nullable,
+                                 uint64_t hist_bytes, uint64_t scatter_bytes, uint64_t agg_bytes);
+
 // Second level of COUNT(DISTINCT x) GROUP BY k: every occupied entry of the
 // (k, x) set adds 1 (when its x field is not NULL) to group k of table `q`.
 struct DistinctFoldParams {
@@ -319,11 +364,12 @@ void launch_merge_packed(prism_gpu_ctx* ctx, const MergeParams& p);
 // Fills n entries with `value`.
 void launch_fill_i64(prism_gpu_ctx* ctx, int64_t* dst, uint64_t n, int64_t value);
 // Compacts the occupied entries of a table: out_keys[i], out_state[s * out_stride + i].
-// g_keys_hi / out_keys_hi are non-null for two-word keys.
+// g_keys_hi / out_keys_hi are non-null for two-word keys.  Entries whose position (counted
+// from *out_count's value on entry) is out_limit or more are counted but not written.
 void launch_emit(prism_gpu_ctx* ctx, bool dense, uint64_t capacity, const uint64_t* g_keys, const uint64_t* g_keys_hi,
                  const int64_t* g_state, int n_slots, uint64_t* out_keys, uint64_t* out_keys_hi, int64_t* out_state,
                  uint64_t out_stride, unsigned long long* out_count, const TopKOrder* order = nullptr,
-                 TopKState* d_threshold = nullptr);
+                 TopKState* d_threshold = nullptr, uint64_t out_limit = ~0ull);
 
 // ---- loader support ----------------------------------------------------------
 

@@ -562,7 +562,7 @@ __global__ __launch_bounds__(kBlock) void k_emit(int dense, uint64_t capacity, c
                                                 const uint64_t* g_keys_hi, const long long* g_state, int n_slots,
                                                 uint64_t* out_keys, uint64_t* out_keys_hi, long long* out_state,
                                                 uint64_t out_stride, unsigned long long* out_count, int filtered,
-                                                TopKOrder order, TopKState* threshold) {
+                                                TopKOrder order, TopKState* threshold, uint64_t out_limit) {
   const uint64_t n = dense ? capacity : capacity + 1;
   const uint64_t min_rank = filtered ? threshold->prefix : 0ull;
   const bool exact = filtered && threshold->exact != 0;
@@ -597,6 +597,7 @@ __global__ __launch_bounds__(kBlock) void k_emit(int dense, uint64_t capacity, c
     first = __shfl(first, __ffsll((long long)m) - 1);
     if (!take || out_keys == nullptr) continue;  // counting pass
     const unsigned long long pos = first + __popcll(m & ((1ull << lane) - 1));
+    if (pos >= out_limit) continue;
     out_keys[pos] = dense ? i : (i == capacity ? kEmptyKey : g_keys[i]);
     if (out_keys_hi) out_keys_hi[pos] = i == capacity ? 0ull : g_keys_hi[i];
     for (int s = 0; s < n_slots; ++s) out_state[(uint64_t)s * out_stride + pos] = g_state[(uint64_t)s * (capacity + 1) + i];
@@ -779,7 +780,7 @@ void launch_fill_i64(prism_gpu_ctx* ctx, int64_t* dst, uint64_t n, int64_t value
 void launch_emit(prism_gpu_ctx* ctx, bool dense, uint64_t capacity, const uint64_t* g_keys, const uint64_t* g_keys_hi,
                  const int64_t* g_state, int n_slots, uint64_t* out_keys, uint64_t* out_keys_hi, int64_t* out_state,
                  uint64_t out_stride, unsigned long long* out_count, const TopKOrder* order,
-                 TopKState* d_threshold) {
+                 TopKState* d_threshold, uint64_t out_limit) {
   uint64_t n = dense ? capacity : capacity + 1;
   if (n == 0) return;
   TopKOrder o{};
@@ -790,7 +791,7 @@ void launch_emit(prism_gpu_ctx* ctx, bool dense, uint64_t capacity, const uint64
   k_emit<<<dim3(stream_grid(ctx, n)), dim3(kBlock), 0, ctx->stream>>>(dense ? 1 : 0, capacity, g_keys, g_keys_hi,
                                                                     (const long long*)g_state, n_slots, out_keys,
                                                                     out_keys_hi, (long long*)out_state, out_stride,
-                                                                    out_count, order ? 1 : 0, o, d_threshold);
+                                                                    out_count, order ? 1 : 0, o, d_threshold, out_limit);
   PRISM_HIP(hipGetLastError());
 }
 

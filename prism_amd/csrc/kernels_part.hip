@@ -1,0 +1,621 @@
+// Partitioned GROUP BY: the path for group sets that fit neither a workgroup's LDS table
+// nor a time window.
+//
+// A device-scope atomic on this part is carried out at the memory side, at roughly 20 G
+// requests per second for the whole chip, whatever the size of the table it lands in.  A
+// GROUP BY whose rows mostly miss the LDS table therefore runs at that rate (about 0.2 TB/s
+// of input) instead of the 6 TB/s the columns could be read at.  This file removes the
+// per-row atomics: the rows are first partitioned by a hash of their packed key into
+// buckets, in HBM, with plain stores; then every bucket is aggregated by one workgroup in an
+// LDS table (LDS atomics only), and because a key lives in exactly one bucket the finished
+// groups are written out with plain stores as well, as a compact list.
+//
+//   k_part_hist     rows of every workgroup per bucket (LDS histogram)
+//   k_part_offsets  per bucket: where each workgroup's rows start inside the bucket
+//   k_part_plan     bucket starts, and the work items of the aggregation pass: a bucket, or
+//                   a slice of a bucket that holds more than chunk_rows rows (a heavy hitter)
+//   k_part_scatter  the same rows again: packed key and widened aggregate inputs of a row
+//                   form a record of W 8-byte words; a tile of records is counting-sorted by
+//                   bucket inside LDS and then copied out, so that neighbouring lanes store
+//                   to neighbouring addresses of one bucket
+//   k_part_agg      one work item per workgroup at a time: LDS open-addressing table over the
+//                   item's records; a whole bucket appends its groups to the list (one atomic
+//                   per bucket to reserve the space), a slice merges them into a small HBM
+//                   hash table with atomics, as do rows that find the LDS table full
+//
+// Traffic per row: key and value columns twice (histogram and scatter), the record written
+// once and read once.
+#include <algorithm>
+
+#include "agg_device.hpp"
+
+namespace prism {
+
+namespace {
+
+constexpr uint32_t kPartBlock = 1024;
+constexpr uint32_t kPartRowsPerTileThread = kTileRows / kPartBlock;  // 4
+constexpr int kPartAggInFlight = 4;
+
+typedef unsigned long long __attribute__((aligned(1))) part_unaligned_u64;
+typedef const __attribute__((address_space(1))) unsigned char* PartBytePtr;
+typedef const __attribute__((address_space(1))) unsigned long long* PartWordPtr;
+
+__device__ __forceinline__ uint64_t part_uniform(uint64_t v) {
+  uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// A fixed-width value from the 8 bytes loaded at its address (the bytes beyond it belong to
+// the next rows or to the allocation's padding).  The width is a plan fact: scalar branches.
+__device__ __forceinline__ long long part_widen(unsigned long long raw, int width, int is_unsigned) {
+  if (width == 8) return (long long)raw;
+  if (width == 4) return is_unsigned ? (long long)(uint32_t)raw : (long long)(int32_t)(uint32_t)raw;
+  return is_unsigned ? (long long)(uint16_t)raw : (long long)(int16_t)(uint16_t)raw;
+}
+
+template <int KW>
+__device__ __forceinline__ uint64_t part_hash(uint64_t lo, uint64_t hi) {
+  return KW == 2 ? hash64(lo ^ hash64(hi)) : hash64(lo);
+}
+
+// One scan tile (kTileRows rows of one segment) as a workgroup sees it; wave uniform.
+struct PartTile {
+  uint32_t seg;   // segment the tile lies in
+  uint32_t n;     // rows of the tile that exist (0: the tile is beyond the workgroup's share)
+  uint64_t row0;  // first row of the tile inside its segment
+  uint64_t tile;  // the tile's number (selection bitmaps are indexed by it)
+};
+
+__device__ __forceinline__ PartTile part_tile(const AggParams& p, uint64_t tile, uint64_t t1) {
+  PartTile r;
+  r.seg = 0; r.n = 0; r.row0 = 0; r.tile = 0;
+  if (tile >= t1) return r;
+  const uint32_t seg = __builtin_amdgcn_readfirstlane(find_seg(p.sd, tile));
+  const uint64_t rows = part_uniform(p.sd.segs[seg].rows), base = part_uniform(p.sd.segs[seg].tile_base);
+  r.seg = seg;
+  r.row0 = (tile - base) * kTileRows;
+  const uint64_t left = rows - r.row0;
+  r.n = left > kTileRows ? kTileRows : (uint32_t)left;
+  r.tile = tile;
+  return r;
+}
+
+// Packed keys of the R rows a thread owns in R / 4 consecutive scan tiles (rows tid,
+// tid + 1024, ... of each).  Every lane loads, rows that do not exist or are not selected
+// load a row that does and are dropped by `live` (bit r).  All loads of one key column are
+// issued before the first is used.
+template <int KW, int R>
+__device__ __forceinline__ void part_load_keys(const AggParams& p, const PartTile (&tl)[R / 4], uint32_t tid,
+                                               uint64_t (&lo)[R], uint64_t (&hi)[R], uint32_t (&rowc)[R], uint32_t& live) {
+  live = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const PartTile& t = tl[r >> 2];
+    const uint32_t in_tile = (uint32_t)(r & 3) * kPartBlock + tid;
+    bool in = in_tile < t.n;
+    rowc[r] = (uint32_t)t.row0 + (in ? in_tile : 0u);
+    if (p.row_mode == kRowsBitmap) {
+      const uint64_t pid = t.tile * kTileRows + in_tile;
+      const uint64_t word = in ? p.sel_bits[pid >> 6] : 0ull;
+      in = in && ((word >> (pid & 63)) & 1ull);
+    }
+    live |= (in ? 1u : 0u) << r;
+    lo[r] = 0;
+    hi[r] = 0;
+  }
+  for (int k = 0; k < p.n_keys; ++k) {
+    const KeySpec& ks = p.keys[k];
+    unsigned long long raw[R];
+    bool ok[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const ColPtr& c = p.cols[(uint64_t)ks.col * p.sd.n_segs + tl[r >> 2].seg];
+      const PartBytePtr base = (PartBytePtr)(uint64_t)c.values;
+      // (a chunk's column is shorter than 4 GiB: the byte offset fits 32 bits, and the load takes
+      // its base from scalar registers)
+      raw[r] = __builtin_nontemporal_load((const __attribute__((address_space(1))) part_unaligned_u64*)(base + rowc[r] * (uint32_t)ks.width));
+      ok[r] = ks.null_bit < 0 || valid_at(c.validity, rowc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      long long v = part_widen(raw[r], ks.width, ks.is_unsigned);
+      if (ks.date_bin) v = bucket_number(v, ks);
+      const uint64_t field = ok[r] ? (((uint64_t)v - (uint64_t)ks.bias) << ks.bit_pos) : (1ull << (ks.null_bit >= 0 ? ks.null_bit : 0));
+      if (KW == 2 && ks.word) hi[r] |= field; else lo[r] |= field;
+    }
+  }
+}
+
+// The aggregate inputs of the same rows, widened to 64 bits; validw[r] bit v = value v is not NULL.
+template <int NV, bool VALID, int R>
+__device__ __forceinline__ void part_load_vals(const AggParams& p, const PartTile (&tl)[R / 4], const uint32_t (&rowc)[R],
+                                               uint64_t (&val)[NV > 0 ? NV : 1][R], uint64_t (&validw)[R]) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) validw[r] = 0;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const ValSpec& vs = p.vals[v];
+    unsigned long long raw[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const ColPtr& c = p.cols[(uint64_t)vs.col * p.sd.n_segs + tl[r >> 2].seg];
+      const PartBytePtr base = (PartBytePtr)(uint64_t)c.values;
+      raw[r] = __builtin_nontemporal_load((const __attribute__((address_space(1))) part_unaligned_u64*)(base + rowc[r] * (uint32_t)vs.width));
+      if (VALID) validw[r] |= (valid_at(c.validity, rowc[r]) ? 1ull : 0ull) << v;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) val[v][r] = (uint64_t)part_widen(raw[r], vs.width, vs.is_unsigned);
+  }
+}
+
+// Exclusive scan of a[0..n) in place (n a power of two between 64 and 4 * kPartBlock), the
+// total in a[n].  Block wide; the caller puts a barrier in front and behind.
+__device__ __forceinline__ void part_block_scan(uint32_t* a, uint32_t n, uint32_t* wave_tot) {
+  const uint32_t tid = threadIdx.x, per = n >= kPartBlock ? n / kPartBlock : 1u;
+  uint32_t v[4], sum = 0;
+#pragma unroll
+  for (uint32_t i = 0; i < 4; ++i) {
+    const uint32_t e = tid * per + i;
+    v[i] = (i < per && e < n) ? a[e] : 0u;
+    sum += v[i];
+  }
+  uint32_t incl = sum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = __shfl_up(incl, off, 64);
+    if ((int)(tid & 63u) >= off) incl += o;
+  }
+  if ((tid & 63u) == 63u) wave_tot[tid >> 6] = incl;
+  __syncthreads();
+  uint32_t before = 0;
+  for (uint32_t w = 0; w < (tid >> 6); ++w) before += wave_tot[w];
+  uint32_t run = before + incl - sum;
+#pragma unroll
+  for (uint32_t i = 0; i < 4; ++i) {
+    const uint32_t e = tid * per + i;
+    if (i < per && e < n) { a[e] = run; run += v[i]; }
+  }
+  if (tid == kPartBlock - 1) a[n] = before + incl;
+}
+
+// ---- pass 1a: histogram ------------------------------------------------------------
+
+template <int KW>
+__global__ __launch_bounds__(kPartBlock) void k_part_hist(AggParams p, PartParams q) {
+  constexpr int R = 8;
+  extern __shared__ __align__(16) unsigned long long part_lds[];
+  uint32_t* h = (uint32_t*)part_lds;
+  const uint32_t tid = threadIdx.x, P = q.n_buckets;
+  for (uint32_t b = tid; b < P; b += kPartBlock) h[b] = 0;
+  __syncthreads();
+  const uint64_t t0 = (uint64_t)blockIdx.x * q.tiles_per_wg;
+  const uint64_t t1 = t0 + q.tiles_per_wg < p.sd.n_tiles ? t0 + q.tiles_per_wg : p.sd.n_tiles;
+  const int shift = 64 - q.p_bits;
+  for (uint64_t t = t0; t < t1; t += R / 4) {
+    PartTile tl[R / 4];
+#pragma unroll
+    for (int j = 0; j < R / 4; ++j) tl[j] = part_tile(p, t + j, t1);
+    uint64_t lo[R], hi[R];
+    uint32_t rowc[R], live;
+    part_load_keys<KW, R>(p, tl, tid, lo, hi, rowc, live);
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if ((live >> r) & 1u) atomicAdd(&h[(uint32_t)(part_hash<KW>(lo[r], hi[r]) >> shift)], 1u);
+  }
+  __syncthreads();
+  for (uint32_t b = tid; b < P; b += kPartBlock) q.hist[(uint64_t)blockIdx.x * P + b] = h[b];
+}
+
+// hist[wg][b] becomes the number of rows of bucket b that workgroups before wg hold;
+// totals[b] the rows of the bucket.
+__global__ __launch_bounds__(kBlock) void k_part_offsets(PartParams q) {
+  const uint32_t b = blockIdx.x * kBlock + threadIdx.x;
+  if (b >= q.n_buckets) return;
+  uint32_t run = 0;
+  for (uint32_t wg = 0; wg < q.n_wg; ++wg) {
+    const uint64_t i = (uint64_t)wg * q.n_buckets + b;
+    const uint32_t c = q.hist[i];
+    q.hist[i] = run;
+    run += c;
+  }
+  q.totals[b] = run;
+}
+
+// One workgroup: bucket starts and the work items of the aggregation pass.
+__global__ __launch_bounds__(kPartBlock) void k_part_plan(PartParams q) {
+  __shared__ uint32_t a[4 * kPartBlock + 1];
+  __shared__ uint32_t wave_tot[kPartBlock / 64];
+  const uint32_t tid = threadIdx.x, P = q.n_buckets;
+  for (uint32_t b = tid; b < P; b += kPartBlock) a[b] = q.totals[b];
+  __syncthreads();
+  part_block_scan(a, P, wave_tot);
+  __syncthreads();
+  for (uint32_t b = tid; b <= P; b += kPartBlock) q.bucket_base[b] = a[b];
+  __syncthreads();
+  // chunks per bucket
+  for (uint32_t b = tid; b < P; b += kPartBlock) a[b] = (uint32_t)ceil_div((uint64_t)q.totals[b], (uint64_t)q.chunk_rows);
+  __syncthreads();
+  part_block_scan(a, P, wave_tot);
+  __syncthreads();
+  for (uint32_t b = tid; b < P; b += kPartBlock) {
+    const uint32_t first = a[b], n = a[b + 1] - first;
+    const uint64_t lo = q.bucket_base[b], hi = q.bucket_base[b + 1];
+    for (uint32_t c = 0; c < n; ++c) {
+      if (first + c >= q.max_items) break;
+      PartItem it;
+      it.bucket = b;
+      it.exclusive = n == 1 ? 1u : 0u;
+      it.lo = lo + (uint64_t)c * q.chunk_rows;
+      it.hi = it.lo + q.chunk_rows < hi ? it.lo + q.chunk_rows : hi;
+      q.items[first + c] = it;
+    }
+  }
+  if (tid == 0) *q.n_items = a[P] < q.max_items ? a[P] : q.max_items;
+}
+
+// ---- pass 1b: scatter ------------------------------------------------------------------
+
+template <int W>
+constexpr int part_rows_per_thread() { return W == 1 ? 16 : (W == 2 ? 8 : 4); }
+
+template <int KW, int NV, bool VALID>
+__global__ __launch_bounds__(kPartBlock) void k_part_scatter(AggParams p, PartParams q) {
+  constexpr int W = KW + NV + (VALID ? 1 : 0);
+  constexpr int R = part_rows_per_thread<W>();
+  constexpr uint32_t T = (uint32_t)R * kPartBlock;
+  extern __shared__ __align__(16) unsigned long long part_lds[];
+  __shared__ uint32_t wave_tot[kPartBlock / 64];
+  unsigned long long* sorted = part_lds;                  // [W][T]
+  uint32_t* start = (uint32_t*)(part_lds + (size_t)W * T);  // [P + 1]: rows of the tile per bucket, then their first slot
+  const uint32_t tid = threadIdx.x, P = q.n_buckets;
+  uint32_t* cursor = start + P + 2;                       // [P]: next record of this workgroup in each bucket
+  for (uint32_t b = tid; b < P; b += kPartBlock) {
+    cursor[b] = (uint32_t)q.bucket_base[b] + q.hist[(uint64_t)blockIdx.x * P + b];
+    start[b] = 0;
+  }
+  if (tid == 0) start[P] = 0;
+  __syncthreads();
+  const uint64_t t0 = (uint64_t)blockIdx.x * q.tiles_per_wg;
+  const uint64_t t1 = t0 + q.tiles_per_wg < p.sd.n_tiles ? t0 + q.tiles_per_wg : p.sd.n_tiles;
+  const int shift = 64 - q.p_bits;
+  for (uint64_t t = t0; t < t1; t += R / 4) {
+    PartTile tl[R / 4];
+#pragma unroll
+    for (int j = 0; j < R / 4; ++j) tl[j] = part_tile(p, t + j, t1);
+    uint64_t rec[W][R];
+    uint32_t rowc[R], live;
+    {
+      uint64_t hi_unused[R];
+      part_load_keys<KW, R>(p, tl, tid, rec[0], KW == 2 ? rec[KW - 1] : hi_unused, rowc, live);
+    }
+    if constexpr (NV > 0) {
+      uint64_t val[NV][R], validw[R];
+      part_load_vals<NV, VALID, R>(p, tl, rowc, val, validw);
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int r = 0; r < R; ++r) rec[KW + v][r] = val[v][r];
+      if constexpr (VALID) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) rec[W - 1][r] = validw[r];
+      }
+    }
+    // rank of every row among the tile's rows of its bucket
+    uint32_t slot[R];  // bucket (low 12 bits) and rank inside it (a tile holds at most 2^14 rows)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const uint32_t b = (uint32_t)(part_hash<KW>(rec[0][r], KW == 2 ? rec[KW - 1][r] : 0ull) >> shift);
+      slot[r] = b;
+      if ((live >> r) & 1u) slot[r] |= atomicAdd(&start[b], 1u) << 12;
+    }
+    __syncthreads();
+    part_block_scan(start, P, wave_tot);
+    __syncthreads();
+    // the tile's records, sorted by bucket, in LDS
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (!((live >> r) & 1u)) continue;
+      const uint32_t pos = start[slot[r] & 0xfffu] + (slot[r] >> 12);
+#pragma unroll
+      for (int w = 0; w < W; ++w) sorted[(size_t)w * T + pos] = rec[w][r];
+    }
+    __syncthreads();
+    // out: neighbouring lanes hold neighbouring records of one bucket
+    const uint32_t n_live = start[P];
+    for (uint32_t i = tid; i < n_live; i += kPartBlock) {
+      uint64_t w0 = sorted[i], w1 = KW == 2 ? sorted[(size_t)T + i] : 0ull;
+      const uint32_t b = (uint32_t)(part_hash<KW>(w0, w1) >> shift);
+      const uint64_t g = (uint64_t)cursor[b] + (i - start[b]);
+      if (g < q.rec_capacity) {
+        q.rec[0][g] = w0;
+        if (KW == 2) q.rec[1][g] = w1;
+#pragma unroll
+        for (int w = KW; w < W; ++w) q.rec[w][g] = sorted[(size_t)w * T + i];
+      }
+    }
+    __syncthreads();
+    uint32_t cnt[4];
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) {
+      const uint32_t b = tid + i * kPartBlock;
+      cnt[i] = b < P ? start[b + 1] - start[b] : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) {
+      const uint32_t b = tid + i * kPartBlock;
+      if (b < P) { cursor[b] += cnt[i]; start[b] = 0; }
+    }
+    if (tid == 0) start[P] = 0;
+    __syncthreads();
+  }
+}
+
+// ---- pass 2: aggregation of one bucket (or slice) in LDS -----------------------------------
+
+constexpr unsigned long long kPartEmpty = ~0ull;
+constexpr int kPartMaxProbes = 128;
+
+__device__ __forceinline__ unsigned long long lds_load(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Entry of the key in the LDS table, inserted when absent; -1: the table is full for this
+// key (it stays full: an item never removes entries, so the key's rows all take the same way).
+template <int KW>
+__device__ __forceinline__ int part_lds_entry(unsigned long long* keys_lo, unsigned long long* keys_hi, uint32_t S,
+                                              int limit, int* n_entries, uint64_t lo, uint64_t hi, uint64_t h) {
+  uint32_t idx = __umulhi((uint32_t)h, S);
+  int probes = 0;
+  while (probes < kPartMaxProbes) {
+    unsigned long long k = lds_load(&keys_lo[idx]);
+    if (k == kPartEmpty) {
+      if (__hip_atomic_load(n_entries, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= limit) return -1;
+      const unsigned long long old = atomicCAS(&keys_lo[idx], kPartEmpty, (unsigned long long)lo);
+      if (old == kPartEmpty) {
+        if (KW == 2) __hip_atomic_store(&keys_hi[idx], (unsigned long long)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        atomicAdd(n_entries, 1);
+        return (int)idx;
+      }
+      k = old;
+    }
+    if (k == lo) {
+      if (KW == 1) return (int)idx;
+      // the claimant of the entry publishes the high word right after its CAS: until then it reads all ones
+      const unsigned long long kh = lds_load(&keys_hi[idx]);
+      if (kh == hi) return (int)idx;
+      if (kh == kPartEmpty) continue;  // not published yet: look again
+    }
+    idx = idx + 1 == S ? 0u : idx + 1;
+    ++probes;
+  }
+  return -1;
+}
+
+template <int KW, int NV>
+__device__ __forceinline__ void part_hbm_update(const AggParams& p, uint64_t lo, uint64_t hi, const RowValsT<NV>& rv) {
+  if (KW == 1) {
+    if (p.keys_only) { (void)global_entry(p, lo); return; }
+    global_update(p, lo, rv);
+    return;
+  }
+  const uint64_t e = global_entry2(p, lo, hi);
+  if (e == ~0ull || p.keys_only) return;
+  for (int s = 0; s < p.n_slots; ++s) {
+    long long x;
+    if (slot_input(p, s, rv, x)) atomic_apply(&p.g_state[(uint64_t)s * (p.capacity + 1) + e], p.slots[s].op, x);
+  }
+}
+
+template <int KW, int NV, bool VALID>
+__global__ __launch_bounds__(kPartBlock) void k_part_agg(AggParams p, PartParams q) {
+  constexpr int W = KW + NV + (VALID ? 1 : 0);
+  extern __shared__ __align__(16) unsigned long long part_lds[];
+  __shared__ int n_entries;
+  __shared__ uint32_t wg_pos, gave_up;
+  __shared__ unsigned long long out_base;
+  const uint32_t S = q.lds_entries, tid = threadIdx.x, lane = tid & 63u;
+  const int n_lds_slots = p.keys_only ? 0 : p.n_slots;
+  unsigned long long* keys_lo = part_lds;
+  unsigned long long* keys_hi = part_lds + (KW == 2 ? S : 0);
+  long long* state = (long long*)(part_lds + (size_t)KW * S);  // [n_lds_slots][S]
+  const uint32_t n_items = *q.n_items;
+  for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+    // (the HBM table overflowed: the whole pass will be run again; one thread looks, so that
+    // the workgroup leaves as a whole)
+    if (tid == 0) gave_up = table_gave_up(p) ? 1u : 0u;
+    __syncthreads();
+    if (gave_up) return;
+    const PartItem it = q.items[item];
+    for (uint32_t i = tid; i < S; i += kPartBlock) {
+      keys_lo[i] = kPartEmpty;
+      if (KW == 2) keys_hi[i] = kPartEmpty;
+      for (int s = 0; s < n_lds_slots; ++s) state[(size_t)s * S + i] = slot_identity(p.slots[s].op);
+    }
+    if (tid == 0) { n_entries = 0; wg_pos = 0; }
+    __syncthreads();
+    for (uint64_t base = it.lo; base < it.hi; base += (uint64_t)kPartAggInFlight * kPartBlock) {
+      uint64_t rec[kPartAggInFlight][W];
+      bool in[kPartAggInFlight];
+#pragma unroll
+      for (int u = 0; u < kPartAggInFlight; ++u) {
+        const uint64_t i = base + (uint64_t)u * kPartBlock + tid;
+        in[u] = i < it.hi;
+        const uint64_t ic = in[u] ? i : it.lo;
+#pragma unroll
+        for (int w = 0; w < W; ++w) rec[u][w] = __builtin_nontemporal_load((PartWordPtr)(uint64_t)(q.rec[w] + ic));
+      }
+#pragma unroll
+      for (int u = 0; u < kPartAggInFlight; ++u) {
+        if (!in[u]) continue;
+        const uint64_t lo = rec[u][0], hi = KW == 2 ? rec[u][KW - 1] : 0ull;
+        RowValsT<NV> rv;
+        rv.valid = VALID ? (uint32_t)rec[u][W - 1] : 0xffffffffu;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) rv.v[v] = (long long)rec[u][KW + v];
+        // (a one-word key of all ones is the table's empty marker: it lives in the HBM table)
+        const int e = lo == kPartEmpty ? -1
+                                       : part_lds_entry<KW>(keys_lo, keys_hi, S, (int)q.lds_limit, &n_entries, lo, hi, part_hash<KW>(lo, hi));
+        if (e < 0) {
+          atomicAdd(&q.flags[1], 1u);
+          part_hbm_update<KW, NV>(p, lo, hi, rv);
+          continue;
+        }
+        for (int s = 0; s < n_lds_slots; ++s) {
+          long long x;
+          if (slot_input(p, s, rv, x)) atomic_apply(&state[(size_t)s * S + (uint32_t)e], p.slots[s].op, x);
+        }
+      }
+    }
+    __syncthreads();
+    const uint32_t n = (uint32_t)n_entries;
+    if (it.exclusive) {
+      // the bucket's groups are nobody else's: append them to the list
+      if (tid == 0) out_base = atomicAdd(q.list_cursor, (unsigned long long)n);
+      __syncthreads();
+      const uint64_t first = out_base;
+      const bool fits = first + n <= q.list_capacity;
+      if (!fits && tid == 0) q.flags[0] = 1u;
+      const uint64_t stride = q.list_capacity + 1;
+      for (uint32_t i0 = 0; i0 < S && fits; i0 += kPartBlock) {
+        const uint32_t i = i0 + tid;
+        const unsigned long long k = i < S ? keys_lo[i] : kPartEmpty;
+        const bool occ = k != kPartEmpty;
+        const uint64_t m = __ballot(occ);
+        uint32_t wave_first = 0;
+        if (lane == 0 && m) wave_first = atomicAdd(&wg_pos, (uint32_t)__popcll(m));
+        wave_first = __shfl(wave_first, 0);
+        if (!occ) continue;
+        const uint64_t pos = first + wave_first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        q.list_keys[pos] = k;
+        if (KW == 2) q.list_keys_hi[pos] = keys_hi[i];
+        for (int s = 0; s < n_lds_slots; ++s) q.list_state[(uint64_t)s * stride + pos] = state[(size_t)s * S + i];
+      }
+    } else {
+      // a slice of a large bucket: other slices hold the same keys, merge through the HBM table
+      for (uint32_t i = tid; i < S; i += kPartBlock) {
+        const unsigned long long k = keys_lo[i];
+        if (k == kPartEmpty) continue;
+        const uint64_t e = KW == 2 ? global_entry2(p, k, keys_hi[i]) : global_entry(p, k);
+        if (e == ~0ull) continue;
+        for (int s = 0; s < n_lds_slots; ++s) {
+          const int op = p.slots[s].op;
+          const long long v = state[(size_t)s * S + i];
+          if (v != slot_identity(op)) atomic_apply(&p.g_state[(uint64_t)s * (p.capacity + 1) + e], op, v);
+        }
+      }
+      if (tid == 0 && n) atomicAdd(&q.flags[1], n);
+    }
+    __syncthreads();
+  }
+}
+
+using PartKernel = void (*)(AggParams, PartParams);
+
+struct PartKernels {
+  PartKernel hist, scatter, agg;
+  int words;
+};
+
+template <int KW, int NV, bool VALID>
+PartKernels part_kernels() {
+  return {k_part_hist<KW>, k_part_scatter<KW, NV, VALID>, k_part_agg<KW, NV, VALID>, KW + NV + (VALID ? 1 : 0)};
+}
+
+bool pick_part_kernels(int kw, int nv, bool valid, PartKernels* out) {
+  if (valid && nv == 0) valid = false;
+  const int code = kw * 100 + nv * 10 + (valid ? 1 : 0);
+  switch (code) {
+    case 100: *out = part_kernels<1, 0, false>(); return true;
+    case 110: *out = part_kernels<1, 1, false>(); return true;
+    case 111: *out = part_kernels<1, 1, true>(); return true;
+    case 120: *out = part_kernels<1, 2, false>(); return true;
+    case 121: *out = part_kernels<1, 2, true>(); return true;
+    case 130: *out = part_kernels<1, 3, false>(); return true;
+    case 200: *out = part_kernels<2, 0, false>(); return true;
+    case 210: *out = part_kernels<2, 1, false>(); return true;
+    case 211: *out = part_kernels<2, 1, true>(); return true;
+    case 220: *out = part_kernels<2, 2, false>(); return true;
+    default: return false;
+  }
+}
+
+constexpr size_t kPartLdsBytes = 160 * 1024 - 1024;  // dynamic LDS of the scatter and aggregation kernels' workgroups (one per CU)
+
+void allow_lds(PartKernel k, size_t bytes) {
+  if (bytes > 48 * 1024) PRISM_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+}
+
+}  // namespace
+
+int part_record_words(const AggParams& p, bool vals_nullable) {
+  PartKernels k;
+  if (!pick_part_kernels(p.key_words, p.keys_only ? 0 : p.n_vals, vals_nullable, &k)) return 0;
+  return k.words;
+}
+
+uint32_t part_max_buckets(int words) {
+  // scatter workgroup: W * R * 1024 records of 8 bytes, (P + 2) + P counters of 4 bytes
+  const size_t tile = (size_t)words * (words == 1 ? 16 : (words == 2 ? 8 : 4)) * kPartBlock * 8;
+  size_t p = 64;
+  while (p * 2 <= 4 * kPartBlock && tile + (2 * (p * 2) + 2) * 4 <= kPartLdsBytes) p *= 2;
+  return (uint32_t)p;
+}
+
+uint32_t part_lds_entries(const AggParams& p) {
+  const size_t per_entry = 8 * ((size_t)p.key_words + (p.keys_only ? 0 : (size_t)p.n_slots));
+  return (uint32_t)(kPartLdsBytes / per_entry);
+}
+
+uint32_t part_scan_workgroups(prism_gpu_ctx* ctx, const AggParams& p, uint32_t* tiles_per_wg) {
+  // whole scan tiles per workgroup, a multiple of 4 (the widest super-tile), one workgroup per CU
+  uint64_t per = ceil_div(p.sd.n_tiles, (uint64_t)ctx->n_cus);
+  per = ceil_div(per, 4) * 4;
+  *tiles_per_wg = (uint32_t)per;
+  return (uint32_t)ceil_div(p.sd.n_tiles, per);
+}
+
+void launch_partitioned_group_by(prism_gpu_ctx* ctx, const AggParams& p_scan, const PartParams& q, bool vals_nullable,
+                                 uint64_t hist_bytes, uint64_t scatter_bytes, uint64_t agg_bytes) {
+  const AggParams& p_table = p_scan;  // the same descriptor carries the scan and the HBM table the stragglers go to
+  PartKernels k;
+  if (!pick_part_kernels(p_scan.key_words, p_scan.keys_only ? 0 : p_scan.n_vals, vals_nullable, &k))
+    fail(PRISM_GPU_EINTERNAL, "no partitioned GROUP BY kernel for this plan shape");
+  const uint32_t P = q.n_buckets;
+  if (P < 64 || P > part_max_buckets(k.words) || (P & (P - 1)) != 0 || (1u << q.p_bits) != P)
+    fail(PRISM_GPU_EINTERNAL, "bad bucket count for the partitioned GROUP BY");
+  if (q.n_wg == 0 || (uint64_t)q.n_wg * q.tiles_per_wg < p_scan.sd.n_tiles || q.tiles_per_wg % 4 != 0)
+    fail(PRISM_GPU_EINTERNAL, "bad work split for the partitioned GROUP BY");
+  const int R = k.words == 1 ? 16 : (k.words == 2 ? 8 : 4);
+  const size_t scatter_lds = (size_t)k.words * R * kPartBlock * 8 + (size_t)(2 * P + 2) * 4;
+  const size_t agg_lds = (size_t)q.lds_entries * 8 * ((size_t)p_scan.key_words + (p_scan.keys_only ? 0 : (size_t)p_scan.n_slots));
+  if (scatter_lds > kPartLdsBytes || agg_lds > kPartLdsBytes) fail(PRISM_GPU_EINTERNAL, "partitioned GROUP BY exceeds LDS");
+  allow_lds(k.scatter, scatter_lds);
+  allow_lds(k.agg, agg_lds);
+  {
+    KernelTimer timer(ctx, "part_hist", hist_bytes);
+    k.hist<<<dim3(q.n_wg), dim3(kPartBlock), (size_t)P * 4, ctx->stream>>>(p_scan, q);
+    PRISM_HIP(hipGetLastError());
+  }
+  {
+    KernelTimer timer(ctx, "part_plan", 0);
+    k_part_offsets<<<dim3((uint32_t)ceil_div(P, kBlock)), dim3(kBlock), 0, ctx->stream>>>(q);
+    PRISM_HIP(hipGetLastError());
+    k_part_plan<<<dim3(1), dim3(kPartBlock), 0, ctx->stream>>>(q);
+    PRISM_HIP(hipGetLastError());
+  }
+  {
+    KernelTimer timer(ctx, "part_scatter", scatter_bytes);
+    k.scatter<<<dim3(q.n_wg), dim3(kPartBlock), scatter_lds, ctx->stream>>>(p_scan, q);
+    PRISM_HIP(hipGetLastError());
+  }
+  {
+    KernelTimer timer(ctx, "part_agg", agg_bytes);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(q.max_items, (uint64_t)ctx->n_cus);
+    k.agg<<<dim3(grid), dim3(kPartBlock), agg_lds, ctx->stream>>>(p_table, q);
+    PRISM_HIP(hipGetLastError());
+  }
+}
+
+}  // namespace prism

@@ -851,7 +851,8 @@ __global__ __launch_bounds__(kStreamBlock, stream_min_waves(NK, NV, K32)) PRISM_
     }
   }
   __shared__ WindowShared win;
-  if (threadIdx.x == 0) { n_entries = 0; win.misses = 0; win.candidate = 0; }
+  __shared__ uint32_t stop_flag;
+  if (threadIdx.x == 0) { n_entries = 0; win.misses = 0; win.candidate = 0; stop_flag = 0; }
   lds_clear<K32>(p, t);
   __syncthreads();
 
@@ -949,11 +950,20 @@ __global__ __launch_bounds__(kStreamBlock, stream_min_waves(NK, NV, K32)) PRISM_
       // groups still cost HBM no per-row atomics on one address, and every other row
       // goes straight to HBM.
       rows_since_flush += kTileRows;
+      if (p.stop_if_scattered && threadIdx.x == 0) stop_flag = table_gave_up(p) ? 1u : 0u;
       __syncthreads();
       const int n = n_entries;
+      const bool stop = p.stop_if_scattered && stop_flag != 0u;
       __syncthreads();
+      if (stop) break;  // another workgroup found its rows scattered: the caller will partition them instead
       if (n > t.S / 2) {
         if (t.replicas == 1 && (uint64_t)n * 4 > rows_since_flush) {
+          if (p.stop_if_scattered) {
+            // Most rows would go to HBM one atomic at a time: say so and leave (the caller
+            // runs the partitioned GROUP BY instead; this table is dropped).
+            if (threadIdx.x == 0) __hip_atomic_store(p.overflow, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
           insert = false;
         } else {
           lds_flush<K32>(p, t);

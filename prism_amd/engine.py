@@ -34,6 +34,7 @@ EXPORTED_SYMBOLS = [
     "prism_gpu_state_import", "prism_gpu_state_merge", "prism_gpu_state_finish", "prism_gpu_state_free",
     "prism_gpu_table_dictionary_digest",
     "prism_gpu_set_profiling", "prism_gpu_get_stats", "prism_gpu_reset_stats",
+    "prism_gpu_set_option",
 ]
 
 _LIB: Optional[C.CDLL] = None
@@ -101,6 +102,7 @@ def load_library() -> C.CDLL:
     L.prism_gpu_set_profiling.argtypes = [V, C.c_int]
     L.prism_gpu_get_stats.argtypes = [V, P(abi.Stats)]
     L.prism_gpu_reset_stats.argtypes = [V]
+    L.prism_gpu_set_option.argtypes = [V, C.c_char_p, C.c_int64]
     _LIB = L
     return L
 
@@ -122,6 +124,9 @@ class Context:
         if self._h:
             self._lib.prism_gpu_ctx_free(self._h)
             self._h = C.c_void_p()
+
+    def set_option(self, name: str, value: int) -> None:
+        _check(self._lib.prism_gpu_set_option(self._h, name.encode(), int(value)))
 
     def set_profiling(self, on: bool) -> None:
         _check(self._lib.prism_gpu_set_profiling(self._h, 1 if on else 0))

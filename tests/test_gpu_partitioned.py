@@ -1,0 +1,227 @@
+"""GPU parity of the partitioned GROUP BY (rows partitioned by key hash in HBM, buckets
+aggregated in LDS): the same plans and the same oracle as the other parity tests, with
+the context told to partition whatever can be partitioned, plus the cases only this path
+has: heavy hitters whose bucket is aggregated in slices, LDS tables that overflow into the
+HBM table, a result list that turns out too short, two-word keys, and the streaming
+kernel handing a plan over when it finds its rows scattered."""
+import pytest
+
+from tests import helpers
+from tests.helpers import assert_tables_match, assert_topk_match
+
+pytestmark = pytest.mark.gpu
+
+from prism_amd import _cabi as abi  # noqa: E402
+from prism_amd import workloads  # noqa: E402
+from prism_amd.plan import QueryPlan, avg, col, count, count_distinct, count_star, date_bin, max_, min_, sum_  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import pyoracle
+
+    return pyoracle
+
+
+@pytest.fixture(scope="module")
+def part_ctx():
+    """A context of its own, so that the options do not leak into the other tests."""
+    from prism_amd.engine import Context
+
+    ctx = Context(0)
+    ctx.set_option("part_min_rows", 0)
+    ctx.set_option("part_force", 1)
+    yield ctx
+    ctx.close()
+
+
+@pytest.fixture(scope="module")
+def rand_tables(part_ctx):
+    from prism_amd.engine import Table
+
+    out = {}
+    for name, n, nulls, parts in [("small", 1000, True, 1), ("mid", 50_000, True, 3), ("nonull", 20_000, False, 2)]:
+        t = helpers.random_table(n, seed=len(name) + n, nulls=nulls)
+        g = Table(part_ctx, t.schema)
+        g.append_table(t, parts)
+        out[name] = (t, g)
+    yield out
+    for _, g in out.values():
+        g.close()
+
+
+PLANS = [p for p in helpers.plan_catalogue() if p[0].startswith(("by_", "distinct_"))]
+
+
+def _kernels(ctx):
+    return {k for k, v in ctx.stats()["kernels"].items() if v["launches"]}
+
+
+@pytest.mark.parametrize("tname", ["small", "mid", "nonull"])
+@pytest.mark.parametrize("pname", [p[0] for p in PLANS])
+def test_catalogue_partitioned(part_ctx, oracle, rand_tables, tname, pname):
+    from prism_amd.engine import Plan
+
+    _, q, n_keys = next(p for p in PLANS if p[0] == pname)
+    t, g = rand_tables[tname]
+    plan = Plan(part_ctx, t.schema, q)
+    try:
+        got = plan.execute(g)
+        again = plan.execute(g)  # sized from what the first run learned
+    finally:
+        plan.close()
+    want = oracle.execute(t, q)
+    assert_tables_match(got, want, n_keys)
+    assert_tables_match(again, want, n_keys)
+
+
+def test_partitioned_path_really_runs(part_ctx, oracle, rand_tables):
+    from prism_amd.engine import Plan
+
+    t, g = rand_tables["mid"]
+    q = QueryPlan([count_star(), sum_("value"), min_("value")], keys=["user"])
+    part_ctx.reset_stats()
+    plan = Plan(part_ctx, t.schema, q)
+    try:
+        got = plan.execute(g)
+    finally:
+        plan.close()
+    assert {"part_hist", "part_scatter", "part_agg"} <= _kernels(part_ctx)
+    assert_tables_match(got, oracle.execute(t, q), 1)
+
+
+@pytest.mark.parametrize("pname", ["by_user", "by_user_value", "by_i16_i32", "by_minute_service_full",
+                                   "distinct_user_by_hour_service"])
+def test_partial_then_merge_partitioned(part_ctx, oracle, rand_tables, pname):
+    from prism_amd.engine import Plan
+
+    _, q, n_keys = next(p for p in PLANS if p[0] == pname)
+    t, g = rand_tables["mid"]
+    plan = Plan(part_ctx, t.schema, q.with_mode(abi.MODE_PARTIAL))
+    try:
+        states = [plan.execute(g, [p]) for p in range(g.num_partitions)]
+        got = plan.merge(states)
+    finally:
+        plan.close()
+    assert_tables_match(got, oracle.execute(t, q), n_keys)
+
+
+def _synth_both(ctx, oracle, wl, rows, parts, queries, hint=None):
+    from prism_amd.engine import Plan
+
+    table = workloads.build_gpu_table(ctx, wl, 0, rows, rows, parts)
+    st = oracle.SynthTable(wl.schema, wl.make_cols(), wl.seed, 0, rows, rows, n_parts=parts)
+    try:
+        for q, n_keys in queries:
+            if hint is not None:
+                q = q.with_groups_hint(hint) if hasattr(q, "with_groups_hint") else q
+            plan = Plan(ctx, wl.schema, q)
+            try:
+                runs = [plan.execute(table), plan.execute(table)]
+            finally:
+                plan.close()
+            want, _ = st.execute(q)
+            want = workloads.decode_dictionary_columns(wl, want)
+            for got in runs:
+                if q.limit is not None:
+                    assert_topk_match(got, want, q.order_by)
+                else:
+                    assert_tables_match(got, want, n_keys)
+    finally:
+        st.close()
+        table.close()
+
+
+def test_heavy_hitters_are_aggregated_in_slices(part_ctx, oracle):
+    """Log-uniform ids: the most frequent id alone is 1/16 of the rows, far more than one
+    work item holds, so its bucket is cut into slices that meet in the HBM table."""
+    wl = workloads.c3(id_bits=16)
+    _synth_both(part_ctx, oracle, wl, 3_000_000, 5, [
+        (wl.query, 1),
+        (QueryPlan([count_star()], keys=["UserID"]), 1),
+    ])
+
+
+def test_lds_tables_overflow_into_the_hbm_table(part_ctx, oracle):
+    """A hint of very few groups gives 64 buckets; with ~10^6 groups every bucket holds
+    more groups than an LDS table takes, and the rest goes through the HBM table (which
+    has to grow) and a result list that was sized far too short."""
+    wl = workloads.c3(id_bits=21)
+    q = QueryPlan([count_star()], keys=["UserID"], groups_hint=100)
+    _synth_both(part_ctx, oracle, wl, 4_000_000, 4, [(q, 1)])
+
+
+def test_values_and_nulls_travel_with_the_records(part_ctx, oracle):
+    import numpy as np
+    import pyarrow as pa
+    from prism_amd.engine import Plan, Table
+
+    rng = np.random.default_rng(11)
+    n = 400_000
+    t = pa.table({
+        "k": pa.array(rng.integers(0, 150_000, n).astype(np.int64) * 1_000_003 - 7, mask=rng.random(n) < 0.01),
+        "a": pa.array(rng.integers(-1 << 40, 1 << 40, n).astype(np.int64), mask=rng.random(n) < 0.2),
+        "b": pa.array(rng.integers(-30000, 30000, n).astype(np.int16), mask=rng.random(n) < 0.5),
+        "c": pa.array(rng.integers(0, 1 << 31, n).astype(np.int32)),
+    })
+    g = Table(part_ctx, t.schema)
+    g.append_table(t, 3)
+    try:
+        for q in [QueryPlan([count_star(), sum_("a"), min_("b"), max_("b"), avg("a"), count("b")], keys=["k"]),
+                  QueryPlan([sum_("c"), max_("a")], keys=["k"], predicate=col("b") > 0),
+                  QueryPlan([count_star(), avg("c")], keys=["k", "b"])]:
+            plan = Plan(part_ctx, t.schema, q)
+            try:
+                got = plan.execute(g)
+            finally:
+                plan.close()
+            assert_tables_match(got, oracle.execute(t, q), len(q.keys))
+    finally:
+        g.close()
+
+
+def test_two_word_keys_and_count_distinct(part_ctx, oracle):
+    wl = workloads.c5(n_services=16, user_bits=14)
+    _synth_both(part_ctx, oracle, wl, 1_500_000, 4, [(wl.query, 2)])
+
+
+def test_streaming_kernel_hands_over_when_rows_scatter(oracle):
+    """No forcing: the streaming kernel runs first, finds that its rows miss the LDS tables,
+    stops, and the plan is partitioned from then on; a low-cardinality plan on the same
+    table stays on the streaming kernel."""
+    from prism_amd.engine import Context, Plan
+
+    ctx = Context(0)
+    ctx.set_option("part_min_rows", 100_000)
+    wl = workloads.c3(id_bits=20)
+    rows, parts = 3_000_000, 6
+    table = workloads.build_gpu_table(ctx, wl, 0, rows, rows, parts)
+    st = oracle.SynthTable(wl.schema, wl.make_cols(), wl.seed, 0, rows, rows, n_parts=parts)
+    try:
+        q = QueryPlan([count_star()], keys=["UserID"])
+        want, _ = st.execute(q)
+        plan = Plan(ctx, wl.schema, q)
+        try:
+            ctx.reset_stats()
+            first = plan.execute(table)
+            assert "part_agg" in _kernels(ctx), "the streaming kernel did not hand the plan over"
+            ctx.reset_stats()
+            second = plan.execute(table)
+            assert "part_agg" in _kernels(ctx)
+        finally:
+            plan.close()
+        assert_tables_match(first, want, 1)
+        assert_tables_match(second, want, 1)
+        # filtered: the predicate is evaluated as a bitmap once the plan partitions
+        qf = QueryPlan([count_star()], keys=["UserID"], predicate=col("UserID") > (1 << 61))
+        wantf, _ = st.execute(qf)
+        plan = Plan(ctx, wl.schema, qf)
+        try:
+            assert_tables_match(plan.execute(table), wantf, 1)
+            assert_tables_match(plan.execute(table), wantf, 1)
+        finally:
+            plan.close()
+    finally:
+        st.close()
+        table.close()
+        ctx.close()
