@@ -119,6 +119,7 @@ struct prism_gpu_plan {
   // run produced (sizes the buckets and the result list of the next).
   std::atomic<int> part_mode{0};
   std::atomic<uint64_t> part_groups{0};
+  std::atomic<uint64_t> part_table_capacity{0};  // capacity that the HBM table behind the LDS tables needed last time
 };
 
 struct prism_gpu_part {

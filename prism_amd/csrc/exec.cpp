@@ -1119,13 +1119,14 @@ uint64_t partitioned_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, AggParam
   uint64_t list_cap = groups_est ? groups_est + groups_est / 16 + 1024 : std::min<uint64_t>(selected, 1ull << 25);
   list_cap = std::max<uint64_t>(1, std::min(list_cap, selected));
   // the HBM table behind the LDS tables: groups of buckets that were aggregated in slices, and stragglers
-  uint64_t fb_cap = std::max<uint64_t>(1ull << 16, plan->learned_capacity.load(std::memory_order_relaxed));
+  uint64_t fb_cap = std::max<uint64_t>(1ull << 16, plan->part_table_capacity.load(std::memory_order_relaxed));
   const uint64_t fb_max = pow2_ceil(std::max<uint64_t>(1024, 2 * selected));
   fb_cap = std::min(fb_cap, fb_max);
   const int n_slots = (int)slot_ops.size();
   const uint64_t rec_bytes = selected * 8 * (uint64_t)words;
   uint64_t groups = 0;
   for (;;) {
+    std::unique_ptr<HostTimer> ht_alloc(new HostTimer(ctx, "host:part_alloc"));
     GroupTable fb;
     table_alloc(ctx, fb, false, fb_cap, slot_ops, ap.key_words);
     GroupTable list;
@@ -1155,6 +1156,7 @@ uint64_t partitioned_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, AggParam
     ap.g_keys_hi = fb.keys_hi.as<uint64_t>();
     ap.g_state = fb.state.as<int64_t>();
     ap.overflow = fb.overflow.as<uint32_t>();
+    ht_alloc.reset();
     {
       // the whole path under the name the one-kernel GROUP BY reports, so that callers price it the same way
       KernelTimer timer(ctx, "group_by", scan_rows * value_bytes);
@@ -1162,6 +1164,7 @@ uint64_t partitioned_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, AggParam
     }
     struct { unsigned long long cursor; uint32_t n_items, pad; uint32_t flags[2]; } h{};
     uint32_t fb_flag = 0;
+    HostTimer ht_wait(ctx, "host:part_wait");
     PRISM_HIP(hipMemcpyAsync(&h, d_small.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     PRISM_HIP(hipMemcpyAsync(&fb_flag, fb.overflow.p, 4, hipMemcpyDeviceToHost, ctx->stream));
     PRISM_HIP(hipStreamSynchronize(ctx->stream));
@@ -1185,7 +1188,7 @@ uint64_t partitioned_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, AggParam
       list_cap = groups + 1024;
       continue;
     }
-    if (h.flags[1]) plan->learned_capacity.store(fb_cap, std::memory_order_relaxed);
+    if (h.flags[1]) plan->part_table_capacity.store(fb_cap, std::memory_order_relaxed);
     gt = std::move(list);
     break;
   }
@@ -1630,12 +1633,12 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
     bool vals_nullable = false;
     for (int j = 0; j < ap.n_vals; ++j)
       for (const Chunk* ch : ss.chunks) vals_nullable = vals_nullable || ch->cols[ss.uses[ap.vals[j].col].column].validity != nullptr;
-    bool part_ok = ap.row_mode != kRowsSelvec && ap.n_pred == 0 && selected >= part_min_rows(ctx) && part_record_words(ap, vals_nullable) > 0;
-    for (const Chunk* ch : ss.chunks) part_ok = part_ok && ch->rows < (1ull << 31);
+    bool part_ok = ap.row_mode != kRowsSelvec && selected >= part_min_rows(ctx) && part_record_words(ap, vals_nullable) > 0;
+    for (const Chunk* ch : ss.chunks) part_ok = part_ok && ch->rows < (1ull << 29);  // byte offsets inside a column fit 32 bits
     uint64_t key_bytes = 0;
     for (auto& sp : layout.specs) key_bytes += sp.width;
     // two-word keys have no LDS stage on the streaming side: every row would be an HBM atomic
-    const bool use_part = part_ok && (layout.words == 2 || prefers_part);
+    const bool use_part = part_ok && ap.n_pred == 0 && (layout.words == 2 || prefers_part);
     // otherwise the streaming kernel runs, and reports it when its rows scatter
     ap.stop_if_scattered = (!use_part && part_ok && plan->part_mode.load(std::memory_order_relaxed) == 0) ? 1 : 0;
     // The packed key indexes the table directly when the key space is small, or when it is

@@ -558,6 +558,29 @@ __global__ __launch_bounds__(kBlock) void k_topk_pick(TopKState* st, int shift, 
   if (t == 0 && shift == 0 && !done) st->exact = st->done ? 0u : 1u;
 }
 
+// Output positions for the entries a workgroup takes in one step of its loop: one update of
+// the counter per workgroup (updates of one address are carried out one after the other at
+// the memory side: a update per wave made the compaction of a large table wait for them).
+// `m`: the wave's lanes that take an entry.  Returns where the wave's first entry goes.
+// Every thread of the workgroup must call it (two barriers).
+__device__ __forceinline__ unsigned long long emit_reserve(uint64_t m, unsigned long long* out_count) {
+  __shared__ uint32_t wave_cnt[kBlock / 64];
+  __shared__ unsigned long long block_first;
+  const uint32_t wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) wave_cnt[wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t total = 0;
+    for (uint32_t w = 0; w < kBlock / 64; ++w) total += wave_cnt[w];
+    block_first = total ? atomicAdd(out_count, (unsigned long long)total) : 0ull;
+  }
+  __syncthreads();
+  unsigned long long first = block_first;
+  for (uint32_t w = 0; w < wave; ++w) first += wave_cnt[w];
+  __syncthreads();  // wave_cnt is rewritten by the next step
+  return first;
+}
+
 __global__ __launch_bounds__(kBlock) void k_emit(int dense, uint64_t capacity, const uint64_t* g_keys,
                                                 const uint64_t* g_keys_hi, const long long* g_state, int n_slots,
                                                 uint64_t* out_keys, uint64_t* out_keys_hi, long long* out_state,
@@ -589,12 +612,8 @@ __global__ __launch_bounds__(kBlock) void k_emit(int dense, uint64_t capacity, c
         if (tie) take = first_tie + __popcll(tm & ((1ull << lane) - 1)) < ties_wanted;
       }
     }
-    // one counter update per wave
     const uint64_t m = __ballot(take);
-    if (m == 0) continue;
-    unsigned long long first = 0;
-    if (lane == __ffsll((long long)m) - 1) first = atomicAdd(out_count, (unsigned long long)__popcll(m));
-    first = __shfl(first, __ffsll((long long)m) - 1);
+    const unsigned long long first = emit_reserve(m, out_count);
     if (!take || out_keys == nullptr) continue;  // counting pass
     const unsigned long long pos = first + __popcll(m & ((1ull << lane) - 1));
     if (pos >= out_limit) continue;
@@ -634,10 +653,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_columns(int dense, uint64_t cap
       }
     }
     const uint64_t m = __ballot(take);
-    if (m == 0) continue;
-    unsigned long long first = 0;
-    if (lane == __ffsll((long long)m) - 1) first = atomicAdd(out_count, (unsigned long long)__popcll(m));
-    first = __shfl(first, __ffsll((long long)m) - 1);
+    const unsigned long long first = emit_reserve(m, out_count);
     if (!take || out_values == nullptr) continue;
     const unsigned long long pos = first + __popcll(m & ((1ull << lane) - 1));
     if (pos >= stride) continue;  // cannot happen when stride >= occupied entries; never write outside

@@ -104,25 +104,40 @@ __device__ __forceinline__ void part_load_keys(const AggParams& p, const PartTil
     lo[r] = 0;
     hi[r] = 0;
   }
+  // at most 8 loads of a column in flight per lane (16 at a time cost more registers than a
+  // 1024-thread workgroup has)
+  constexpr int B = R < 8 ? R : 8;
   for (int k = 0; k < p.n_keys; ++k) {
     const KeySpec& ks = p.keys[k];
-    unsigned long long raw[R];
-    bool ok[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const ColPtr& c = p.cols[(uint64_t)ks.col * p.sd.n_segs + tl[r >> 2].seg];
-      const PartBytePtr base = (PartBytePtr)(uint64_t)c.values;
-      // (a chunk's column is shorter than 4 GiB: the byte offset fits 32 bits, and the load takes
-      // its base from scalar registers)
-      raw[r] = __builtin_nontemporal_load((const __attribute__((address_space(1))) part_unaligned_u64*)(base + rowc[r] * (uint32_t)ks.width));
-      ok[r] = ks.null_bit < 0 || valid_at(c.validity, rowc[r]);
-    }
+    for (int r0 = 0; r0 < R; r0 += B) {
+      unsigned long long raw[B];
+      uint32_t ok = 0xffffffffu;  // bit i: the key of row r0 + i is not NULL
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      long long v = part_widen(raw[r], ks.width, ks.is_unsigned);
-      if (ks.date_bin) v = bucket_number(v, ks);
-      const uint64_t field = ok[r] ? (((uint64_t)v - (uint64_t)ks.bias) << ks.bit_pos) : (1ull << (ks.null_bit >= 0 ? ks.null_bit : 0));
-      if (KW == 2 && ks.word) hi[r] |= field; else lo[r] |= field;
+      for (int i = 0; i < B; ++i) {
+        const int r = r0 + i;
+        const ColPtr& c = p.cols[(uint64_t)ks.col * p.sd.n_segs + tl[r >> 2].seg];
+        const PartBytePtr base = (PartBytePtr)(uint64_t)c.values;
+        // (a chunk's column is shorter than 4 GiB: the byte offset fits 32 bits, and the load takes
+        // its base from scalar registers)
+        raw[i] = __builtin_nontemporal_load((const __attribute__((address_space(1))) part_unaligned_u64*)(base + rowc[r] * (uint32_t)ks.width));
+      }
+      if (ks.null_bit >= 0) {
+#pragma unroll
+        for (int i = 0; i < B; ++i) {
+          const int r = r0 + i;
+          const ColPtr& c = p.cols[(uint64_t)ks.col * p.sd.n_segs + tl[r >> 2].seg];
+          if (!valid_at(c.validity, rowc[r])) ok &= ~(1u << i);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < B; ++i) {
+        const int r = r0 + i;
+        long long v = part_widen(raw[i], ks.width, ks.is_unsigned);
+        if (ks.date_bin) v = bucket_number(v, ks);
+        const uint64_t field = ((ok >> i) & 1u) ? (((uint64_t)v - (uint64_t)ks.bias) << ks.bit_pos) : (1ull << (ks.null_bit >= 0 ? ks.null_bit : 0));
+        if (KW == 2 && ks.word) hi[r] |= field; else lo[r] |= field;
+      }
     }
   }
 }
@@ -213,11 +228,16 @@ __global__ __launch_bounds__(kBlock) void k_part_offsets(PartParams q) {
   const uint32_t b = blockIdx.x * kBlock + threadIdx.x;
   if (b >= q.n_buckets) return;
   uint32_t run = 0;
-  for (uint32_t wg = 0; wg < q.n_wg; ++wg) {
-    const uint64_t i = (uint64_t)wg * q.n_buckets + b;
-    const uint32_t c = q.hist[i];
-    q.hist[i] = run;
-    run += c;
+  constexpr uint32_t kBatch = 8;  // independent loads in flight (the running sum is the only chain)
+  for (uint32_t wg0 = 0; wg0 < q.n_wg; wg0 += kBatch) {
+    uint32_t c[kBatch];
+#pragma unroll
+    for (uint32_t j = 0; j < kBatch; ++j) c[j] = wg0 + j < q.n_wg ? q.hist[(uint64_t)(wg0 + j) * q.n_buckets + b] : 0u;
+#pragma unroll
+    for (uint32_t j = 0; j < kBatch; ++j) {
+      if (wg0 + j < q.n_wg) q.hist[(uint64_t)(wg0 + j) * q.n_buckets + b] = run;
+      run += c[j];
+    }
   }
   q.totals[b] = run;
 }
@@ -361,11 +381,10 @@ __device__ __forceinline__ unsigned long long lds_load(const unsigned long long*
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// Entry of the key in the LDS table, inserted when absent; -1: the table is full for this
-// key (it stays full: an item never removes entries, so the key's rows all take the same way).
+// Entry of the key in the LDS table, inserted when absent; -1: the table is full for this key.
 template <int KW>
 __device__ __forceinline__ int part_lds_entry(unsigned long long* keys_lo, unsigned long long* keys_hi, uint32_t S,
-                                              int limit, int* n_entries, uint64_t lo, uint64_t hi, uint64_t h) {
+                                              int limit, int* n_entries, uint64_t lo, uint64_t hi, uint64_t h, bool& inserted) {
   uint32_t idx = __umulhi((uint32_t)h, S);
   int probes = 0;
   while (probes < kPartMaxProbes) {
@@ -375,7 +394,7 @@ __device__ __forceinline__ int part_lds_entry(unsigned long long* keys_lo, unsig
       const unsigned long long old = atomicCAS(&keys_lo[idx], kPartEmpty, (unsigned long long)lo);
       if (old == kPartEmpty) {
         if (KW == 2) __hip_atomic_store(&keys_hi[idx], (unsigned long long)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        atomicAdd(n_entries, 1);
+        inserted = true;  // the caller counts it (once per wave: the counter is one LDS word)
         return (int)idx;
       }
       k = old;
@@ -391,6 +410,44 @@ __device__ __forceinline__ int part_lds_entry(unsigned long long* keys_lo, unsig
     ++probes;
   }
   return -1;
+}
+
+// One-word keys: the table is cut into buckets of two entries, read with one 16-byte load,
+// and a key has two home buckets (tried in order, then the buckets after the second).  A
+// wave's look-up takes as many steps as its slowest lane: with one home slot and linear
+// probing that was eight or nine steps at half load, with two choices of two entries it is
+// two or three.  A key is only ever placed in the first free entry on its path and entries
+// are never removed, so a free entry on the path proves the key absent.
+__device__ __forceinline__ int part_lds_entry2way(unsigned long long* keys, uint32_t n_buckets, int limit, int* n_entries,
+                                                  uint64_t key, bool& inserted) {
+  const uint32_t m1 = ((uint32_t)key ^ (uint32_t)(key >> 32)) * 0x9E3779B1u;
+  const uint32_t m2 = (m1 ^ (m1 >> 15)) * 0x85EBCA6Bu;
+  uint32_t b = __umulhi(m1, n_buckets);
+  int step = 0;
+  while (step < kPartMaxProbes) {
+    asm volatile("" ::: "memory");  // the bucket is read afresh in every step
+    const ulonglong2 c = *(const ulonglong2*)&keys[2 * (size_t)b];
+    if (c.x == key) return (int)(2 * b);
+    if (c.y == key) return (int)(2 * b + 1);
+    if (c.x == kPartEmpty || c.y == kPartEmpty) {
+      if (__hip_atomic_load(n_entries, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= limit) return -1;
+      const uint32_t e = 2 * b + (c.x == kPartEmpty ? 0u : 1u);
+      const unsigned long long old = atomicCAS(&keys[e], kPartEmpty, (unsigned long long)key);
+      if (old == kPartEmpty) { inserted = true; return (int)e; }
+      if (old == key) return (int)e;
+      continue;  // somebody else took the entry: look at the bucket again
+    }
+    b = step == 0 ? __umulhi(m2, n_buckets) : (b + 1 == n_buckets ? 0u : b + 1);
+    ++step;
+  }
+  return -1;
+}
+
+template <int KW>
+__device__ __forceinline__ int part_find(unsigned long long* keys_lo, unsigned long long* keys_hi, uint32_t S, int limit,
+                                         int* n_entries, uint64_t lo, uint64_t hi, bool& inserted) {
+  if (KW == 1) return part_lds_entry2way(keys_lo, S / 2, limit, n_entries, lo, inserted);
+  return part_lds_entry<KW>(keys_lo, keys_hi, S, limit, n_entries, lo, hi, part_hash<KW>(lo, hi), inserted);
 }
 
 template <int KW, int NV>
@@ -413,9 +470,9 @@ __global__ __launch_bounds__(kPartBlock) void k_part_agg(AggParams p, PartParams
   constexpr int W = KW + NV + (VALID ? 1 : 0);
   extern __shared__ __align__(16) unsigned long long part_lds[];
   __shared__ int n_entries;
-  __shared__ uint32_t wg_pos, gave_up;
+  __shared__ uint32_t wg_pos, gave_up, n_rejects;
   __shared__ unsigned long long out_base;
-  const uint32_t S = q.lds_entries, tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t S = q.lds_entries & ~1u, tid = threadIdx.x, lane = tid & 63u;
   const int n_lds_slots = p.keys_only ? 0 : p.n_slots;
   unsigned long long* keys_lo = part_lds;
   unsigned long long* keys_hi = part_lds + (KW == 2 ? S : 0);
@@ -433,7 +490,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_agg(AggParams p, PartParams
       if (KW == 2) keys_hi[i] = kPartEmpty;
       for (int s = 0; s < n_lds_slots; ++s) state[(size_t)s * S + i] = slot_identity(p.slots[s].op);
     }
-    if (tid == 0) { n_entries = 0; wg_pos = 0; }
+    if (tid == 0) { n_entries = 0; wg_pos = 0; n_rejects = 0; }
     __syncthreads();
     for (uint64_t base = it.lo; base < it.hi; base += (uint64_t)kPartAggInFlight * kPartBlock) {
       uint64_t rec[kPartAggInFlight][W];
@@ -448,29 +505,70 @@ __global__ __launch_bounds__(kPartBlock) void k_part_agg(AggParams p, PartParams
       }
 #pragma unroll
       for (int u = 0; u < kPartAggInFlight; ++u) {
-        if (!in[u]) continue;
+        const bool act = in[u];
         const uint64_t lo = rec[u][0], hi = KW == 2 ? rec[u][KW - 1] : 0ull;
         RowValsT<NV> rv;
         rv.valid = VALID ? (uint32_t)rec[u][W - 1] : 0xffffffffu;
 #pragma unroll
         for (int v = 0; v < NV; ++v) rv.v[v] = (long long)rec[u][KW + v];
-        // (a one-word key of all ones is the table's empty marker: it lives in the HBM table)
-        const int e = lo == kPartEmpty ? -1
-                                       : part_lds_entry<KW>(keys_lo, keys_hi, S, (int)q.lds_limit, &n_entries, lo, hi, part_hash<KW>(lo, hi));
-        if (e < 0) {
-          atomicAdd(&q.flags[1], 1u);
-          part_hbm_update<KW, NV>(p, lo, hi, rv);
-          continue;
+        if (!it.exclusive) {
+          // A slice of a bucket that was too large for one workgroup: a heavy hitter, as a
+          // rule, so whole wave instructions carry one key, and 64 LDS atomics on one address
+          // are applied one after the other.  Such rows are reduced in the wave first.
+          const uint64_t m_act = __ballot(act);
+          if (m_act == 0) continue;
+          const int leader = __ffsll((long long)m_act) - 1;
+          const uint64_t flo = __shfl(lo, leader), fhi = KW == 2 ? __shfl(hi, leader) : 0ull;
+          if (__ballot(act && lo == flo && hi == fhi) == m_act && flo != kPartEmpty) {
+            int e = -1;
+            bool ins = false;
+            if ((int)lane == leader) e = part_find<KW>(keys_lo, keys_hi, S, (int)q.lds_limit, &n_entries, lo, hi, ins);
+            if (ins) atomicAdd(&n_entries, 1);
+            e = __shfl(e, leader);
+            if (e >= 0) {
+              for (int s = 0; s < n_lds_slots; ++s) {
+                const int op = p.slots[s].op;
+                long long x;
+                if (!(act && slot_input(p, s, rv, x))) x = op == kSlotAddF64 ? __double_as_longlong(-0.0) : slot_identity(op);
+                if (op == kSlotMin) x = wave_min_i64(x);
+                else if (op == kSlotMax) x = wave_max_i64(x);
+                else if (op == kSlotAddF64) x = __double_as_longlong(wave_sum_f64(__longlong_as_double(x)));
+                else x = (long long)wave_sum_u64((unsigned long long)x);
+                if (lane == 0) atomic_apply(&state[(size_t)s * S + (uint32_t)e], op, x);
+              }
+              continue;
+            }
+          }
         }
-        for (int s = 0; s < n_lds_slots; ++s) {
-          long long x;
-          if (slot_input(p, s, rv, x)) atomic_apply(&state[(size_t)s * S + (uint32_t)e], p.slots[s].op, x);
+        // (a one-word key of all ones is the table's empty marker: it lives in the HBM table)
+        int e = -1;
+        bool ins = false;
+        if (act && lo != kPartEmpty)
+          e = part_find<KW>(keys_lo, keys_hi, S, (int)q.lds_limit, &n_entries, lo, hi, ins);
+        const uint64_t m_ins = __ballot(ins);
+        if (m_ins && (int)lane == __ffsll((long long)m_ins) - 1) atomicAdd(&n_entries, __popcll(m_ins));
+        const bool rejected = act && e < 0;
+        const uint64_t m_rej = __ballot(rejected);
+        if (m_rej) {
+          if ((int)lane == __ffsll((long long)m_rej) - 1) atomicAdd(&n_rejects, (uint32_t)__popcll(m_rej));
+          if (rejected) part_hbm_update<KW, NV>(p, lo, hi, rv);
+        }
+        if (act && e >= 0) {
+          for (int s = 0; s < n_lds_slots; ++s) {
+            long long x;
+            if (slot_input(p, s, rv, x)) atomic_apply(&state[(size_t)s * S + (uint32_t)e], p.slots[s].op, x);
+          }
         }
       }
     }
     __syncthreads();
     const uint32_t n = (uint32_t)n_entries;
-    if (it.exclusive) {
+    // Rows that found the table full went to the HBM table.  Whether a key is turned away
+    // depends on when its row looks (the fill count moves while other waves insert), so a key
+    // may sit in both tables: a bucket that turned rows away merges all its groups into the
+    // HBM table instead of appending them to the list.
+    const bool to_list = it.exclusive && n_rejects == 0;
+    if (to_list) {
       // the bucket's groups are nobody else's: append them to the list
       if (tid == 0) out_base = atomicAdd(q.list_cursor, (unsigned long long)n);
       __syncthreads();
@@ -505,7 +603,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_agg(AggParams p, PartParams
           if (v != slot_identity(op)) atomic_apply(&p.g_state[(uint64_t)s * (p.capacity + 1) + e], op, v);
         }
       }
-      if (tid == 0 && n) atomicAdd(&q.flags[1], n);
+      if (tid == 0) atomicAdd(&q.flags[1], n + n_rejects);
     }
     __syncthreads();
   }

@@ -9,7 +9,7 @@ from collections import defaultdict
 
 
 def short(name: str) -> str:
-    for key in ("k_group_by", "k_cmp_leaf", "k_agg_global", "k_emit", "k_fill", "k_contains", "k_str_leaf", "k_lut",
+    for key in ("k_part_hist", "k_part_scatter", "k_part_agg", "k_part_offsets", "k_part_plan", "k_group_by", "k_cmp_leaf", "k_agg_global", "k_emit", "k_fill", "k_contains", "k_str_leaf", "k_lut",
                 "k_col_stats", "k_synth", "k_bitmap", "k_tile_counts", "k_scan_counts", "k_write_selvec", "k_validity",
                 "k_distinct_fold"):
         if key in name:

@@ -187,40 +187,43 @@ def test_two_word_keys_and_count_distinct(part_ctx, oracle):
 
 def test_streaming_kernel_hands_over_when_rows_scatter(oracle):
     """No forcing: the streaming kernel runs first, finds that its rows miss the LDS tables,
-    stops, and the plan is partitioned from then on; a low-cardinality plan on the same
-    table stays on the streaming kernel."""
+    stops, and the plan is partitioned from then on (its predicate, evaluated inside the
+    streaming kernel on the first attempt, as a bitmap)."""
+    import pyarrow.compute as pc
     from prism_amd.engine import Context, Plan
 
     ctx = Context(0)
     ctx.set_option("part_min_rows", 100_000)
-    wl = workloads.c3(id_bits=20)
-    rows, parts = 3_000_000, 6
+    wl = workloads.c3(id_bits=22)
+    rows, parts = 32_000_000, 8  # enough tiles per workgroup for the LDS tables to fill up a few times
     table = workloads.build_gpu_table(ctx, wl, 0, rows, rows, parts)
-    st = oracle.SynthTable(wl.schema, wl.make_cols(), wl.seed, 0, rows, rows, n_parts=parts)
+    st = oracle.SynthTable(wl.schema, wl.make_cols(), wl.seed, 0, rows, rows, n_parts=parts, threads=8)
+
+    def same(got, want):
+        # millions of groups: compared as sorted columns rather than row by row in Python
+        assert got.num_rows == want.num_rows
+        for t in (got, want):
+            assert t.schema.names == ["UserID", "COUNT(*)"]
+        gi, wi = pc.sort_indices(got, [("UserID", "ascending")]), pc.sort_indices(want, [("UserID", "ascending")])
+        assert got.take(gi).equals(want.take(wi))
+
     try:
-        q = QueryPlan([count_star()], keys=["UserID"])
-        want, _ = st.execute(q)
-        plan = Plan(ctx, wl.schema, q)
-        try:
-            ctx.reset_stats()
-            first = plan.execute(table)
-            assert "part_agg" in _kernels(ctx), "the streaming kernel did not hand the plan over"
-            ctx.reset_stats()
-            second = plan.execute(table)
-            assert "part_agg" in _kernels(ctx)
-        finally:
-            plan.close()
-        assert_tables_match(first, want, 1)
-        assert_tables_match(second, want, 1)
-        # filtered: the predicate is evaluated as a bitmap once the plan partitions
-        qf = QueryPlan([count_star()], keys=["UserID"], predicate=col("UserID") > (1 << 61))
-        wantf, _ = st.execute(qf)
-        plan = Plan(ctx, wl.schema, qf)
-        try:
-            assert_tables_match(plan.execute(table), wantf, 1)
-            assert_tables_match(plan.execute(table), wantf, 1)
-        finally:
-            plan.close()
+        for q in [QueryPlan([count_star()], keys=["UserID"]),
+                  QueryPlan([count_star()], keys=["UserID"], predicate=col("UserID") > (1 << 61))]:
+            want, _ = st.execute(q, threads=8)
+            plan = Plan(ctx, wl.schema, q)
+            try:
+                ctx.reset_stats()
+                first = plan.execute(table)
+                ran = _kernels(ctx)
+                assert "part_agg" in ran, "the streaming kernel did not hand the plan over"
+                ctx.reset_stats()
+                second = plan.execute(table)
+                assert "part_agg" in _kernels(ctx)
+            finally:
+                plan.close()
+            same(first, want)
+            same(second, want)
     finally:
         st.close()
         table.close()
