@@ -1095,7 +1095,11 @@ uint64_t partitioned_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, AggParam
   q.p_bits = p_bits;
   q.n_buckets = P;
   q.n_wg = part_scan_workgroups(ctx, ap, &q.tiles_per_wg);
-  q.chunk_rows = (uint32_t)std::min<uint64_t>(1u << 30, std::max<uint64_t>(65536, 2 * ceil_div(selected, P)));
+  // A bucket of more than 4 times the average holds a heavy hitter and is aggregated in
+  // slices, by several workgroups, that meet in the HBM table.  (Slices are kept large: every
+  // slice sends each of the bucket's ordinary keys it has seen to the HBM table, and rows of
+  // the heavy hitter itself are cheap, being reduced wave by wave.)
+  q.chunk_rows = (uint32_t)std::min<uint64_t>(1u << 30, std::max<uint64_t>(65536, 4 * ceil_div(selected, P)));
   q.max_items = (uint32_t)(P + selected / q.chunk_rows + 2);
   q.lds_entries = lds_entries;
   q.lds_limit = lds_limit;
@@ -1115,6 +1119,7 @@ uint64_t partitioned_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, AggParam
   q.list_cursor = d_small.as<unsigned long long>();
   q.n_items = (uint32_t*)(d_small.as<uint8_t>() + 8);
   q.flags = (uint32_t*)(d_small.as<uint8_t>() + 16);
+  q.queue = (uint32_t*)(d_small.as<uint8_t>() + 24);
 
   uint64_t list_cap = groups_est ? groups_est + groups_est / 16 + 1024 : std::min<uint64_t>(selected, 1ull << 25);
   list_cap = std::max<uint64_t>(1, std::min(list_cap, selected));

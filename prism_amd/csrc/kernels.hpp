@@ -248,6 +248,7 @@ struct PartParams {
   uint64_t list_capacity;
   unsigned long long* list_cursor;
   uint32_t* flags;         // [0]: the list overflowed, [1]: rows / groups sent to the HBM table
+  uint32_t* queue;         // next item of the aggregation pass (starts at 0)
 };
 // 8-byte words of a row's record for this plan shape (key words + value columns + one word
 // of validity bits when a value column has NULLs); 0: the shape has no partitioned kernels.

@@ -253,13 +253,15 @@ __global__ __launch_bounds__(kPartBlock) void k_part_plan(PartParams q) {
   __syncthreads();
   for (uint32_t b = tid; b <= P; b += kPartBlock) q.bucket_base[b] = a[b];
   __syncthreads();
-  // chunks per bucket
-  for (uint32_t b = tid; b < P; b += kPartBlock) a[b] = (uint32_t)ceil_div((uint64_t)q.totals[b], (uint64_t)q.chunk_rows);
+  // Items: the slices of the buckets that are cut up come first (they are the long ones, and
+  // the aggregation pass hands items out in order), then one item per remaining bucket.
+  auto chunks_of = [&](uint32_t b) { return (uint32_t)ceil_div((uint64_t)q.totals[b], (uint64_t)q.chunk_rows); };
+  for (uint32_t b = tid; b < P; b += kPartBlock) { const uint32_t n = chunks_of(b); a[b] = n > 1 ? n : 0u; }
   __syncthreads();
   part_block_scan(a, P, wave_tot);
   __syncthreads();
-  for (uint32_t b = tid; b < P; b += kPartBlock) {
-    const uint32_t first = a[b], n = a[b + 1] - first;
+  const uint32_t n_sliced = a[P];
+  auto emit_items = [&](uint32_t b, uint32_t first, uint32_t n) {
     const uint64_t lo = q.bucket_base[b], hi = q.bucket_base[b + 1];
     for (uint32_t c = 0; c < n; ++c) {
       if (first + c >= q.max_items) break;
@@ -270,8 +272,22 @@ __global__ __launch_bounds__(kPartBlock) void k_part_plan(PartParams q) {
       it.hi = it.lo + q.chunk_rows < hi ? it.lo + q.chunk_rows : hi;
       q.items[first + c] = it;
     }
+  };
+  for (uint32_t b = tid; b < P; b += kPartBlock) {
+    const uint32_t n = chunks_of(b);
+    if (n > 1) emit_items(b, a[b], n);
   }
-  if (tid == 0) *q.n_items = a[P] < q.max_items ? a[P] : q.max_items;
+  __syncthreads();
+  for (uint32_t b = tid; b < P; b += kPartBlock) a[b] = chunks_of(b) == 1 ? 1u : 0u;
+  __syncthreads();
+  part_block_scan(a, P, wave_tot);
+  __syncthreads();
+  for (uint32_t b = tid; b < P; b += kPartBlock)
+    if (chunks_of(b) == 1) emit_items(b, n_sliced + a[b], 1);
+  if (tid == 0) {
+    const uint32_t total = n_sliced + a[P];
+    *q.n_items = total < q.max_items ? total : q.max_items;
+  }
 }
 
 // ---- pass 1b: scatter ------------------------------------------------------------------
@@ -470,7 +486,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_agg(AggParams p, PartParams
   constexpr int W = KW + NV + (VALID ? 1 : 0);
   extern __shared__ __align__(16) unsigned long long part_lds[];
   __shared__ int n_entries;
-  __shared__ uint32_t wg_pos, gave_up, n_rejects;
+  __shared__ uint32_t wg_pos, gave_up, n_rejects, next_item;
   __shared__ unsigned long long out_base;
   const uint32_t S = q.lds_entries & ~1u, tid = threadIdx.x, lane = tid & 63u;
   const int n_lds_slots = p.keys_only ? 0 : p.n_slots;
@@ -478,12 +494,17 @@ __global__ __launch_bounds__(kPartBlock) void k_part_agg(AggParams p, PartParams
   unsigned long long* keys_hi = part_lds + (KW == 2 ? S : 0);
   long long* state = (long long*)(part_lds + (size_t)KW * S);  // [n_lds_slots][S]
   const uint32_t n_items = *q.n_items;
-  for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
-    // (the HBM table overflowed: the whole pass will be run again; one thread looks, so that
-    // the workgroup leaves as a whole)
-    if (tid == 0) gave_up = table_gave_up(p) ? 1u : 0u;
+  for (;;) {
+    // Items are handed out in order through a counter (long ones first).  Thread 0 takes the
+    // next one and looks whether the HBM table has overflowed (then the whole pass will be run
+    // again), so that the workgroup leaves as a whole.
+    if (tid == 0) {
+      next_item = atomicAdd(q.queue, 1u);
+      gave_up = table_gave_up(p) ? 1u : 0u;
+    }
     __syncthreads();
-    if (gave_up) return;
+    const uint32_t item = next_item;
+    if (gave_up || item >= n_items) return;
     const PartItem it = q.items[item];
     for (uint32_t i = tid; i < S; i += kPartBlock) {
       keys_lo[i] = kPartEmpty;
@@ -492,34 +513,50 @@ __global__ __launch_bounds__(kPartBlock) void k_part_agg(AggParams p, PartParams
     }
     if (tid == 0) { n_entries = 0; wg_pos = 0; n_rejects = 0; }
     __syncthreads();
-    for (uint64_t base = it.lo; base < it.hi; base += (uint64_t)kPartAggInFlight * kPartBlock) {
+    // Software pipelined: the records of the next step are requested before those of this
+    // step are looked up (all waves of the workgroup start an item together, so without this
+    // they would also wait for memory together).
+    constexpr uint64_t kStep = (uint64_t)kPartAggInFlight * kPartBlock;
+    uint64_t next[kPartAggInFlight][W];
+    auto request = [&](uint64_t base) {
+#pragma unroll
+      for (int u = 0; u < kPartAggInFlight; ++u) {
+        const uint64_t i = base + (uint64_t)u * kPartBlock + tid;
+        const uint64_t ic = i < it.hi ? i : it.lo;
+#pragma unroll
+        for (int w = 0; w < W; ++w) next[u][w] = __builtin_nontemporal_load((PartWordPtr)(uint64_t)(q.rec[w] + ic));
+      }
+    };
+    request(it.lo);
+    for (uint64_t base = it.lo; base < it.hi; base += kStep) {
       uint64_t rec[kPartAggInFlight][W];
       bool in[kPartAggInFlight];
 #pragma unroll
       for (int u = 0; u < kPartAggInFlight; ++u) {
-        const uint64_t i = base + (uint64_t)u * kPartBlock + tid;
-        in[u] = i < it.hi;
-        const uint64_t ic = in[u] ? i : it.lo;
+        in[u] = base + (uint64_t)u * kPartBlock + tid < it.hi;
 #pragma unroll
-        for (int w = 0; w < W; ++w) rec[u][w] = __builtin_nontemporal_load((PartWordPtr)(uint64_t)(q.rec[w] + ic));
+        for (int w = 0; w < W; ++w) rec[u][w] = next[u][w];
       }
+      if (base + kStep < it.hi) request(base + kStep);
 #pragma unroll
       for (int u = 0; u < kPartAggInFlight; ++u) {
-        const bool act = in[u];
         const uint64_t lo = rec[u][0], hi = KW == 2 ? rec[u][KW - 1] : 0ull;
         RowValsT<NV> rv;
         rv.valid = VALID ? (uint32_t)rec[u][W - 1] : 0xffffffffu;
 #pragma unroll
         for (int v = 0; v < NV; ++v) rv.v[v] = (long long)rec[u][KW + v];
-        if (!it.exclusive) {
-          // A slice of a bucket that was too large for one workgroup: a heavy hitter, as a
-          // rule, so whole wave instructions carry one key, and 64 LDS atomics on one address
-          // are applied one after the other.  Such rows are reduced in the wave first.
+        bool act = in[u];
+        {
+          // Heavy hitters: when many lanes of the wave carry the key of its first row, those
+          // rows are reduced in the wave and applied once (64 LDS atomics on one address are
+          // carried out one after the other); the other lanes go on as usual.
           const uint64_t m_act = __ballot(act);
           if (m_act == 0) continue;
           const int leader = __ffsll((long long)m_act) - 1;
           const uint64_t flo = __shfl(lo, leader), fhi = KW == 2 ? __shfl(hi, leader) : 0ull;
-          if (__ballot(act && lo == flo && hi == fhi) == m_act && flo != kPartEmpty) {
+          const bool grp = act && lo == flo && hi == fhi;
+          const uint64_t m_grp = __ballot(grp);
+          if (__popcll(m_grp) >= 16 && flo != kPartEmpty) {
             int e = -1;
             bool ins = false;
             if ((int)lane == leader) e = part_find<KW>(keys_lo, keys_hi, S, (int)q.lds_limit, &n_entries, lo, hi, ins);
@@ -529,22 +566,41 @@ __global__ __launch_bounds__(kPartBlock) void k_part_agg(AggParams p, PartParams
               for (int s = 0; s < n_lds_slots; ++s) {
                 const int op = p.slots[s].op;
                 long long x;
-                if (!(act && slot_input(p, s, rv, x))) x = op == kSlotAddF64 ? __double_as_longlong(-0.0) : slot_identity(op);
-                if (op == kSlotMin) x = wave_min_i64(x);
+                const bool has = grp && slot_input(p, s, rv, x);
+                if (!has) x = op == kSlotAddF64 ? __double_as_longlong(-0.0) : slot_identity(op);
+                // counters are a population count; the other rules a shuffle reduction
+                if (op == kSlotAddOne || op == kSlotAddValid) x = (long long)__popcll(__ballot(has));
+                else if (op == kSlotMin) x = wave_min_i64(x);
                 else if (op == kSlotMax) x = wave_max_i64(x);
                 else if (op == kSlotAddF64) x = __double_as_longlong(wave_sum_f64(__longlong_as_double(x)));
                 else x = (long long)wave_sum_u64((unsigned long long)x);
                 if (lane == 0) atomic_apply(&state[(size_t)s * S + (uint32_t)e], op, x);
               }
-              continue;
+              act = act && !grp;
             }
           }
         }
         // (a one-word key of all ones is the table's empty marker: it lives in the HBM table)
         int e = -1;
         bool ins = false;
-        if (act && lo != kPartEmpty)
-          e = part_find<KW>(keys_lo, keys_hi, S, (int)q.lds_limit, &n_entries, lo, hi, ins);
+        bool search = act && lo != kPartEmpty;
+        if (KW == 1) {
+          // Most rows find their key in one of its two home buckets: both are read at once and
+          // compared without a branch; only the lanes that found nothing (new keys, as a rule)
+          // enter the search-and-insert loop.
+          const uint32_t nb = S / 2;
+          const uint32_t m1 = ((uint32_t)lo ^ (uint32_t)(lo >> 32)) * 0x9E3779B1u;
+          const uint32_t m2 = (m1 ^ (m1 >> 15)) * 0x85EBCA6Bu;
+          const uint32_t b1 = __umulhi(m1, nb), b2 = __umulhi(m2, nb);
+          const ulonglong2 c1 = *(const ulonglong2*)&keys_lo[2 * (size_t)b1], c2 = *(const ulonglong2*)&keys_lo[2 * (size_t)b2];
+          int f = -1;
+          f = c2.y == lo ? (int)(2 * b2 + 1) : f;
+          f = c2.x == lo ? (int)(2 * b2) : f;
+          f = c1.y == lo ? (int)(2 * b1 + 1) : f;
+          f = c1.x == lo ? (int)(2 * b1) : f;
+          if (search && f >= 0) { e = f; search = false; }
+        }
+        if (search) e = part_find<KW>(keys_lo, keys_hi, S, (int)q.lds_limit, &n_entries, lo, hi, ins);
         const uint64_t m_ins = __ballot(ins);
         if (m_ins && (int)lane == __ffsll((long long)m_ins) - 1) atomicAdd(&n_entries, __popcll(m_ins));
         const bool rejected = act && e < 0;
