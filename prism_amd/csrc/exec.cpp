@@ -39,13 +39,24 @@ struct ScanSet {
     uses.push_back({column, codes});
     return (int)uses.size() - 1;
   }
-  const ColPtr* col(int slot) const { return d_cols.as<ColPtr>() + (size_t)slot * segs.size(); }
+  ColPtr* cols_dev = nullptr;
+  const ColPtr* col(int slot) const { return cols_dev + (size_t)slot * segs.size(); }
 
-  void upload() {
+  // `arena` (with `arena_bytes` of room): the descriptors go there instead of into scratch
+  // blocks of the pool (the entry point that may not allocate); returns the bytes used.
+  size_t upload(void* arena = nullptr, size_t arena_bytes = 0) {
     uploaded = true;
-    if (segs.empty()) return;
-    d_segs = Scratch(ctx, segs.size() * sizeof(ScanSeg));
-    PRISM_HIP(hipMemcpyAsync(d_segs.p, segs.data(), segs.size() * sizeof(ScanSeg), hipMemcpyHostToDevice, ctx->stream));
+    if (segs.empty()) return 0;
+    const size_t seg_bytes = round_up(segs.size() * sizeof(ScanSeg), 256), col_bytes = uses.size() * segs.size() * sizeof(ColPtr);
+    void* segs_dst;
+    if (arena) {
+      if (seg_bytes + col_bytes > arena_bytes) fail(PRISM_GPU_EUNSUPPORTED, "too many partitions for the allocation-free entry point");
+      segs_dst = arena;
+    } else {
+      d_segs = Scratch(ctx, segs.size() * sizeof(ScanSeg));
+      segs_dst = d_segs.p;
+    }
+    PRISM_HIP(hipMemcpyAsync(segs_dst, segs.data(), segs.size() * sizeof(ScanSeg), hipMemcpyHostToDevice, ctx->stream));
     std::vector<ColPtr> cp(uses.size() * segs.size());
     for (size_t u = 0; u < uses.size(); ++u)
       for (size_t s = 0; s < segs.size(); ++s) {
@@ -56,14 +67,21 @@ struct ScanSet {
         else { c.values = dc.values; c.bytes = dc.bytes; }
         if (!c.values) fail(PRISM_GPU_EINTERNAL, "column representation missing on the device");
       }
+    cols_dev = nullptr;
     if (!cp.empty()) {
-      d_cols = Scratch(ctx, cp.size() * sizeof(ColPtr));
-      PRISM_HIP(hipMemcpyAsync(d_cols.p, cp.data(), cp.size() * sizeof(ColPtr), hipMemcpyHostToDevice, ctx->stream));
-      PRISM_HIP(hipStreamSynchronize(ctx->stream));  // cp goes out of scope
+      if (arena) {
+        cols_dev = (ColPtr*)((uint8_t*)arena + seg_bytes);
+      } else {
+        d_cols = Scratch(ctx, cp.size() * sizeof(ColPtr));
+        cols_dev = d_cols.as<ColPtr>();
+      }
+      PRISM_HIP(hipMemcpyAsync(cols_dev, cp.data(), cp.size() * sizeof(ColPtr), hipMemcpyHostToDevice, ctx->stream));
     }
-    desc.segs = d_segs.as<ScanSeg>();
+    PRISM_HIP(hipStreamSynchronize(ctx->stream));  // segs' and cp's host memory may go away
+    desc.segs = (const ScanSeg*)segs_dst;
     desc.n_segs = (uint32_t)segs.size();
     desc.n_tiles = n_tiles;
+    return seg_bytes + round_up(col_bytes, 256);
   }
 };
 
@@ -869,13 +887,9 @@ std::shared_ptr<void> lease_pinned(prism_gpu_ctx* ctx, size_t bytes) {
   });
 }
 
-// Reads the groups of a finished table and appends them to `cols`; with ORDER BY ...
-// LIMIT only the leading groups leave the device.  The columns are assembled on the device
-// (launch_emit_columns) and arrive through pinned memory as whole columns.  Returns the
-// number of groups read.
-uint64_t emit_groups(prism_gpu_ctx* ctx, const prism_gpu_plan* plan, const prism_gpu_table* table,
-                     const std::vector<KeySrc>& keys, const KeyLayout& layout, const Lowered& low, const GroupTable& gt,
-                     bool partial, std::vector<OutColumn>& cols) {
+// How the result columns are built from a table's entries (launch_emit_columns).
+EmitColumns emit_columns_of(const prism_gpu_table* table, const std::vector<KeySrc>& keys, const KeyLayout& layout,
+                            const Lowered& low, bool partial) {
   EmitColumns ec{};
   ec.n_keys = (int)keys.size();
   for (size_t i = 0; i < keys.size(); ++i) {
@@ -906,6 +920,17 @@ uint64_t emit_groups(prism_gpu_ctx* ctx, const prism_gpu_plan* plan, const prism
       default: fail(PRISM_GPU_EINTERNAL, "aggregate cannot be emitted");
     }
   }
+  return ec;
+}
+
+// Reads the groups of a finished table and appends them to `cols`; with ORDER BY ...
+// LIMIT only the leading groups leave the device.  The columns are assembled on the device
+// (launch_emit_columns) and arrive through pinned memory as whole columns.  Returns the
+// number of groups read.
+uint64_t emit_groups(prism_gpu_ctx* ctx, const prism_gpu_plan* plan, const prism_gpu_table* table,
+                     const std::vector<KeySrc>& keys, const KeyLayout& layout, const Lowered& low, const GroupTable& gt,
+                     bool partial, std::vector<OutColumn>& cols) {
+  const EmitColumns ec = emit_columns_of(table, keys, layout, low, partial);
   const size_t n_cols = (size_t)ec.n_keys + (size_t)ec.n_aggs;
   if (n_cols != cols.size()) fail(PRISM_GPU_EINTERNAL, "result columns do not match the output schema");
 
@@ -1194,6 +1219,11 @@ uint64_t partitioned_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, AggParam
       continue;
     }
     if (h.flags[1]) plan->part_table_capacity.store(fb_cap, std::memory_order_relaxed);
+    // More groups than the largest number of buckets can hold in LDS: most of them went
+    // through the HBM table after all, on top of the partitioning.  The plan goes back to the
+    // streaming kernels.
+    if (P == p_max && (uint64_t)h.flags[1] > groups / 2 && groups > (uint64_t)p_max * lds_limit)
+      plan->part_mode.store(-1, std::memory_order_relaxed);
     gt = std::move(list);
     break;
   }
@@ -1276,6 +1306,82 @@ bool fusable_leaves(const prism_gpu_plan* p, const prism_gpu_table* t, int node,
   }
   leaves.push_back(node);
   return leaves.size() <= (size_t)kMaxFusedLeaves;
+}
+
+// Tries to move the plan's WHERE into the streaming GROUP BY kernel: on success `ap` carries
+// the leaves (and any column only they read) and the caller runs with row_mode kRowsAll.
+// `always`: also when few rows are expected to survive (the caller has no bitmap path).
+bool try_fuse_predicate(const prism_gpu_plan* plan, const prism_gpu_table* table, ScanSet& ss, const std::vector<KeySrc>& keys,
+                        const KeyLayout& layout, AggParams& ap, bool always) {
+    std::vector<int> leaves;
+    if (fusable_leaves(plan, table, plan->pred_root, -1, leaves)) {
+      AggParams trial = ap;
+      trial.n_keys = (int)layout.specs.size();
+      for (size_t i = 0; i < layout.specs.size(); ++i) trial.keys[i] = layout.specs[i];
+      trial.key_bits = plan->keys.empty() ? 0 : layout.total_bits;
+      trial.key_words = 1;
+      trial.lds_slots = lds_slots_for(trial.n_slots);
+      trial.row_mode = kRowsAll;
+      trial.n_pred = (int)leaves.size();
+      trial.pred_or = plan->pred[plan->pred_root].kind == PredNode::OR ? 1 : 0;
+      bool fits = true;
+      // the kernel variant with 32-bit keys (the same test pick_stream_kernel makes)
+      bool k32 = trial.key_bits <= 31;
+      for (int k = 0; k < trial.n_keys; ++k) k32 = k32 && trial.keys[k].fast32 != 0;
+      for (size_t l = 0; l < leaves.size() && fits; ++l) {
+        const PredNode& n = plan->pred[leaves[l]];
+        const FieldType& f = table->fields[n.column];
+        int kind = n.kind == PredNode::CMP ? kLeafCmp : (n.kind == PredNode::IS_NULL ? kLeafIsNull : kLeafIsNotNull);
+        long long lit = (long long)n.lit_i64;
+        if (f.is_string && n.kind != PredNode::IS_NULL && n.kind != PredNode::IS_NOT_NULL) {
+          kind = kLeafLut;
+          const std::vector<uint8_t> lut = dict_lut(n, table->dicts[n.column]);
+          uint64_t set = 0;
+          for (size_t c = 0; c + 1 < lut.size() && c < 64; ++c) set |= (uint64_t)(lut[c] != 0) << c;
+          lit = (long long)set;
+        }
+        // A column that is a GROUP BY key is loaded already: read it from there (WHERE on the
+        // timestamp that is also bucketed is the everyday query).  The 32-bit-key kernel holds
+        // the low word only, which is enough: value - base is below 2^32 for every row.
+        int from_key = -1;
+        for (size_t i = 0; i < keys.size() && from_key < 0; ++i)
+          if (keys[i].column == n.column && (k32 ? trial.keys[i].width >= 4 : trial.keys[i].width == 8)) from_key = (int)i;
+        if (from_key >= 0) {
+          const KeySpec& ks = trial.keys[from_key];
+          const __int128 rel = (__int128)lit - (__int128)ks.base;
+          long long lit_k32 = rel < -1 ? -1ll : (rel > ((__int128)1 << 32) ? (1ll << 32) : (long long)rel);
+          // (codes of the scan start at base: the set moves down with them)
+          if (kind == kLeafLut) lit_k32 = ks.base >= 0 && ks.base < 64 ? (long long)((uint64_t)lit >> ks.base) : 0ll;
+          trial.pred[l] = {-(from_key + 1), kind, n.cmp_mask, (uint32_t)(uint64_t)ks.base, lit, lit_k32};
+          continue;
+        }
+        const int col = ss.use(n.column, f.is_string);  // strings: their dictionary codes
+        int v = 0;
+        while (v < trial.n_vals && trial.vals[v].col != col) ++v;
+        if (v == trial.n_vals) {
+          if (trial.n_vals >= kMaxVals) { fits = false; break; }
+          trial.vals[v] = {col, f.is_string ? 4 : f.width, (f.is_string || f.is_unsigned) ? 1 : 0, 0};
+          trial.n_vals += 1;
+        }
+        trial.pred[l] = {v, kind, n.cmp_mask, 0u, lit, 0ll};
+      }
+      // Few expected survivors: the bitmap pass followed by a gather of only those rows is
+      // cheaper than streaming every column of every row through the aggregation kernel.
+      double keep = trial.pred_or ? 0.0 : 1.0;
+      for (int leaf : leaves) {
+        const PredNode& ln = plan->pred[leaf];
+        const double f = leaf_selectivity(ss, ln, table->fields[ln.column].is_string ? &table->dicts[ln.column] : nullptr);
+        keep = trial.pred_or ? 1.0 - (1.0 - keep) * (1.0 - f) : keep * f;
+      }
+      if (fits && (always || keep >= 1.0 / 16) && group_by_streams(trial)) {
+        const int n_keys = ap.n_keys, key_bits = ap.key_bits, key_words = ap.key_words, lds_slots = ap.lds_slots;
+        ap = trial;
+        // (the branches below set these for their own shape)
+        ap.n_keys = n_keys; ap.key_bits = key_bits; ap.key_words = key_words; ap.lds_slots = lds_slots;
+        return true;
+      }
+    }
+  return false;
 }
 
 void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions,
@@ -1381,76 +1487,8 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
   // A plan that partitions its rows evaluates the predicate as a bitmap (the partitioning
   // kernels take a selection, not a predicate).
   const bool prefers_part = !plan->keys.empty() && (plan->part_mode.load(std::memory_order_relaxed) == 1 || part_forced(ctx));
-  if (has_pred && !count_only && !plan->distinct_plan && layout.words == 1 && !prefers_part) {
-    std::vector<int> leaves;
-    if (fusable_leaves(plan, table, plan->pred_root, -1, leaves)) {
-      AggParams trial = ap;
-      trial.n_keys = (int)layout.specs.size();
-      for (size_t i = 0; i < layout.specs.size(); ++i) trial.keys[i] = layout.specs[i];
-      trial.key_bits = plan->keys.empty() ? 0 : layout.total_bits;
-      trial.key_words = 1;
-      trial.lds_slots = lds_slots_for(trial.n_slots);
-      trial.row_mode = kRowsAll;
-      trial.n_pred = (int)leaves.size();
-      trial.pred_or = plan->pred[plan->pred_root].kind == PredNode::OR ? 1 : 0;
-      bool fits = true;
-      // the kernel variant with 32-bit keys (the same test pick_stream_kernel makes)
-      bool k32 = trial.key_bits <= 31;
-      for (int k = 0; k < trial.n_keys; ++k) k32 = k32 && trial.keys[k].fast32 != 0;
-      for (size_t l = 0; l < leaves.size() && fits; ++l) {
-        const PredNode& n = plan->pred[leaves[l]];
-        const FieldType& f = table->fields[n.column];
-        int kind = n.kind == PredNode::CMP ? kLeafCmp : (n.kind == PredNode::IS_NULL ? kLeafIsNull : kLeafIsNotNull);
-        long long lit = (long long)n.lit_i64;
-        if (f.is_string && n.kind != PredNode::IS_NULL && n.kind != PredNode::IS_NOT_NULL) {
-          kind = kLeafLut;
-          const std::vector<uint8_t> lut = dict_lut(n, table->dicts[n.column]);
-          uint64_t set = 0;
-          for (size_t c = 0; c + 1 < lut.size() && c < 64; ++c) set |= (uint64_t)(lut[c] != 0) << c;
-          lit = (long long)set;
-        }
-        // A column that is a GROUP BY key is loaded already: read it from there (WHERE on the
-        // timestamp that is also bucketed is the everyday query).  The 32-bit-key kernel holds
-        // the low word only, which is enough: value - base is below 2^32 for every row.
-        int from_key = -1;
-        for (size_t i = 0; i < keys.size() && from_key < 0; ++i)
-          if (keys[i].column == n.column && (k32 ? trial.keys[i].width >= 4 : trial.keys[i].width == 8)) from_key = (int)i;
-        if (from_key >= 0) {
-          const KeySpec& ks = trial.keys[from_key];
-          const __int128 rel = (__int128)lit - (__int128)ks.base;
-          long long lit_k32 = rel < -1 ? -1ll : (rel > ((__int128)1 << 32) ? (1ll << 32) : (long long)rel);
-          // (codes of the scan start at base: the set moves down with them)
-          if (kind == kLeafLut) lit_k32 = ks.base >= 0 && ks.base < 64 ? (long long)((uint64_t)lit >> ks.base) : 0ll;
-          trial.pred[l] = {-(from_key + 1), kind, n.cmp_mask, (uint32_t)(uint64_t)ks.base, lit, lit_k32};
-          continue;
-        }
-        const int col = ss.use(n.column, f.is_string);  // strings: their dictionary codes
-        int v = 0;
-        while (v < trial.n_vals && trial.vals[v].col != col) ++v;
-        if (v == trial.n_vals) {
-          if (trial.n_vals >= kMaxVals) { fits = false; break; }
-          trial.vals[v] = {col, f.is_string ? 4 : f.width, (f.is_string || f.is_unsigned) ? 1 : 0, 0};
-          trial.n_vals += 1;
-        }
-        trial.pred[l] = {v, kind, n.cmp_mask, 0u, lit, 0ll};
-      }
-      // Few expected survivors: the bitmap pass followed by a gather of only those rows is
-      // cheaper than streaming every column of every row through the aggregation kernel.
-      double keep = trial.pred_or ? 0.0 : 1.0;
-      for (int leaf : leaves) {
-        const PredNode& ln = plan->pred[leaf];
-        const double f = leaf_selectivity(ss, ln, table->fields[ln.column].is_string ? &table->dicts[ln.column] : nullptr);
-        keep = trial.pred_or ? 1.0 - (1.0 - keep) * (1.0 - f) : keep * f;
-      }
-      if (fits && keep >= 1.0 / 16 && group_by_streams(trial)) {
-        const int n_keys = ap.n_keys, key_bits = ap.key_bits, key_words = ap.key_words, lds_slots = ap.lds_slots;
-        ap = trial;
-        // (the branches below set these for their own shape)
-        ap.n_keys = n_keys; ap.key_bits = key_bits; ap.key_words = key_words; ap.lds_slots = lds_slots;
-        fused = true;
-      }
-    }
-  }
+  if (has_pred && !count_only && !plan->distinct_plan && layout.words == 1 && !prefers_part)
+    fused = try_fuse_predicate(plan, table, ss, keys, layout, ap, false);
   if (has_pred && !count_only && !fused) {
     // register every column the predicate touches before the upload
     for (const PredNode& n : plan->pred)
@@ -1458,7 +1496,7 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
   }
   ss.upload();
   ap.sd = ss.desc;
-  ap.cols = ss.d_cols.as<ColPtr>();
+  ap.cols = ss.cols_dev;
 
   Scratch d_scalar(ctx, 256);
   if (has_pred && count_only) {
@@ -1642,8 +1680,20 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
     for (const Chunk* ch : ss.chunks) part_ok = part_ok && ch->rows < (1ull << 29);  // byte offsets inside a column fit 32 bits
     uint64_t key_bytes = 0;
     for (auto& sp : layout.specs) key_bytes += sp.width;
-    // two-word keys have no LDS stage on the streaming side: every row would be an HBM atomic
-    const bool use_part = part_ok && ap.n_pred == 0 && (layout.words == 2 || prefers_part);
+    // Two-word keys have no LDS stage on the streaming side (every row is an HBM atomic), so
+    // they are partitioned whenever the expected groups fit the buckets' LDS tables.
+    bool wide_fits = false;
+    if (layout.words == 2 && part_ok && plan->part_mode.load(std::memory_order_relaxed) >= 0) {
+      AggParams probe = ap;
+      probe.key_words = 2;
+      probe.keys_only = (plan->distinct_plan && layout.words == 2) ? 1 : 0;
+      const int words = part_record_words(probe, vals_nullable);
+      uint64_t est = plan->part_groups.load(std::memory_order_relaxed);
+      if (!est) est = plan->groups_hint;
+      wide_fits = words > 0 && est > 0 && est <= (uint64_t)part_max_buckets(words) * (part_lds_entries(probe) / 2);
+    }
+    const bool use_part = part_ok && ap.n_pred == 0 && plan->part_mode.load(std::memory_order_relaxed) >= 0 &&
+                          (wide_fits || (layout.words == 1 && prefers_part) || (layout.words == 2 && part_forced(ctx)));
     // otherwise the streaming kernel runs, and reports it when its rows scatter
     ap.stop_if_scattered = (!use_part && part_ok && plan->part_mode.load(std::memory_order_relaxed) == 0) ? 1 : 0;
     // The packed key indexes the table directly when the key space is small, or when it is
