@@ -262,6 +262,34 @@ int prism_gpu_execute(prism_gpu_plan* plan, prism_gpu_table* table,
                       const uint32_t* partition_ids, size_t n_partitions,
                       struct ArrowArray* out);
 
+/* prism_gpu_execute for callers that cannot allocate device memory: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in
+ * the reference.  The call allocates nothing on the device (no hipMalloc / hipFree, no pool):
+ * the group table, the scan descriptors and the counters live in a fixed 9 MiB device array
+ * inside the library, which every GPU the library runs on holds until the process ends, and
+ * the result goes to buffers of the caller instead of an ArrowArray.
+ *
+ * Limits (PRISM_GPU_EUNSUPPORTED beyond them, with a message that says which): a GROUP BY
+ * plan in SINGLE mode, no COUNT(DISTINCT), no ORDER BY / LIMIT; a WHERE only of the kind the
+ * aggregation kernel evaluates itself (up to four comparisons / IS NULL tests joined by one
+ * of AND / OR); a packed key of at most 22 bits over the scanned partitions, and
+ * (2^key_bits + 1) x accumulators <= 1048576 (8 MiB); at most ~2700 partition chunks x columns.
+ *
+ * Output: out_values is [n_columns][out_stride] 8-byte values and out_valid the same shape in
+ * bytes (1 = not NULL), columns in the order of prism_gpu_plan_final_schema; Int64 / Timestamp
+ * / counts as int64, AVG as the bit pattern of a double, string keys as the code of the value
+ * in the table's dictionary.  Both may be device memory or page-locked host memory.
+ * *n_groups (host memory) receives the number of rows; if it exceeds out_stride the call fails
+ * with PRISM_GPU_EINVAL and nothing was written past the buffers.
+ *
+ * Every call on a GPU uses that GPU's one array: calls from one process are serialised by the
+ * library, calls from different processes that overlap on one GPU race.  The array keeps the
+ * last call's contents; each call clears what it needs. */
+int prism_gpu_execute_noalloc(prism_gpu_plan* plan, prism_gpu_table* table,
+                              const uint32_t* partition_ids, size_t n_partitions,
+                              int64_t* out_values, uint8_t* out_valid, uint64_t out_stride,
+                              uint64_t* n_groups);
+
 /* Streaming form, one prism_gpu_part per DataFusion partition
  * (ExecutionPlan::execute(partition, ..) polled on its own thread):
  * push_batch moves one input RecordBatch in, finish returns the partition's

@@ -59,6 +59,7 @@ int prism_gpu_init(int device_ordinal, prism_gpu_ctx** out) {
     hipDeviceProp_t prop;
     PRISM_HIP(hipGetDeviceProperties(&prop, device_ordinal));
     ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    prism::noalloc_init(device_ordinal);
     PRISM_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     PRISM_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     for (int i = 0; i < 2; ++i) {
@@ -177,6 +178,14 @@ int prism_gpu_execute(prism_gpu_plan* plan, prism_gpu_table* table, const uint32
   return guarded([&] {
     require(plan && table && out, "null argument");
     prism::execute_plan(plan, table, partition_ids, n_partitions, false, out);
+  });
+}
+
+int prism_gpu_execute_noalloc(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions,
+                              int64_t* out_values, uint8_t* out_valid, uint64_t out_stride, uint64_t* n_groups) {
+  return guarded([&] {
+    require(plan && table && n_groups && (out_stride == 0 || (out_values && out_valid)), "null argument");
+    prism::execute_noalloc(plan, table, partition_ids, n_partitions, out_values, out_valid, out_stride, n_groups);
   });
 }
 

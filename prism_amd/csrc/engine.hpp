@@ -150,6 +150,19 @@ void state_merge(prism_gpu_state* st, const void* device_src, uint64_t n_groups)
 void state_finish(prism_gpu_state* st, ArrowArray* out);
 void state_free(prism_gpu_state* st);
 
+// The entry point that allocates nothing (prism_gpu_execute_noalloc): its device memory is
+// a fixed array of the library (noalloc.hip), laid out as descriptors | counters | accumulators.
+constexpr size_t kNoAllocDescriptorBytes = 1ull << 20;
+constexpr uint64_t kNoAllocMaxAccumulators = 1ull << 20;  // 8-byte accumulators: entries x slots
+constexpr size_t kNoAllocBytes = kNoAllocDescriptorBytes + kNoAllocMaxAccumulators * 8;
+// Address of the array on `device` (found once per device, at prism_gpu_init) and the lock
+// that keeps two calls of one process from using it at once.
+void noalloc_init(int device);
+void* noalloc_scratch(int device);
+std::mutex& noalloc_mutex(int device);
+void execute_noalloc(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions,
+                     int64_t* out_values, uint8_t* out_valid, uint64_t out_stride, uint64_t* n_groups);
+
 // Host implementation of SQL LIKE, used on dictionary values.
 std::vector<LikeToken> like_compile(const std::string& pattern);
 bool like_match_host(const std::vector<LikeToken>& tokens, const std::string& s, bool case_insensitive);

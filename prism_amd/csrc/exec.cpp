@@ -1852,6 +1852,122 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
   export_record_batch(cols, out);
 }
 
+}  // namespace
+
+// ---- the entry point that allocates nothing ------------------------------------------------
+// GROUP BY over resident partitions into a dense group table that lives, with the scan
+// descriptors and the counters, in a fixed device array of the library (noalloc.hip) instead
+// of scratch blocks of the pool; the result columns are written to buffers of the caller.
+void execute_noalloc(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions,
+                     int64_t* out_values, uint8_t* out_valid, uint64_t out_stride, uint64_t* n_groups) {
+  prism_gpu_ctx* ctx = plan->ctx;
+  bind(ctx);
+  if (table->ctx != ctx) fail(PRISM_GPU_EINVAL, "plan and table belong to different contexts");
+  if (plan->keys.empty() || plan->distinct_plan || plan->mode != PRISM_MODE_SINGLE || plan->order_by >= 0 || plan->limit >= 0)
+    fail(PRISM_GPU_EUNSUPPORTED, "the allocation-free entry point runs GROUP BY plans in SINGLE mode without COUNT(DISTINCT), ORDER BY or LIMIT");
+  if (table->fields.size() != plan->fields.size()) fail(PRISM_GPU_EINVAL, "table schema does not match the plan's input schema");
+  for (size_t i = 0; i < plan->fields.size(); ++i)
+    if (table->fields[i].logical != plan->fields[i].logical)
+      fail(PRISM_GPU_EINVAL, "column " + std::to_string(i) + " (`" + table->fields[i].name + "`) has a different type than the plan expects");
+  // one call at a time per device: every call uses the same array
+  std::lock_guard<std::mutex> one_call(noalloc_mutex(ctx->device));
+  uint8_t* const arena = (uint8_t*)noalloc_scratch(ctx->device);
+  table_sync_stats(table);
+
+  ScanSet ss;
+  ss.ctx = ctx;
+  for (const Chunk& ch : table->chunks) {
+    bool take = partition_ids == nullptr || n_partitions == 0;
+    for (size_t i = 0; !take && i < n_partitions; ++i) take = partition_ids[i] == ch.partition_id;
+    if (!take || ch.rows == 0) continue;
+    if (plan->pred_root >= 0 && !chunk_may_match(plan, table, plan->pred_root, ch)) continue;
+    ss.chunks.push_back(&ch);
+    ss.segs.push_back({ch.rows, ss.n_tiles});
+    ss.n_tiles += ceil_div(ch.rows, kTileRows);
+    ss.rows += ch.rows;
+  }
+  *n_groups = 0;
+  if (ss.chunks.empty()) return;
+  if (ss.n_tiles * (uint64_t)kTileRows > 0xffffffffull) fail(PRISM_GPU_EUNSUPPORTED, "more than 2^32 rows in one scan; split the scan by partition");
+
+  std::vector<KeySrc> keys;
+  for (const KeyPlan& k : plan->keys) keys.push_back({k.column, k.kind == PRISM_KEY_DATE_BIN, k.stride_ms, k.origin_ms});
+  Lowered low = lower_raw(plan, ss);
+  AggParams ap;
+  std::memset(&ap, 0, sizeof(ap));
+  KeyLayout layout;
+  KeyCursor cursor;
+  layout_keys(ss, table, keys, cursor, layout);
+  fill_slots(table, ss, low, ap);
+  const uint64_t entries = layout.words == 1 && layout.total_bits <= kDenseMaxBits ? (1ull << layout.total_bits) : 0;
+  if (entries == 0 || (entries + 1) * (uint64_t)ap.n_slots > kNoAllocMaxAccumulators)
+    fail(PRISM_GPU_EUNSUPPORTED, "the group table of this plan over these partitions (" +
+                                     (entries ? std::to_string(entries) + " entries of " + std::to_string(ap.n_slots) + " accumulators"
+                                              : std::string("a hash table")) +
+                                     ") exceeds the " + std::to_string(kNoAllocMaxAccumulators) +
+                                     " accumulators of the allocation-free entry point; use prism_gpu_execute");
+  if (plan->pred_root >= 0 && !try_fuse_predicate(plan, table, ss, keys, layout, ap, true))
+    fail(PRISM_GPU_EUNSUPPORTED, "the allocation-free entry point only takes predicates that the aggregation kernel evaluates itself");
+  // ---- the array: descriptors | counters | accumulators ----
+  const size_t used = ss.upload(arena, kNoAllocDescriptorBytes - 256);
+  (void)used;
+  unsigned long long* const d_count = (unsigned long long*)(arena + kNoAllocDescriptorBytes - 256);  // [0..1] emit, [2] rows selected, [3] flag
+  int64_t* const d_state = (int64_t*)(arena + kNoAllocDescriptorBytes);
+  PRISM_HIP(hipMemsetAsync(d_count, 0, 64, ctx->stream));
+  for (int s = 0; s < ap.n_slots; ++s) {
+    int64_t* base = d_state + (uint64_t)s * (entries + 1);
+    const long long id = slot_identity_host(ap.slots[s].op);
+    if (id == 0) PRISM_HIP(hipMemsetAsync(base, 0, (entries + 1) * 8, ctx->stream));
+    else launch_fill_i64(ctx, base, entries + 1, id);
+  }
+  ap.sd = ss.desc;
+  ap.cols = ss.cols_dev;
+  ap.n_keys = (int)layout.specs.size();
+  for (size_t i = 0; i < layout.specs.size(); ++i) ap.keys[i] = layout.specs[i];
+  ap.lds_slots = lds_slots_for(ap.n_slots);
+  ap.key_bits = layout.total_bits;
+  ap.key_words = 1;
+  ap.row_mode = kRowsAll;
+  ap.selected_out = d_count + 2;
+  ap.dense = 1;
+  ap.capacity = entries;
+  ap.g_state = d_state;
+  ap.overflow = (uint32_t*)(d_count + 3);
+  {
+    int align = 64;  // (the lowest bit a time-typed key occupies: see execute_impl)
+    for (size_t i = 0; i < keys.size(); ++i) {
+      if (!(keys[i].date_bin || table->fields[keys[i].column].logical == PRISM_COL_TIMESTAMP)) continue;
+      const KeyField& kf = layout.fields[i];
+      if (kf.bits) align = std::min(align, kf.bit_pos);
+      if (kf.null_bit >= 0) align = std::min(align, kf.null_bit);
+    }
+    if (align < 32) ap.window_hint = 1 + align;
+  }
+  uint64_t value_bytes = 0;
+  for (int j = 0; j < ap.n_vals; ++j) value_bytes += ap.vals[j].width;
+  for (auto& sp : layout.specs) value_bytes += sp.width;
+  launch_group_by(ctx, ap, ss.rows * value_bytes);
+  const EmitColumns ec = emit_columns_of(table, keys, layout, low, false);
+  launch_emit_columns(ctx, true, entries, nullptr, nullptr, d_state, ec, out_values, out_valid, out_stride, d_count, nullptr, nullptr);
+  unsigned long long h[3] = {0, 0, 0};
+  PRISM_HIP(hipMemcpyAsync(h, d_count, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  PRISM_HIP(hipStreamSynchronize(ctx->stream));
+  collect_timings(ctx);
+  if (h[1]) fail(PRISM_GPU_EINTERNAL, "dictionary code out of range in result");
+  *n_groups = h[0];
+  {
+    std::lock_guard<std::mutex> g(ctx->mu);
+    ctx->stats.rows_scanned += ss.rows;
+    ctx->stats.rows_selected += ap.n_pred ? h[2] : ss.rows;
+    ctx->stats.groups_out += h[0];
+  }
+  if (h[0] > out_stride)
+    fail(PRISM_GPU_EINVAL, "the result has " + std::to_string(h[0]) + " groups, the output buffers hold " + std::to_string(out_stride) +
+                               " per column (nothing was written past them)");
+}
+
+namespace {
+
 void state_compact(prism_gpu_state* st) {
   if (st->compacted) return;
   prism_gpu_ctx* ctx = st->plan->ctx;

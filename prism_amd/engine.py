@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = [
     "prism_gpu_state_import", "prism_gpu_state_merge", "prism_gpu_state_finish", "prism_gpu_state_free",
     "prism_gpu_table_dictionary_digest",
     "prism_gpu_set_profiling", "prism_gpu_get_stats", "prism_gpu_reset_stats",
-    "prism_gpu_set_option",
+    "prism_gpu_set_option", "prism_gpu_execute_noalloc",
 ]
 
 _LIB: Optional[C.CDLL] = None
@@ -103,6 +103,7 @@ def load_library() -> C.CDLL:
     L.prism_gpu_get_stats.argtypes = [V, P(abi.Stats)]
     L.prism_gpu_reset_stats.argtypes = [V]
     L.prism_gpu_set_option.argtypes = [V, C.c_char_p, C.c_int64]
+    L.prism_gpu_execute_noalloc.argtypes = [V, V, P(C.c_uint32), C.c_size_t, V, V, C.c_uint64, P(C.c_uint64)]
     _LIB = L
     return L
 
@@ -252,6 +253,15 @@ class Plan:
                 arr[0] = 0xFFFFFFFF  # an id no partition has: scan nothing
             _check(self._lib.prism_gpu_execute(self._h, table._h, arr, max(1, len(ids)), C.byref(out)))
         return pa.Table.from_batches([abi.import_batch(out, self.output_schema)])
+
+    def execute_noalloc(self, table: Table, partitions, out_values_ptr: int, out_valid_ptr: int, out_stride: int) -> int:
+        """prism_gpu_execute_noalloc: result columns into caller-provided (device) buffers;
+        returns the number of groups."""
+        arr, k = self._partition_args(partitions)
+        n = C.c_uint64()
+        _check(self._lib.prism_gpu_execute_noalloc(self._h, table._h, arr, k, C.c_void_p(out_values_ptr),
+                                                   C.c_void_p(out_valid_ptr), out_stride, C.byref(n)))
+        return n.value
 
     def run_batches(self, partition: int, batches: Iterable[pa.RecordBatch]) -> pa.Table:
         """Streaming form: partition_open / push_batch* / finish."""
