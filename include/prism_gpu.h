@@ -252,6 +252,16 @@ int prism_gpu_plan_create(prism_gpu_ctx* ctx,
 /* ExecutionPlan::schema(): the schema of what execute/finish will return. */
 int prism_gpu_plan_output_schema(const prism_gpu_plan* plan,
                                  struct ArrowSchema* out);
+/* The range of `column` (an integer or Timestamp(ms) input column) outside which no row can
+ * pass the plan's WHERE, inclusive on both sides; INT64_MIN / INT64_MAX for an open side,
+ * start > end when no value can pass.  It is what the reference's TableProvider::scan would
+ * put into GetTablePartitionsRequest.time_range (always None today,
+ * src/prism-query/src/providers/table_provider.rs:86-93) so that the catalogue only lists
+ * partitions whose Partition.time_range (proto/common/prism/common/v1/partition.proto:5-14)
+ * overlaps it.  `ctx` may be NULL in prism_gpu_plan_create for a plan that is only inspected
+ * (schemas, this range) and never run. */
+int prism_gpu_plan_time_range(const prism_gpu_plan* plan, int32_t column,
+                              int64_t* start_ms, int64_t* end_ms);
 void prism_gpu_plan_free(prism_gpu_plan* plan);
 
 /* ExecutionPlan::execute + collect over HBM-resident partitions.

@@ -152,7 +152,7 @@ int prism_gpu_table_synth(prism_gpu_table* table, uint32_t partition_id, uint64_
 int prism_gpu_plan_create(prism_gpu_ctx* ctx, const struct ArrowSchema* input_schema, const prism_gpu_plan_desc* desc,
                           prism_gpu_plan** out) {
   return guarded([&] {
-    require(ctx && input_schema && desc && out, "null argument");
+    require(input_schema && desc && out, "null argument");
     *out = prism::plan_create(ctx, input_schema, desc).release();
   });
 }
@@ -171,12 +171,20 @@ int prism_gpu_plan_final_schema(const prism_gpu_plan* plan, struct ArrowSchema* 
   });
 }
 
+int prism_gpu_plan_time_range(const prism_gpu_plan* plan, int32_t column, int64_t* start_ms, int64_t* end_ms) {
+  return guarded([&] {
+    require(plan && start_ms && end_ms, "null argument");
+    prism::plan_value_range(plan, column, start_ms, end_ms);
+  });
+}
+
 void prism_gpu_plan_free(prism_gpu_plan* plan) { delete plan; }
 
 int prism_gpu_execute(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions,
                       struct ArrowArray* out) {
   return guarded([&] {
     require(plan && table && out, "null argument");
+    require(plan->ctx != nullptr, "the plan was created without a context: it can be inspected, not run");
     prism::execute_plan(plan, table, partition_ids, n_partitions, false, out);
   });
 }
@@ -185,6 +193,7 @@ int prism_gpu_execute_noalloc(prism_gpu_plan* plan, prism_gpu_table* table, cons
                               int64_t* out_values, uint8_t* out_valid, uint64_t out_stride, uint64_t* n_groups) {
   return guarded([&] {
     require(plan && table && n_groups && (out_stride == 0 || (out_values && out_valid)), "null argument");
+    require(plan->ctx != nullptr, "the plan was created without a context: it can be inspected, not run");
     prism::execute_noalloc(plan, table, partition_ids, n_partitions, out_values, out_valid, out_stride, n_groups);
   });
 }
@@ -192,6 +201,7 @@ int prism_gpu_execute_noalloc(prism_gpu_plan* plan, prism_gpu_table* table, cons
 int prism_gpu_partition_open(prism_gpu_plan* plan, uint32_t partition, prism_gpu_part** out) {
   return guarded([&] {
     require(plan && out, "null argument");
+    require(plan->ctx != nullptr, "the plan was created without a context: it can be inspected, not run");
     auto part = std::make_unique<prism_gpu_part>();
     part->plan = plan;
     part->partition = partition;
@@ -222,6 +232,7 @@ void prism_gpu_part_free(prism_gpu_part* part) { delete part; }
 int prism_gpu_merge(prism_gpu_plan* plan, struct ArrowArray* const* states, size_t n_states, struct ArrowArray* out) {
   return guarded([&] {
     require(plan && out && (states || n_states == 0), "null argument");
+    require(plan->ctx != nullptr, "the plan was created without a context: it can be inspected, not run");
     auto table = new_table(plan->ctx, plan->partial_fields);
     for (size_t i = 0; i < n_states; ++i) {
       require(states[i] != nullptr, "null state array");
@@ -235,6 +246,7 @@ int prism_gpu_scan_stats(prism_gpu_plan* plan, prism_gpu_table* table, const uin
                          prism_gpu_col_stats* out) {
   return guarded([&] {
     require(plan && table && out, "null argument");
+    require(plan->ctx != nullptr, "the plan was created without a context: it can be inspected, not run");
     prism::scan_stats(plan, table, partition_ids, n_partitions, out);
   });
 }
@@ -243,6 +255,7 @@ int prism_gpu_aggregate(prism_gpu_plan* plan, prism_gpu_table* table, const uint
                         const prism_gpu_col_stats* stats, prism_gpu_state** out) {
   return guarded([&] {
     require(plan && table && out, "null argument");
+    require(plan->ctx != nullptr, "the plan was created without a context: it can be inspected, not run");
     *out = prism::aggregate_state(plan, table, partition_ids, n_partitions, stats);
   });
 }

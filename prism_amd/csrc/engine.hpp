@@ -133,6 +133,9 @@ namespace prism {
 std::unique_ptr<prism_gpu_plan> plan_create(prism_gpu_ctx* ctx, const ArrowSchema* schema,
                                             const prism_gpu_plan_desc* desc);
 
+// [lo, hi] (inclusive; lo > hi: no value) outside which `column` cannot satisfy the plan's WHERE.
+void plan_value_range(const prism_gpu_plan* plan, int column, int64_t* lo, int64_t* hi);
+
 // Runs the plan over resident chunks.  merge_input: the table holds PARTIAL state
 // batches of this plan and the result is the final rows.
 void execute_plan(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions,

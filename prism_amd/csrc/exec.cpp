@@ -1437,6 +1437,22 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
   }
   if (ss.n_tiles * (uint64_t)kTileRows > 0xffffffffull)
     fail(PRISM_GPU_EUNSUPPORTED, "more than 2^32 rows in one scan; split the scan by partition");
+  if (stats_override) {
+    // Keys are packed from these statistics without a mask: a value outside them would land
+    // in another key's bits, or outside a dense table.  They must cover this scan.
+    std::vector<int> used;
+    for (const KeyPlan& k : plan->keys) used.push_back(k.column);
+    for (const AggPlan& a : plan->aggs) if (a.column >= 0) used.push_back(a.column);
+    for (int c : used)
+      for (const Chunk* ch : ss.chunks) {
+        const ColStats& cs = ch->stats[c];
+        const prism_gpu_col_stats& o = stats_override[c];
+        const bool covered = (cs.min > cs.max || (o.min <= cs.min && cs.max <= o.max)) && (cs.null_count == 0 || o.nulls > 0);
+        if (!covered)
+          fail(PRISM_GPU_EINVAL, "the column statistics passed for `" + table->fields[c].name + "` do not cover partition " +
+                                     std::to_string(ch->partition_id) + " of this scan (its values or NULLs fall outside them)");
+      }
+  }
   const uint64_t n_words = ss.n_tiles * kTileWords;
   const bool partial = plan->mode == PRISM_MODE_PARTIAL && !merge_input;
 

@@ -1,6 +1,7 @@
 // Plan validation and normalisation: what DataFusion's physical planner does
 // between TableProvider::scan (src/prism-query/src/providers/table_provider.rs:73-132)
 // and the first poll of the aggregate stream.
+#include <algorithm>
 #include <cstring>
 
 #include "engine.hpp"
@@ -265,6 +266,59 @@ std::unique_ptr<prism_gpu_plan> plan_create(prism_gpu_ctx* ctx, const ArrowSchem
   }
   if (plan->order_by >= (int)plan->final_fields.size()) fail(PRISM_GPU_EINVAL, "order_by column out of range");
   return plan;
+}
+
+namespace {
+
+struct Interval {
+  int64_t lo, hi;  // inclusive; lo > hi: empty
+};
+constexpr int64_t kI64Lo = -0x7fffffffffffffffll - 1, kI64Hi = 0x7fffffffffffffffll;
+
+// Values of `column` for which node `i` can be TRUE.
+Interval range_of(const prism_gpu_plan* p, int i, int column) {
+  const PredNode& n = p->pred[i];
+  switch (n.kind) {
+    case PredNode::AND: {
+      const Interval a = range_of(p, n.lhs, column), b = range_of(p, n.rhs, column);
+      return {std::max(a.lo, b.lo), std::min(a.hi, b.hi)};
+    }
+    case PredNode::OR: {
+      const Interval a = range_of(p, n.lhs, column), b = range_of(p, n.rhs, column);
+      if (a.lo > a.hi) return b;
+      if (b.lo > b.hi) return a;
+      return {std::min(a.lo, b.lo), std::max(a.hi, b.hi)};
+    }
+    case PredNode::CMP: {
+      if (n.column != column || p->fields[column].is_string || p->fields[column].is_float) return {kI64Lo, kI64Hi};
+      const int64_t v = n.lit_i64;
+      switch (n.cmp_mask) {
+        case kEq: return {v, v};
+        case kLt: return v == kI64Lo ? Interval{0, -1} : Interval{kI64Lo, v - 1};
+        case kLt | kEq: return {kI64Lo, v};
+        case kGt: return v == kI64Hi ? Interval{0, -1} : Interval{v + 1, kI64Hi};
+        case kGt | kEq: return {v, kI64Hi};
+        case 0: return {0, -1};
+        default: return {kI64Lo, kI64Hi};  // <>, or always true
+      }
+    }
+    case PredNode::IS_NULL:
+      // a NULL has no value inside any range: partitions are not pruned for it
+      return {kI64Lo, kI64Hi};
+    default: return {kI64Lo, kI64Hi};
+  }
+}
+
+}  // namespace
+
+void plan_value_range(const prism_gpu_plan* plan, int column, int64_t* lo, int64_t* hi) {
+  if (column < 0 || (size_t)column >= plan->fields.size()) fail(PRISM_GPU_EINVAL, "column out of range");
+  const FieldType& f = plan->fields[column];
+  if (f.is_string || f.is_float) fail(PRISM_GPU_EINVAL, "a value range exists for integer and timestamp columns only");
+  Interval r{kI64Lo, kI64Hi};
+  if (plan->pred_root >= 0) r = range_of(plan, plan->pred_root, column);
+  *lo = r.lo;
+  *hi = r.hi;
 }
 
 }  // namespace prism

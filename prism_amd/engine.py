@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = [
     "prism_gpu_state_import", "prism_gpu_state_merge", "prism_gpu_state_finish", "prism_gpu_state_free",
     "prism_gpu_table_dictionary_digest",
     "prism_gpu_set_profiling", "prism_gpu_get_stats", "prism_gpu_reset_stats",
-    "prism_gpu_set_option", "prism_gpu_execute_noalloc",
+    "prism_gpu_set_option", "prism_gpu_execute_noalloc", "prism_gpu_plan_time_range",
 ]
 
 _LIB: Optional[C.CDLL] = None
@@ -103,6 +103,7 @@ def load_library() -> C.CDLL:
     L.prism_gpu_get_stats.argtypes = [V, P(abi.Stats)]
     L.prism_gpu_reset_stats.argtypes = [V]
     L.prism_gpu_set_option.argtypes = [V, C.c_char_p, C.c_int64]
+    L.prism_gpu_plan_time_range.argtypes = [V, C.c_int32, P(C.c_int64), P(C.c_int64)]
     L.prism_gpu_execute_noalloc.argtypes = [V, V, P(C.c_uint32), C.c_size_t, V, V, C.c_uint64, P(C.c_uint64)]
     _LIB = L
     return L
@@ -222,16 +223,18 @@ class Table:
 class Plan:
     """prism_gpu_plan over an input schema."""
 
-    def __init__(self, ctx: Context, schema: pa.Schema, query: QueryPlan):
+    def __init__(self, ctx: Optional[Context], schema: pa.Schema, query: QueryPlan):
+        """`ctx` None: a plan that can be inspected (schemas, time_range) but not run."""
         self.ctx = ctx
         self.schema = schema
         self.query = query
-        self._lib = ctx._lib
+        self._lib = ctx._lib if ctx is not None else load_library()
         self._lowered = lower(query, schema.names)
         self._h = C.c_void_p()
         cs = abi.export_schema(schema)
         try:
-            _check(self._lib.prism_gpu_plan_create(ctx._h, C.byref(cs), self._lowered.ptr(), C.byref(self._h)))
+            _check(self._lib.prism_gpu_plan_create(ctx._h if ctx is not None else None, C.byref(cs), self._lowered.ptr(),
+                                                   C.byref(self._h)))
         finally:
             abi.release_schema(cs)
         self.output_schema = self._schema(self._lib.prism_gpu_plan_output_schema)
@@ -253,6 +256,12 @@ class Plan:
                 arr[0] = 0xFFFFFFFF  # an id no partition has: scan nothing
             _check(self._lib.prism_gpu_execute(self._h, table._h, arr, max(1, len(ids)), C.byref(out)))
         return pa.Table.from_batches([abi.import_batch(out, self.output_schema)])
+
+    def time_range(self, column: str) -> tuple:
+        """(start, end) inclusive: values of `column` outside it cannot pass the WHERE."""
+        lo, hi = C.c_int64(), C.c_int64()
+        _check(self._lib.prism_gpu_plan_time_range(self._h, self.schema.names.index(column), C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
 
     def execute_noalloc(self, table: Table, partitions, out_values_ptr: int, out_valid_ptr: int, out_stride: int) -> int:
         """prism_gpu_execute_noalloc: result columns into caller-provided (device) buffers;
