@@ -303,7 +303,17 @@ int prism_gpu_execute_noalloc(prism_gpu_plan* plan, prism_gpu_table* table,
 /* Streaming form, one prism_gpu_part per DataFusion partition
  * (ExecutionPlan::execute(partition, ..) polled on its own thread):
  * push_batch moves one input RecordBatch in, finish returns the partition's
- * output (PARTIAL state or SINGLE result). */
+ * output (PARTIAL state or SINGLE result).
+ *
+ * push_batch takes the ArrowArray by the Arrow move rule: the struct is copied and
+ * batch->release is set to NULL at once; the library calls the release callback when the
+ * rows have been copied to the device, which happens once about 2^20 rows have gathered (or
+ * at finish), not inside the push.  What the struct points at (children, buffers,
+ * private_data) therefore has to stay valid until that release, as for any Arrow consumer.
+ * Each gathered chunk is copied through the partition's own page-locked ring on its own
+ * stream, aggregated while the next chunk gathers, and the chunk states are merged at
+ * finish.  Different parts may be driven from different threads at the same time; one part
+ * is driven by one thread at a time. */
 int prism_gpu_partition_open(prism_gpu_plan* plan, uint32_t partition,
                              prism_gpu_part** out);
 int prism_gpu_push_batch(prism_gpu_part* part, struct ArrowArray* batch);

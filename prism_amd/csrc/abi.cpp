@@ -62,10 +62,6 @@ int prism_gpu_init(int device_ordinal, prism_gpu_ctx** out) {
     prism::noalloc_init(device_ordinal);
     PRISM_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     PRISM_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-    for (int i = 0; i < 2; ++i) {
-      PRISM_HIP(hipHostMalloc(&ctx->stage[i], prism_gpu_ctx::kStageBytes, hipHostMallocDefault));
-      PRISM_HIP(hipEventCreateWithFlags(&ctx->stage_done[i], hipEventDisableTiming));
-    }
     *out = ctx.release();
   });
 }
@@ -74,17 +70,7 @@ void prism_gpu_ctx_free(prism_gpu_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
-  for (auto& kv : ctx->free_blocks) (void)hipFree(kv.second);
-  for (auto& kv : ctx->live_blocks) (void)hipFree(kv.first);
-  for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
-  for (int i = 0; i < 2; ++i) {
-    if (ctx->stage[i]) (void)hipHostFree(ctx->stage[i]);
-    if (ctx->stage_done[i]) (void)hipEventDestroy(ctx->stage_done[i]);
-  }
-  if (ctx->result_pinned) (void)hipHostFree(ctx->result_pinned);
-  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
-  if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
-  delete ctx;
+  prism::ctx_destroy(ctx);
 }
 
 int prism_gpu_table_create(prism_gpu_ctx* ctx, const struct ArrowSchema* schema, prism_gpu_table** out) {
@@ -202,11 +188,7 @@ int prism_gpu_partition_open(prism_gpu_plan* plan, uint32_t partition, prism_gpu
   return guarded([&] {
     require(plan && out, "null argument");
     require(plan->ctx != nullptr, "the plan was created without a context: it can be inspected, not run");
-    auto part = std::make_unique<prism_gpu_part>();
-    part->plan = plan;
-    part->partition = partition;
-    part->table = new_table(plan->ctx, plan->fields);
-    *out = part.release();
+    *out = prism::part_open(plan, partition).release();
   });
 }
 
@@ -216,14 +198,14 @@ int prism_gpu_push_batch(prism_gpu_part* part, struct ArrowArray* batch) {
       if (batch && batch->release) batch->release(batch);
       prism::fail(PRISM_GPU_EINVAL, "part is null");
     }
-    prism::table_append(part->table.get(), part->partition, batch, true);
+    prism::part_push(part, batch);
   });
 }
 
 int prism_gpu_finish(prism_gpu_part* part, struct ArrowArray* out) {
   return guarded([&] {
     require(part && out, "null argument");
-    prism::execute_plan(part->plan, part->table.get(), nullptr, 0, false, out);
+    prism::part_finish(part, out);
   });
 }
 

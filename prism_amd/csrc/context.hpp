@@ -43,11 +43,20 @@ struct prism_gpu_ctx {
   size_t pool_bytes = 0;
 
   // ---- pinned staging ring (two halves, double buffered against the copy) ----
-  static constexpr size_t kStageBytes = 64ull << 20;
+  // Allocated on first use.  A half is refilled only after the event recorded behind the
+  // copy that read it has completed; stage_mu makes staging one thread at a time per context
+  // (threads that stream partitions concurrently have a context each: child contexts).
+  static constexpr size_t kStageBytes = 64ull << 20, kChildStageBytes = 32ull << 20;
+  std::mutex stage_mu;
+  size_t stage_bytes = kStageBytes;
   void* stage[2] = {nullptr, nullptr};
   hipEvent_t stage_done[2] = {nullptr, nullptr};
-  bool stage_busy[2] = {false, false};
+  bool stage_used[2] = {false, false};
   int stage_next = 0;
+
+  // ---- child contexts: same device, streams / ring / pool / statistics of their own ----
+  prism_gpu_ctx* parent = nullptr;
+  std::vector<prism_gpu_ctx*> idle_children;  // (parent only, under mu) kept warm between partitions
 
   // ---- pinned landing buffer for results read back from HBM ----
   std::mutex result_mu;
@@ -75,6 +84,14 @@ struct prism_gpu_ctx {
 namespace prism {
 
 inline void bind(prism_gpu_ctx* ctx) { PRISM_HIP(hipSetDevice(ctx->device)); }
+
+// (under ctx->stage_mu)
+inline void ensure_stage_ring(prism_gpu_ctx* ctx) {
+  for (int i = 0; i < 2; ++i) {
+    if (!ctx->stage[i]) PRISM_HIP(hipHostMalloc(&ctx->stage[i], ctx->stage_bytes, hipHostMallocDefault));
+    if (!ctx->stage_done[i]) PRISM_HIP(hipEventCreateWithFlags(&ctx->stage_done[i], hipEventDisableTiming));
+  }
+}
 
 // Scratch memory for one call; returned to the pool by free_scratch.
 inline void* alloc_scratch(prism_gpu_ctx* ctx, size_t bytes) {

@@ -51,6 +51,7 @@ constexpr size_t kMaxDictValues = 1u << 16;
 
 struct prism_gpu_table {
   prism_gpu_ctx* ctx = nullptr;
+  bool pooled = false;  // column memory comes from the context's scratch pool (short-lived chunk tables)
   std::vector<prism::FieldType> fields;
   std::vector<prism::Chunk> chunks;
   std::vector<prism::ColumnDict> dicts;  // one per column (used by string columns)
@@ -62,6 +63,9 @@ namespace prism {
 
 // Appends one RecordBatch.  `take` = release the array when done (moved), else borrow.
 void table_append(prism_gpu_table* t, uint32_t partition_id, ArrowArray* batch, bool take);
+// The same for several batches that become one chunk.
+void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray* const* batches, size_t n_batches, bool take);
+void free_chunk_memory(prism_gpu_table* t, Chunk& ch);
 void table_synth(prism_gpu_table* t, uint32_t partition_id, uint64_t seed, uint64_t first_row, uint64_t n_rows,
                  uint64_t total_rows, const prism_gpu_synth_col* cols, uint32_t n_cols);
 void table_sync_stats(prism_gpu_table* t);
@@ -122,11 +126,21 @@ struct prism_gpu_plan {
   std::atomic<uint64_t> part_table_capacity{0};  // capacity that the HBM table behind the LDS tables needed last time
 };
 
+// One streaming partition (ExecutionPlan::execute(partition) on a thread of its own).  It
+// works on a child context (streams, pinned ring, scratch pool of its own), gathers the
+// incoming batches into chunks of about kPartChunkRows rows, stages a chunk while the one
+// before it is aggregated into PARTIAL state, and merges the states at the end.
 struct prism_gpu_part {
   prism_gpu_plan* plan = nullptr;
   uint32_t partition = 0;
-  std::unique_ptr<prism_gpu_table> table;
+  prism_gpu_ctx* ctx = nullptr;             // child context, returned to the parent when the part is freed
+  std::vector<ArrowArray> pending;          // batches moved in, not yet staged
+  uint64_t pending_rows = 0, rows_total = 0, chunks_done = 0;
+  std::unique_ptr<prism_gpu_table> staged;    // the chunk in flight: staged, not yet aggregated
+  std::unique_ptr<prism_gpu_table> partials;  // PARTIAL state of the chunks aggregated so far
+  ~prism_gpu_part();
 };
+constexpr uint64_t kPartChunkRows = 1ull << 20;
 
 namespace prism {
 
@@ -141,6 +155,19 @@ void plan_value_range(const prism_gpu_plan* plan, int column, int64_t* lo, int64
 void execute_plan(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions,
                   bool merge_input, ArrowArray* out);
 
+// The same on a given (child) context, over all chunks of the table; emit_partial: PARTIAL
+// state columns whatever the plan's mode (merge_input + emit_partial merges states into states).
+void execute_plan_on(prism_gpu_ctx* ctx, prism_gpu_plan* plan, prism_gpu_table* table, bool merge_input, bool emit_partial,
+                     ArrowArray* out);
+
+// Streaming partitions (part.cpp).
+prism_gpu_ctx* ctx_acquire_child(prism_gpu_ctx* parent);
+void ctx_release_child(prism_gpu_ctx* child);
+void ctx_destroy(prism_gpu_ctx* ctx);
+std::unique_ptr<prism_gpu_part> part_open(prism_gpu_plan* plan, uint32_t partition);
+void part_push(prism_gpu_part* part, ArrowArray* batch);
+void part_finish(prism_gpu_part* part, ArrowArray* out);
+
 // Device-resident aggregate state (prism_gpu_aggregate and friends).
 void scan_stats(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions,
                 prism_gpu_col_stats* out);
@@ -152,6 +179,36 @@ void state_import(prism_gpu_state* st, const void* device_src, size_t bytes);
 void state_merge(prism_gpu_state* st, const void* device_src, uint64_t n_groups);
 void state_finish(prism_gpu_state* st, ArrowArray* out);
 void state_free(prism_gpu_state* st);
+
+// What a collective needs to see of a state (comm.cpp).  Dense: slot s occupies
+// dense_state[s * dense_stride .. + entries].  Hash: the occupied groups in compact form,
+// keys[entries] and state[n_slots][entries]; valid until the state is merged into or freed.
+struct StateView {
+  prism_gpu_plan* plan = nullptr;
+  bool dense = false;
+  int n_slots = 0;
+  uint64_t entries = 0;
+  int64_t* dense_state = nullptr;
+  uint64_t dense_stride = 0;
+  const uint64_t* keys = nullptr;
+  const int64_t* state = nullptr;
+  std::vector<int> slot_ops;  // SlotOp per slot
+};
+StateView state_view(prism_gpu_state* st);
+// The groups of a hash state that can still appear in the plan's result: all of them, or,
+// with ORDER BY .. LIMIT over a column the device can rank, the leading ones (ties at the
+// cut included).  Compact form in fresh blocks: keys[n], state[n_slots][n]; returns n.
+uint64_t state_leading_rows(prism_gpu_state* st, struct Scratch& out_keys, struct Scratch& out_state);
+
+// ---- collectives between the GPUs of a node (comm.cpp) ----
+prism_gpu_comm* comm_create_rccl(prism_gpu_ctx* ctx, const void* unique_id, int rank, int world);
+prism_gpu_comm* comm_create_callbacks(prism_gpu_ctx* ctx, const prism_gpu_transport* t, int rank, int world);
+void comm_unique_id(void* out);
+void comm_destroy(prism_gpu_comm* c);
+// 1 when `out` was filled (this rank is `root`), 0 otherwise.
+int execute_sharded(prism_gpu_comm* c, prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids,
+                    size_t n_partitions, int root, ArrowArray* out);
+void comm_stats(prism_gpu_comm* c, prism_gpu_comm_stats* out);
 
 // The entry point that allocates nothing (prism_gpu_execute_noalloc): its device memory is
 // a fixed array of the library (noalloc.hip), laid out as descriptors | counters | accumulators.

@@ -1385,12 +1385,18 @@ bool try_fuse_predicate(const prism_gpu_plan* plan, const prism_gpu_table* table
 }
 
 void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions,
-                  bool merge_input, ArrowArray* out, const prism_gpu_col_stats* stats_override, prism_gpu_state** capture);
+                  bool merge_input, ArrowArray* out, const prism_gpu_col_stats* stats_override, prism_gpu_state** capture,
+                  bool emit_partial = false, prism_gpu_ctx* ctx_override = nullptr);
 }
 
 void execute_plan(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions,
                   bool merge_input, ArrowArray* out) {
   execute_impl(plan, table, partition_ids, n_partitions, merge_input, out, nullptr, nullptr);
+}
+
+void execute_plan_on(prism_gpu_ctx* ctx, prism_gpu_plan* plan, prism_gpu_table* table, bool merge_input, bool emit_partial,
+                     ArrowArray* out) {
+  execute_impl(plan, table, nullptr, 0, merge_input, out, nullptr, nullptr, emit_partial, ctx);
 }
 
 namespace {
@@ -1399,8 +1405,10 @@ namespace {
 // over instead of producing rows; `stats_override` then replaces the scan's own column
 // statistics so that every rank of a multi-GPU query packs keys the same way.
 void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions,
-                  bool merge_input, ArrowArray* out, const prism_gpu_col_stats* stats_override, prism_gpu_state** capture) {
-  prism_gpu_ctx* ctx = plan->ctx;
+                  bool merge_input, ArrowArray* out, const prism_gpu_col_stats* stats_override, prism_gpu_state** capture,
+                  bool emit_partial, prism_gpu_ctx* ctx_override) {
+  // (ctx_override: a child context of the plan's, for partitions that stream concurrently)
+  prism_gpu_ctx* ctx = ctx_override ? ctx_override : plan->ctx;
   bind(ctx);
   if (capture && (plan->keys.empty() || plan->distinct_plan))
     fail(PRISM_GPU_EUNSUPPORTED, "device-resident aggregate state needs a GROUP BY without COUNT(DISTINCT)");
@@ -1454,7 +1462,9 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       }
   }
   const uint64_t n_words = ss.n_tiles * kTileWords;
-  const bool partial = plan->mode == PRISM_MODE_PARTIAL && !merge_input;
+  // emit_partial: state columns whatever the plan's mode (the chunks of a streaming partition
+  // are aggregated one by one and merged at the end)
+  const bool partial = emit_partial || (plan->mode == PRISM_MODE_PARTIAL && !merge_input);
 
   // ---- lowering ----
   std::vector<KeySrc> keys;
@@ -1756,7 +1766,7 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
         selvec.reset();
         PRISM_HIP(hipStreamSynchronize(ctx->stream));
         collect_timings(ctx);
-        execute_impl(plan, table, partition_ids, n_partitions, merge_input, out, stats_override, capture);
+        execute_impl(plan, table, partition_ids, n_partitions, merge_input, out, stats_override, capture, emit_partial, ctx_override);
         return;
       }
       if (dense || flag == 0u) break;
@@ -2161,6 +2171,71 @@ void state_finish(prism_gpu_state* st, ArrowArray* out) {
 void state_free(prism_gpu_state* st) {
   if (st) bind(st->plan->ctx);
   delete st;
+}
+
+StateView state_view(prism_gpu_state* st) {
+  bind(st->plan->ctx);
+  StateView v;
+  v.plan = st->plan;
+  v.dense = st->gt.dense;
+  v.n_slots = st->gt.n_slots;
+  v.slot_ops = st->slot_ops;
+  if (v.dense) {
+    v.entries = st->gt.capacity;
+    v.dense_state = st->gt.state.as<int64_t>();
+    v.dense_stride = st->gt.capacity + 1;
+  } else {
+    state_compact(st);
+    v.entries = st->c_n;
+    v.keys = st->c_keys.as<uint64_t>();
+    v.state = st->c_state.as<int64_t>();
+  }
+  return v;
+}
+
+uint64_t state_leading_rows(prism_gpu_state* st, Scratch& out_keys, Scratch& out_state) {
+  prism_gpu_plan* plan = st->plan;
+  prism_gpu_ctx* ctx = plan->ctx;
+  bind(ctx);
+  const GroupTable& g = st->gt;
+  if (g.dense) fail(PRISM_GPU_EINTERNAL, "leading rows are read from hash states");
+  const uint64_t entries = g.capacity + 1;
+  TopKOrder order;
+  std::vector<OutColumn> cols = make_columns(plan->final_fields);
+  if (!(entries >= kTopKMinEntries && topk_order(plan, st->table, st->keys, st->layout, st->low, cols, order))) {
+    state_compact(st);
+    out_keys = Scratch(ctx, std::max<uint64_t>(1, st->c_n) * 8);
+    out_state = Scratch(ctx, std::max<uint64_t>(1, st->c_n) * 8 * (uint64_t)g.n_slots);
+    if (st->c_n) {
+      PRISM_HIP(hipMemcpyAsync(out_keys.p, st->c_keys.p, st->c_n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+      PRISM_HIP(hipMemcpyAsync(out_state.p, st->c_state.p, st->c_n * 8 * (uint64_t)g.n_slots, hipMemcpyDeviceToDevice, ctx->stream));
+      PRISM_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return st->c_n;
+  }
+  // at most the limit plus the entries of the last radix bin pass the threshold
+  const uint64_t room = (uint64_t)std::max<int64_t>(1, plan->limit) + 4096;
+  Scratch d_topk(ctx, sizeof(TopKState)), d_count(ctx, 256);
+  launch_topk_threshold(ctx, false, g.capacity, g.keys.as<uint64_t>(), nullptr, g.state.as<int64_t>(), order,
+                        (uint64_t)std::max<int64_t>(1, plan->limit), d_topk.as<TopKState>());
+  out_keys = Scratch(ctx, room * 8);
+  out_state = Scratch(ctx, room * 8 * (uint64_t)g.n_slots);
+  PRISM_HIP(hipMemsetAsync(d_count.p, 0, 8, ctx->stream));
+  launch_emit(ctx, false, g.capacity, g.keys.as<uint64_t>(), nullptr, g.state.as<int64_t>(), g.n_slots, out_keys.as<uint64_t>(),
+              nullptr, out_state.as<int64_t>(), room, d_count.as<unsigned long long>(), &order, d_topk.as<TopKState>(), room);
+  unsigned long long n = 0;
+  PRISM_HIP(hipMemcpyAsync(&n, d_count.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+  PRISM_HIP(hipStreamSynchronize(ctx->stream));
+  collect_timings(ctx);
+  if (n > room) fail(PRISM_GPU_EINTERNAL, "more leading groups than the radix select admits");
+  // columns are `room` apart: close them up to n
+  if (n && n < room) {
+    Scratch packed(ctx, n * 8 * (uint64_t)g.n_slots);
+    PRISM_HIP(hipMemcpy2DAsync(packed.p, n * 8, out_state.p, room * 8, n * 8, (size_t)g.n_slots, hipMemcpyDeviceToDevice, ctx->stream));
+    PRISM_HIP(hipStreamSynchronize(ctx->stream));
+    out_state = std::move(packed);
+  }
+  return n;
 }
 
 }  // namespace prism

@@ -28,30 +28,71 @@ uint32_t ColumnDict::id_of(const char* s, size_t n) {
 
 namespace {
 
-void* dev_alloc(size_t bytes) {
-  void* p = nullptr;
+// Device memory of a table's columns: a plain allocation, or (tables that come and go,
+// like the chunks of a streaming partition) a block of the context's scratch pool.
+void* dev_alloc(prism_gpu_table* t, size_t bytes) {
   // slack: kernels read whole 16-byte vectors (plus one dword) at the tail
-  PRISM_HIP(hipMalloc(&p, round_up(bytes, 256) + 256));
+  const size_t padded = round_up(bytes, 256) + 256;
+  if (t->pooled) return alloc_scratch(t->ctx, padded);
+  void* p = nullptr;
+  PRISM_HIP(hipMalloc(&p, padded));
   return p;
 }
 
-// Host -> HBM through the pinned ring.  The source may be pageable memory owned by
-// the caller (Arrow buffers): it is copied into a pinned half while the other half
-// is still in flight on the copy stream.
-void stage_copy(prism_gpu_ctx* ctx, void* dst, const void* src, size_t bytes) {
-  std::lock_guard<std::mutex> g(ctx->mu);
-  const size_t step = prism_gpu_ctx::kStageBytes;
-  for (size_t off = 0; off < bytes; off += step) {
-    size_t n = bytes - off < step ? bytes - off : step;
-    int i = ctx->stage_next;
+void dev_free(prism_gpu_table* t, void* p) {
+  if (!p) return;
+  if (t->pooled) free_scratch(t->ctx, p);
+  else (void)hipFree(p);
+}
+
+// Host -> HBM through the pinned ring: bytes are gathered into a pinned half (they may come
+// from many small Arrow buffers) and leave with one copy per half while the other half
+// fills.  A half is reused only after the copy that read it has completed (its event); the
+// ring belongs to one context, and a context stages for one thread at a time (ctx->stage_mu).
+struct StageWriter {
+  prism_gpu_ctx* ctx;
+  uint8_t* dst = nullptr;  // device address the next flushed byte goes to
+  int half = -1;
+  size_t fill = 0;
+  explicit StageWriter(prism_gpu_ctx* c) : ctx(c) {}
+  void begin(void* device_dst) { flush(); dst = (uint8_t*)device_dst; }
+  void acquire() {
+    half = ctx->stage_next;
     ctx->stage_next ^= 1;
-    if (ctx->stage_busy[i]) PRISM_HIP(hipEventSynchronize(ctx->stage_done[i]));
-    std::memcpy(ctx->stage[i], (const uint8_t*)src + off, n);
-    PRISM_HIP(hipMemcpyAsync((uint8_t*)dst + off, ctx->stage[i], n, hipMemcpyHostToDevice, ctx->copy_stream));
-    PRISM_HIP(hipEventRecord(ctx->stage_done[i], ctx->copy_stream));
-    ctx->stage_busy[i] = true;
+    if (ctx->stage_used[half]) PRISM_HIP(hipEventSynchronize(ctx->stage_done[half]));
+    fill = 0;
   }
-  ctx->stats.bytes_staged += bytes;
+  void write(const void* src, size_t bytes) {
+    const uint8_t* s = (const uint8_t*)src;
+    while (bytes) {
+      if (half < 0) acquire();
+      const size_t room = ctx->stage_bytes - fill, n = bytes < room ? bytes : room;
+      std::memcpy((uint8_t*)ctx->stage[half] + fill, s, n);
+      fill += n;
+      s += n;
+      bytes -= n;
+      if (fill == ctx->stage_bytes) flush();
+    }
+  }
+  void flush() {
+    if (half < 0 || fill == 0) { return; }
+    PRISM_HIP(hipMemcpyAsync(dst, ctx->stage[half], fill, hipMemcpyHostToDevice, ctx->copy_stream));
+    PRISM_HIP(hipEventRecord(ctx->stage_done[half], ctx->copy_stream));
+    ctx->stage_used[half] = true;
+    ctx->stats.bytes_staged += fill;
+    dst += fill;
+    half = -1;
+    fill = 0;
+  }
+};
+
+void stage_copy(prism_gpu_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  std::lock_guard<std::mutex> g(ctx->stage_mu);
+  ensure_stage_ring(ctx);
+  StageWriter w(ctx);
+  w.begin(dst);
+  w.write(src, bytes);
+  w.flush();
 }
 
 bool bit_at(const uint8_t* bits, int64_t i) { return (bits[i >> 3] >> (i & 7)) & 1; }
@@ -78,48 +119,101 @@ struct StrView {
 
 }  // namespace prism
 
+namespace prism {
+
+void free_chunk_memory(prism_gpu_table* t, Chunk& ch) {
+  for (auto& c : ch.cols) {
+    dev_free(t, c.values);
+    dev_free(t, c.validity);
+    dev_free(t, c.bytes);
+    dev_free(t, c.codes);
+    c = DeviceColumn();
+  }
+  dev_free(t, ch.d_stats);
+  ch.d_stats = nullptr;
+}
+
+}  // namespace prism
+
 prism_gpu_table::~prism_gpu_table() {
   if (ctx) (void)hipSetDevice(ctx->device);
-  for (auto& ch : chunks) {
-    for (auto& c : ch.cols) {
-      if (c.values) (void)hipFree(c.values);
-      if (c.validity) (void)hipFree(c.validity);
-      if (c.bytes) (void)hipFree(c.bytes);
-      if (c.codes) (void)hipFree(c.codes);
-    }
-    if (ch.d_stats) (void)hipFree(ch.d_stats);
-  }
+  // copies and statistics kernels of recent appends may still be reading or writing the buffers
+  if (ctx && ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+  for (auto& ch : chunks) prism::free_chunk_memory(this, ch);
 }
 
 namespace prism {
 
 namespace {
 
-void init_stats(prism_gpu_ctx* ctx, Chunk& ch, size_t n_cols) {
+void init_stats(prism_gpu_table* t, Chunk& ch, size_t n_cols) {
   ch.stats.assign(n_cols, ColStats{0x7fffffffffffffffll, -0x7fffffffffffffffll - 1, 0});
-  ch.d_stats = (ColStats*)dev_alloc(n_cols * sizeof(ColStats));
-  stage_copy(ctx, ch.d_stats, ch.stats.data(), n_cols * sizeof(ColStats));
+  ch.d_stats = (ColStats*)dev_alloc(t, n_cols * sizeof(ColStats));
+  stage_copy(t->ctx, ch.d_stats, ch.stats.data(), n_cols * sizeof(ColStats));
 }
 
 }  // namespace
 
-void table_append(prism_gpu_table* t, uint32_t partition_id, ArrowArray* batch, bool take) {
+namespace {
+
+// Appends bits [offset, offset + n) of `bits` (nullptr: all ones) at bit position `at` of `out`.
+void append_bits(std::vector<uint64_t>& out, uint64_t at, const uint8_t* bits, int64_t offset, int64_t n) {
+  if (n <= 0) return;
+  if (!bits) {
+    for (int64_t i = 0; i < n;) {
+      const uint64_t pos = at + (uint64_t)i, room = 64 - (pos & 63), take = (uint64_t)(n - i) < room ? (uint64_t)(n - i) : room;
+      const uint64_t mask = take == 64 ? ~0ull : (((1ull << take) - 1ull) << (pos & 63));
+      out[(size_t)(pos >> 6)] |= mask;
+      i += (int64_t)take;
+    }
+    return;
+  }
+  if ((at & 7) == 0 && (offset & 7) == 0) {
+    uint8_t* o = (uint8_t*)out.data() + (at >> 3);
+    const uint8_t* in = bits + (offset >> 3);
+    const int64_t whole = n >> 3;
+    std::memcpy(o, in, (size_t)whole);
+    for (int64_t i = whole * 8; i < n; ++i)
+      if (bit_at(bits, offset + i)) out[(size_t)((at + (uint64_t)i) >> 6)] |= 1ull << ((at + (uint64_t)i) & 63);
+    return;
+  }
+  for (int64_t i = 0; i < n; ++i)
+    if (bit_at(bits, offset + i)) out[(size_t)((at + (uint64_t)i) >> 6)] |= 1ull << ((at + (uint64_t)i) & 63);
+}
+
+}  // namespace
+
+// One chunk from one or more RecordBatches (the batches of a streaming partition arrive
+// 8192 rows at a time; a chunk of them is staged and scanned as one).
+void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray* const* batches, size_t n_batches, bool take) {
   prism_gpu_ctx* ctx = t->ctx;
   bind(ctx);
   struct Releaser {
-    ArrowArray* a;
+    ArrowArray* const* b;
+    size_t n;
     bool take;
-    ~Releaser() { if (take && a && a->release) a->release(a); }
-  } releaser{batch, take};
+    ~Releaser() {
+      if (!take) return;
+      for (size_t i = 0; i < n; ++i)
+        if (b[i] && b[i]->release) b[i]->release(b[i]);
+    }
+  } releaser{batches, n_batches, take};
 
-  if (!batch) fail(PRISM_GPU_EINVAL, "batch is null");
-  if (batch->n_children != (int64_t)t->fields.size())
-    fail(PRISM_GPU_EINVAL, "batch has " + std::to_string(batch->n_children) + " columns, table schema has " +
-                               std::to_string(t->fields.size()));
-  if (batch->offset != 0) fail(PRISM_GPU_EUNSUPPORTED, "struct arrays with a non-zero offset are not supported");
-  const int64_t n = batch->length;
+  int64_t n = 0;
+  for (size_t b = 0; b < n_batches; ++b) {
+    const ArrowArray* batch = batches[b];
+    if (!batch) fail(PRISM_GPU_EINVAL, "batch is null");
+    if (batch->n_children != (int64_t)t->fields.size())
+      fail(PRISM_GPU_EINVAL, "batch has " + std::to_string(batch->n_children) + " columns, table schema has " +
+                                 std::to_string(t->fields.size()));
+    if (batch->offset != 0) fail(PRISM_GPU_EUNSUPPORTED, "struct arrays with a non-zero offset are not supported");
+    for (size_t ci = 0; ci < t->fields.size(); ++ci)
+      if (batch->children[ci]->length != batch->length)
+        fail(PRISM_GPU_EINVAL, "column " + t->fields[ci].name + " has a different length than the batch");
+    n += batch->length;
+  }
   if (n == 0) return;
-  if (n > 0x7fffffff) fail(PRISM_GPU_EUNSUPPORTED, "a batch may hold at most 2^31-1 rows");
+  if (n > 0x1fffffff) fail(PRISM_GPU_EUNSUPPORTED, "a chunk may hold at most 2^29-1 rows");
 
   auto t0 = std::chrono::steady_clock::now();
   std::lock_guard<std::mutex> g(t->mu);
@@ -129,108 +223,148 @@ void table_append(prism_gpu_table* t, uint32_t partition_id, ArrowArray* batch, 
   ch.cols.resize(t->fields.size());
   // the chunk owns its device memory from here on: on failure free it
   struct ChunkGuard {
+    prism_gpu_table* t;
     Chunk* ch;
     bool armed = true;
-    ~ChunkGuard() {
-      if (!armed) return;
-      for (auto& c : ch->cols) {
-        if (c.values) (void)hipFree(c.values);
-        if (c.validity) (void)hipFree(c.validity);
-        if (c.bytes) (void)hipFree(c.bytes);
-        if (c.codes) (void)hipFree(c.codes);
-      }
-      if (ch->d_stats) (void)hipFree(ch->d_stats);
-    }
-  } guard{&ch};
-  init_stats(ctx, ch, t->fields.size());
+    ~ChunkGuard() { if (armed) free_chunk_memory(t, *ch); }
+  } guard{t, &ch};
+  init_stats(t, ch, t->fields.size());
 
+  std::lock_guard<std::mutex> stage_lock(ctx->stage_mu);
+  ensure_stage_ring(ctx);
+  StageWriter w(ctx);
   for (size_t ci = 0; ci < t->fields.size(); ++ci) {
     const FieldType& f = t->fields[ci];
-    const ArrowArray* a = batch->children[ci];
     DeviceColumn& dc = ch.cols[ci];
-    if (a->length != n) fail(PRISM_GPU_EINVAL, "column " + f.name + " has a different length than the batch");
-    const uint8_t* vbits = (a->null_count != 0 && a->n_buffers > 0) ? (const uint8_t*)a->buffers[0] : nullptr;
-    if (vbits) {
-      std::vector<uint64_t> words = realign_validity(vbits, a->offset, n);
-      bool any_null = false;
+    // ---- validity: one bitmap for the chunk, present only if some row is NULL ----
+    bool any_null = false;
+    for (size_t b = 0; b < n_batches && !any_null; ++b) {
+      const ArrowArray* a = batches[b]->children[ci];
+      any_null = a->null_count != 0 && a->n_buffers > 0 && a->buffers[0] != nullptr && a->length > 0;
+    }
+    if (any_null) {
+      std::vector<uint64_t> words((size_t)ceil_div((uint64_t)n, kTileRows) * kTileWords, 0);  // whole tiles: kernels read a tile's words even past the last row
+      uint64_t at = 0;
+      for (size_t b = 0; b < n_batches; ++b) {
+        const ArrowArray* a = batches[b]->children[ci];
+        const uint8_t* vbits = (a->null_count != 0 && a->n_buffers > 0) ? (const uint8_t*)a->buffers[0] : nullptr;
+        append_bits(words, at, vbits, a->offset, a->length);
+        at += (uint64_t)a->length;
+      }
+      any_null = false;
       for (int64_t i = 0; i < n && !any_null; i += 64) {
-        uint64_t want = n - i >= 64 ? ~0ull : ((1ull << (n - i)) - 1ull);
+        const uint64_t want = n - i >= 64 ? ~0ull : ((1ull << (n - i)) - 1ull);
         any_null = (words[(size_t)(i >> 6)] & want) != want;
       }
       if (any_null) {
-        dc.validity = (uint64_t*)dev_alloc(words.size() * 8);
-        stage_copy(ctx, dc.validity, words.data(), words.size() * 8);
+        dc.validity = (uint64_t*)dev_alloc(t, words.size() * 8);
+        w.begin(dc.validity);
+        w.write(words.data(), words.size() * 8);
       }
     }
     if (!f.is_string) {
-      if (a->dictionary) fail(PRISM_GPU_EUNSUPPORTED, "dictionary encoding is only supported for string columns");
-      if (a->n_buffers < 2 || !a->buffers[1]) fail(PRISM_GPU_EINVAL, "column " + f.name + " has no value buffer");
-      const uint8_t* src = (const uint8_t*)a->buffers[1] + (size_t)a->offset * f.width;
-      dc.values = dev_alloc((size_t)n * f.width);
-      stage_copy(ctx, dc.values, src, (size_t)n * f.width);
-      launch_col_stats(ctx, dc.values, dc.validity, f.width, f.is_unsigned, (uint64_t)n, &ch.d_stats[ci],
-                       ctx->copy_stream);
+      dc.values = dev_alloc(t, (size_t)n * f.width);
+      w.begin(dc.values);
+      for (size_t b = 0; b < n_batches; ++b) {
+        const ArrowArray* a = batches[b]->children[ci];
+        if (a->dictionary) fail(PRISM_GPU_EUNSUPPORTED, "dictionary encoding is only supported for string columns");
+        if (a->length == 0) continue;
+        if (a->n_buffers < 2 || !a->buffers[1]) fail(PRISM_GPU_EINVAL, "column " + f.name + " has no value buffer");
+        w.write((const uint8_t*)a->buffers[1] + (size_t)a->offset * f.width, (size_t)a->length * f.width);
+      }
+      w.flush();
+      launch_col_stats(ctx, dc.values, dc.validity, f.width, f.is_unsigned, (uint64_t)n, &ch.d_stats[ci], ctx->copy_stream);
       continue;
     }
     // ---- string column: raw representation + table-wide dictionary codes ----
     ColumnDict& dict = t->dicts[ci];
     std::vector<uint32_t> codes;
     if (dict.alive) codes.resize((size_t)n);
-    std::vector<int32_t> offs((size_t)n + 1);
-    std::vector<uint8_t> expanded;  // raw bytes when the input is dictionary encoded
-    const uint8_t* raw_src = nullptr;
-    size_t raw_len = 0;
-    if (a->dictionary) {
-      const ArrowArray* d = a->dictionary;
-      const int32_t* idx = (const int32_t*)a->buffers[1] + a->offset;
-      const int32_t* doff = (const int32_t*)d->buffers[1] + d->offset;
-      const char* dbytes = (const char*)d->buffers[2];
-      std::vector<uint32_t> remap;
-      if (dict.alive) {
-        remap.resize((size_t)d->length);
-        for (int64_t k = 0; k < d->length; ++k) remap[(size_t)k] = dict.id_of(dbytes + doff[k], (size_t)(doff[k + 1] - doff[k]));
-      }
-      size_t total = 0;
-      for (int64_t i = 0; i < n; ++i) {
-        bool valid = !vbits || bit_at(vbits, a->offset + i);
-        int32_t k = valid ? idx[i] : 0;
-        if (valid && (k < 0 || k >= d->length)) fail(PRISM_GPU_EINVAL, "dictionary index out of range in " + f.name);
-        total += valid ? (size_t)(doff[k + 1] - doff[k]) : 0;
-      }
-      if (total > 0x7fffffffull) fail(PRISM_GPU_EUNSUPPORTED, "string data of one batch exceeds 2 GiB");
-      expanded.resize(total);
-      size_t pos = 0;
-      offs[0] = 0;
-      for (int64_t i = 0; i < n; ++i) {
-        bool valid = !vbits || bit_at(vbits, a->offset + i);
-        if (valid) {
-          int32_t k = idx[i];
-          size_t len = (size_t)(doff[k + 1] - doff[k]);
-          std::memcpy(expanded.data() + pos, dbytes + doff[k], len);
-          pos += len;
-          if (dict.alive) codes[(size_t)i] = remap[(size_t)k];
-        } else if (dict.alive) {
-          codes[(size_t)i] = 0;
+    // Chunks of a streaming partition whose every batch is dictionary encoded keep only the
+    // codes (the table-wide dictionary of such a table stays small: it is the union of the
+    // batches' dictionaries).
+    bool codes_only = t->pooled && dict.alive && t->chunks.empty();
+    for (size_t b = 0; b < n_batches && codes_only; ++b) {
+      const ArrowArray* a = batches[b]->children[ci];
+      codes_only = a->length == 0 || (a->dictionary != nullptr && a->dictionary->length <= 4096);
+    }
+    std::vector<int32_t> offs(codes_only ? 1 : (size_t)n + 1);
+    offs[0] = 0;
+    // bytes of the chunk: total first (it sizes the device buffer), then the pieces
+    uint64_t total = 0;
+    struct Piece { const uint8_t* p; size_t n; };
+    std::vector<Piece> pieces;
+    std::vector<std::vector<uint8_t>> expanded;  // raw bytes of dictionary-encoded input
+    int64_t row0 = 0;
+    for (size_t b = 0; b < n_batches; ++b) {
+      const ArrowArray* a = batches[b]->children[ci];
+      const int64_t nb = a->length;
+      if (nb == 0) continue;
+      const uint8_t* vbits = (a->null_count != 0 && a->n_buffers > 0) ? (const uint8_t*)a->buffers[0] : nullptr;
+      if (a->dictionary) {
+        // Int32 indices into a Utf8 / Binary dictionary (the schema declares the index type
+        // when the column is declared dictionary encoded; other index widths are not accepted)
+        const ArrowArray* d = a->dictionary;
+        if (a->n_buffers < 2 || !a->buffers[1] || d->n_buffers < 3 || !d->buffers[1])
+          fail(PRISM_GPU_EINVAL, "dictionary-encoded column " + f.name + " lacks a buffer");
+        const int32_t* idx = (const int32_t*)a->buffers[1] + a->offset;
+        const int32_t* doff = (const int32_t*)d->buffers[1] + d->offset;
+        const char* dbytes = (const char*)d->buffers[2];
+        const uint8_t* dvalid = (d->null_count != 0 && d->n_buffers > 0) ? (const uint8_t*)d->buffers[0] : nullptr;
+        if (dvalid) fail(PRISM_GPU_EUNSUPPORTED, "NULL entries inside a dictionary are not supported (column " + f.name + ")");
+        std::vector<uint32_t> remap;
+        if (dict.alive) {
+          remap.resize((size_t)d->length);
+          for (int64_t k = 0; k < d->length; ++k) remap[(size_t)k] = dict.id_of(dbytes + doff[k], (size_t)(doff[k + 1] - doff[k]));
         }
-        offs[(size_t)i + 1] = (int32_t)pos;
-      }
-      raw_src = expanded.data();
-      raw_len = total;
-    } else {
-      if (a->n_buffers < 3 || !a->buffers[1]) fail(PRISM_GPU_EINVAL, "string column " + f.name + " has no offsets");
-      const int32_t* so = (const int32_t*)a->buffers[1] + a->offset;
-      const uint8_t* sb = (const uint8_t*)a->buffers[2];
-      int32_t base = so[0];
-      for (int64_t i = 0; i <= n; ++i) offs[(size_t)i] = so[i] - base;
-      raw_src = sb ? sb + base : nullptr;
-      raw_len = (size_t)(so[n] - base);
-      if (dict.alive) {
-        for (int64_t i = 0; i < n; ++i) {
-          bool valid = !vbits || bit_at(vbits, a->offset + i);
-          codes[(size_t)i] = valid ? dict.id_of((const char*)sb + so[i], (size_t)(so[i + 1] - so[i])) : 0;
-          if (dict.values.size() > kMaxDictValues) break;
+        if (codes_only) {
+          // a streaming chunk whose input is dictionary encoded: the codes are all the kernels
+          // need (no per-row expansion of the strings on the host)
+          for (int64_t i = 0; i < nb; ++i) {
+            const bool valid = !vbits || bit_at(vbits, a->offset + i);
+            const int32_t k = valid ? idx[i] : 0;
+            if (valid && (k < 0 || k >= d->length)) fail(PRISM_GPU_EINVAL, "dictionary index out of range in " + f.name);
+            codes[(size_t)(row0 + i)] = valid ? remap[(size_t)k] : 0u;
+          }
+          row0 += nb;
+          continue;
         }
+        expanded.emplace_back();
+        std::vector<uint8_t>& ex = expanded.back();
+        for (int64_t i = 0; i < nb; ++i) {
+          const bool valid = !vbits || bit_at(vbits, a->offset + i);
+          if (valid) {
+            const int32_t k = idx[i];
+            if (k < 0 || k >= d->length) fail(PRISM_GPU_EINVAL, "dictionary index out of range in " + f.name);
+            ex.insert(ex.end(), dbytes + doff[k], dbytes + doff[k + 1]);
+            if (dict.alive) codes[(size_t)(row0 + i)] = remap[(size_t)k];
+          } else if (dict.alive) {
+            codes[(size_t)(row0 + i)] = 0;
+          }
+          if (total + ex.size() > 0x7fffffffull) fail(PRISM_GPU_EUNSUPPORTED, "string data of one chunk exceeds 2 GiB");
+          offs[(size_t)(row0 + i) + 1] = (int32_t)(total + ex.size());
+        }
+        total += ex.size();
+        pieces.push_back({ex.data(), ex.size()});
+      } else {
+        if (a->n_buffers < 3 || !a->buffers[1]) fail(PRISM_GPU_EINVAL, "string column " + f.name + " has no offsets");
+        const int32_t* so = (const int32_t*)a->buffers[1] + a->offset;
+        const uint8_t* sb = (const uint8_t*)a->buffers[2];
+        const int32_t base = so[0];
+        const uint64_t len = (uint64_t)(so[nb] - base);
+        if (total + len > 0x7fffffffull) fail(PRISM_GPU_EUNSUPPORTED, "string data of one chunk exceeds 2 GiB");
+        for (int64_t i = 1; i <= nb; ++i) offs[(size_t)(row0 + i)] = (int32_t)(total + (uint64_t)(so[i] - base));
+        if (dict.alive) {
+          for (int64_t i = 0; i < nb; ++i) {
+            const bool valid = !vbits || bit_at(vbits, a->offset + i);
+            codes[(size_t)(row0 + i)] = valid ? dict.id_of((const char*)sb + so[i], (size_t)(so[i + 1] - so[i])) : 0;
+            if (dict.values.size() > kMaxDictValues) break;
+          }
+        }
+        if (len) pieces.push_back({sb + base, (size_t)len});
+        total += len;
       }
+      row0 += nb;
     }
     if (dict.alive && dict.values.size() > kMaxDictValues) {
       // too many distinct values: this column keeps only its raw form from now on
@@ -238,31 +372,46 @@ void table_append(prism_gpu_table* t, uint32_t partition_id, ArrowArray* batch, 
       dict.ids.clear();
       dict.values.clear();
       for (auto& old : t->chunks) {
-        if (old.cols[ci].codes) { (void)hipFree(old.cols[ci].codes); old.cols[ci].codes = nullptr; }
+        dev_free(t, old.cols[ci].codes);
+        old.cols[ci].codes = nullptr;
       }
     }
-    dc.values = dev_alloc(offs.size() * 4);
-    stage_copy(ctx, dc.values, offs.data(), offs.size() * 4);
-    dc.bytes = (uint8_t*)dev_alloc(raw_len);
-    dc.n_bytes = raw_len;
-    if (raw_len) stage_copy(ctx, dc.bytes, raw_src, raw_len);
+    if (codes_only && !dict.alive) fail(PRISM_GPU_EUNSUPPORTED, "dictionary-encoded column " + f.name + " has more than " + std::to_string(kMaxDictValues) + " distinct values");
+    if (!codes_only) {
+      dc.values = dev_alloc(t, offs.size() * 4);
+      w.begin(dc.values);
+      w.write(offs.data(), offs.size() * 4);
+      dc.bytes = (uint8_t*)dev_alloc(t, (size_t)total);
+      dc.n_bytes = total;
+      w.begin(dc.bytes);
+      for (const Piece& pc : pieces) w.write(pc.p, pc.n);
+    }
     if (dict.alive) {
-      dc.codes = (uint32_t*)dev_alloc((size_t)n * 4);
-      stage_copy(ctx, dc.codes, codes.data(), (size_t)n * 4);
+      dc.codes = (uint32_t*)dev_alloc(t, (size_t)n * 4);
+      w.begin(dc.codes);
+      w.write(codes.data(), (size_t)n * 4);
+      w.flush();
       launch_col_stats(ctx, dc.codes, dc.validity, 4, true, (uint64_t)n, &ch.d_stats[ci], ctx->copy_stream);
     } else {
       // no codes: the offsets stand in as values so that the NULL count is still recorded
+      w.flush();
       launch_col_stats(ctx, dc.values, dc.validity, 4, true, (uint64_t)n, &ch.d_stats[ci], ctx->copy_stream);
     }
   }
-  PRISM_HIP(hipStreamSynchronize(ctx->copy_stream));
+  w.flush();
+  // The bytes are in pinned memory or on their way: the batches can go.  The copies are
+  // awaited where the chunk's statistics are read (table_sync_stats), before any scan.
   {
     std::lock_guard<std::mutex> gs(ctx->mu);
-    ctx->stage_busy[0] = ctx->stage_busy[1] = false;
     ctx->stats.staging_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
   guard.armed = false;
   t->chunks.push_back(std::move(ch));
+}
+
+void table_append(prism_gpu_table* t, uint32_t partition_id, ArrowArray* batch, bool take) {
+  ArrowArray* one[1] = {batch};
+  table_append_batches(t, partition_id, one, 1, take);
 }
 
 void table_synth(prism_gpu_table* t, uint32_t partition_id, uint64_t seed, uint64_t first_row, uint64_t n_rows,
@@ -277,7 +426,13 @@ void table_synth(prism_gpu_table* t, uint32_t partition_id, uint64_t seed, uint6
   ch.partition_id = partition_id;
   ch.rows = n_rows;
   ch.cols.resize(t->fields.size());
-  init_stats(ctx, ch, t->fields.size());
+  struct ChunkGuard {
+    prism_gpu_table* t;
+    Chunk* ch;
+    bool armed = true;
+    ~ChunkGuard() { if (armed) free_chunk_memory(t, *ch); }
+  } guard{t, &ch};
+  init_stats(t, ch, t->fields.size());
   PRISM_HIP(hipStreamSynchronize(ctx->copy_stream));
   std::vector<void*> cdfs;
   for (uint32_t i = 0; i < n_cols; ++i) {
@@ -302,14 +457,10 @@ void table_synth(prism_gpu_table* t, uint32_t partition_id, uint64_t seed, uint6
         if (pos > 0x7fffffffull) fail(PRISM_GPU_EUNSUPPORTED, "string data of one partition exceeds 2 GiB; use more partitions");
         offs[(size_t)r + 1] = (int32_t)pos;
       }
-      dc.values = dev_alloc(offs.size() * 4);
+      dc.values = dev_alloc(t, offs.size() * 4);
       stage_copy(ctx, dc.values, offs.data(), offs.size() * 4);
       PRISM_HIP(hipStreamSynchronize(ctx->copy_stream));
-      {
-        std::lock_guard<std::mutex> gs(ctx->mu);
-        ctx->stage_busy[0] = ctx->stage_busy[1] = false;
-      }
-      dc.bytes = (uint8_t*)dev_alloc(pos);
+      dc.bytes = (uint8_t*)dev_alloc(t, pos);
       dc.n_bytes = pos;
       launch_synth_url(ctx, (const int32_t*)dc.values, dc.bytes, n_rows, first_row, sc.p[0], sc.p[1], key);
       launch_col_stats(ctx, dc.values, nullptr, 4, true, n_rows, &ch.d_stats[sc.column], ctx->stream);
@@ -328,7 +479,7 @@ void table_synth(prism_gpu_table* t, uint32_t partition_id, uint64_t seed, uint6
     }
     if (sc.kind == PRISM_SYNTH_CATEGORICAL) {
       if (!sc.cdf || sc.cdf_len == 0) fail(PRISM_GPU_EINVAL, "CATEGORICAL generator needs a cdf table");
-      void* dcdf = dev_alloc(sc.cdf_len * 4);
+      void* dcdf = dev_alloc(t, sc.cdf_len * 4);
       cdfs.push_back(dcdf);
       PRISM_HIP(hipMemcpy(dcdf, sc.cdf, sc.cdf_len * 4, hipMemcpyHostToDevice));
       d.cdf = (const uint32_t*)dcdf;
@@ -337,7 +488,7 @@ void table_synth(prism_gpu_table* t, uint32_t partition_id, uint64_t seed, uint6
     if (sc.kind == PRISM_SYNTH_LOGUNIFORM_ID && (sc.p[0] < 1 || sc.p[0] > 62))
       fail(PRISM_GPU_EINVAL, "LOGUNIFORM_ID needs 1 <= B <= 62");
     d.column_key = prism_synth_column_key(seed, (uint32_t)sc.column);
-    void* dst = dev_alloc((size_t)n_rows * d.width);
+    void* dst = dev_alloc(t, (size_t)n_rows * d.width);
     d.dst = dst;
     if (f.is_string) dc.codes = (uint32_t*)dst; else dc.values = dst;
     launch_synth(ctx, d, first_row, n_rows, total_rows);
@@ -345,16 +496,20 @@ void table_synth(prism_gpu_table* t, uint32_t partition_id, uint64_t seed, uint6
     launch_col_stats(ctx, dst, nullptr, d.width, f.is_string || f.is_unsigned, n_rows, &ch.d_stats[sc.column], ctx->stream);
   }
   PRISM_HIP(hipStreamSynchronize(ctx->stream));
-  for (void* p : cdfs) (void)hipFree(p);
+  for (void* p : cdfs) dev_free(t, p);
   for (size_t ci = 0; ci < t->fields.size(); ++ci)
     if (!ch.cols[ci].values && !ch.cols[ci].codes) fail(PRISM_GPU_EINVAL, "column " + t->fields[ci].name + " has no generator");
+  guard.armed = false;
   t->chunks.push_back(std::move(ch));
 }
 
 void table_sync_stats(prism_gpu_table* t) {
   std::lock_guard<std::mutex> g(t->mu);
+  bool waited = false;
   for (auto& ch : t->chunks) {
     if (ch.stats_ready) continue;
+    // the chunk's copies and statistics kernels run on the staging stream
+    if (!waited) { PRISM_HIP(hipStreamSynchronize(t->ctx->copy_stream)); waited = true; }
     PRISM_HIP(hipMemcpy(ch.stats.data(), ch.d_stats, ch.stats.size() * sizeof(ColStats), hipMemcpyDeviceToHost));
     ch.stats_ready = true;
   }

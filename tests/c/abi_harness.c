@@ -8,6 +8,7 @@
  *   exit code 3          no GPU: prism_gpu_init refused loudly (there is no CPU fallback)
  *   exit code 1          a check failed (message on stderr)
  */
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -91,6 +92,143 @@ static void check_result(const struct ArrowArray* out, const Expect* want, int n
       CHECK(mn[i] == e->min, "%s: MIN of %lld", what, (long long)k[i]);
     }
   }
+}
+
+/* ---- concurrent streaming partitions ------------------------------------------------
+ * DataFusion polls execute(partition) of every partition on its own worker thread
+ * (src/prism-query/src/main.rs:45) and hands over 8192-row batches.  Four threads, one
+ * prism_gpu_part each on a shared plan; every batch owns its buffers and frees them when the
+ * library releases it (the library keeps batches until a chunk of them is staged). */
+#define T_THREADS 4
+#define T_ROWS_PER_THREAD 2300000 /* more than two chunks of 2^20 rows */
+#define T_BATCH 8192
+
+static int64_t big_k(int64_t i) { return (int64_t)(((uint64_t)i * 2654435761ull >> 7) % N_KEYS); }
+static int64_t big_v(int64_t i) { return (int64_t)(((uint64_t)i * 40503ull + 17) % 2000) - 1000; }
+static int big_valid(int64_t i) { return i % 13 != 5; }
+
+typedef struct HeapBatch {
+  struct ArrowArray top, cols[2];
+  struct ArrowArray* children[2];
+  const void* top_buffers[1];
+  const void* k_buffers[2];
+  const void* v_buffers[2];
+  int64_t* k;
+  int64_t* v;
+  uint8_t* valid;
+} HeapBatch;
+
+static void release_child(struct ArrowArray* a) { a->release = NULL; }
+static void release_heap_batch(struct ArrowArray* a) {
+  HeapBatch* b = (HeapBatch*)a->private_data;
+  a->release = NULL;
+  free(b->k); free(b->v); free(b->valid); free(b);
+}
+
+/* rows [lo, hi) of the generated table as a batch the consumer owns */
+static struct ArrowArray* heap_batch(int64_t lo, int64_t hi) {
+  HeapBatch* b = (HeapBatch*)calloc(1, sizeof(HeapBatch));
+  int64_t n = hi - lo, nulls = 0;
+  b->k = (int64_t*)malloc((size_t)n * 8);
+  b->v = (int64_t*)malloc((size_t)n * 8);
+  b->valid = (uint8_t*)calloc((size_t)(n + 7) / 8, 1);
+  for (int64_t i = 0; i < n; ++i) {
+    b->k[i] = big_k(lo + i);
+    b->v[i] = big_v(lo + i);
+    if (big_valid(lo + i)) b->valid[i >> 3] |= (uint8_t)(1u << (i & 7)); else ++nulls;
+  }
+  b->k_buffers[1] = b->k;
+  b->v_buffers[0] = b->valid;
+  b->v_buffers[1] = b->v;
+  for (int c = 0; c < 2; ++c) {
+    b->cols[c].length = n;
+    b->cols[c].n_buffers = 2;
+    b->cols[c].release = release_child;
+    b->children[c] = &b->cols[c];
+  }
+  b->cols[0].buffers = b->k_buffers;
+  b->cols[1].buffers = b->v_buffers;
+  b->cols[1].null_count = nulls;
+  b->top.length = n;
+  b->top.n_buffers = 1;
+  b->top.buffers = b->top_buffers;
+  b->top.n_children = 2;
+  b->top.children = b->children;
+  b->top.release = release_heap_batch;
+  b->top.private_data = b;
+  return &b->top;
+}
+
+typedef struct ThreadArg {
+  prism_gpu_plan* plan;
+  uint32_t partition;
+  int64_t lo, hi;
+  struct ArrowArray state;
+  int rc;
+  char err[256];
+} ThreadArg;
+
+static void* stream_partition(void* p) {
+  ThreadArg* a = (ThreadArg*)p;
+  prism_gpu_part* part = NULL;
+  a->rc = prism_gpu_partition_open(a->plan, a->partition, &part);
+  for (int64_t r = a->lo; a->rc == 0 && r < a->hi; r += T_BATCH) {
+    int64_t z = r + T_BATCH < a->hi ? r + T_BATCH : a->hi;
+    a->rc = prism_gpu_push_batch(part, heap_batch(r, z));
+  }
+  if (a->rc == 0) a->rc = prism_gpu_finish(part, &a->state);
+  if (a->rc != 0) snprintf(a->err, sizeof(a->err), "%s", prism_gpu_last_error()); /* the message is per thread */
+  prism_gpu_part_free(part);
+  return NULL;
+}
+
+static void check_concurrent_streams(prism_gpu_plan* pplan) {
+  static Expect want[N_KEYS];
+  memset(want, 0, sizeof(want));
+  const int64_t total = (int64_t)T_THREADS * T_ROWS_PER_THREAD;
+  for (int64_t i = 0; i < total; ++i) {
+    int valid = big_valid(i);
+    int64_t v = big_v(i);
+    if (valid && v < -500) continue;
+    Expect* e = &want[big_k(i)];
+    e->count += 1;
+    if (valid) { e->sum += v; e->min = (!e->any || v < e->min) ? v : e->min; e->any = 1; }
+  }
+  int n_want = 0;
+  for (int k = 0; k < N_KEYS; ++k) n_want += want[k].count > 0;
+
+  pthread_t th[T_THREADS];
+  static ThreadArg args[T_THREADS];
+  struct ArrowArray* ptrs[T_THREADS + 1];
+  for (int t = 0; t < T_THREADS; ++t) {
+    memset(&args[t], 0, sizeof(args[t]));
+    args[t].plan = pplan;
+    args[t].partition = (uint32_t)t;
+    args[t].lo = (int64_t)t * T_ROWS_PER_THREAD;
+    args[t].hi = (int64_t)(t + 1) * T_ROWS_PER_THREAD;
+    CHECK(pthread_create(&th[t], NULL, stream_partition, &args[t]) == 0, "pthread_create");
+  }
+  for (int t = 0; t < T_THREADS; ++t) {
+    pthread_join(th[t], NULL);
+    CHECK(args[t].rc == 0, "streaming thread %d: rc %d: %s", t, args[t].rc, args[t].err);
+    ptrs[t] = &args[t].state;
+  }
+  struct ArrowArray out;
+  CHECK(prism_gpu_merge(pplan, ptrs, T_THREADS, &out) == 0, "merge of concurrent streams");
+  check_result(&out, want, n_want, "4 concurrent streaming partitions");
+  out.release(&out);
+  /* the same rows through one part on this thread give the same answer */
+  ThreadArg one;
+  memset(&one, 0, sizeof(one));
+  one.plan = pplan; one.partition = 0; one.lo = 0; one.hi = total;
+  stream_partition(&one);
+  CHECK(one.rc == 0, "single stream: rc %d: %s", one.rc, one.err);
+  ptrs[0] = &one.state;
+  CHECK(prism_gpu_merge(pplan, ptrs, 1, &out) == 0, "merge of the single stream");
+  check_result(&out, want, n_want, "one streaming partition over all rows");
+  out.release(&out);
+  one.state.release(&one.state);
+  for (int t = 0; t < T_THREADS; ++t) args[t].state.release(&args[t].state);
 }
 
 int main(void) {
@@ -200,11 +338,11 @@ int main(void) {
     CHECK(prism_gpu_partition_open(pplan, p, &part) == 0, "partition_open");
     /* feed the partition in three pushes */
     int64_t lo = p == 0 ? 0 : split, hi = p == 0 ? split : N_ROWS;
+    Batch b[3]; /* a moved array keeps pointing at its children: they live until finish */
     for (int s = 0; s < 3; ++s) {
-      Batch b;
       int64_t a = lo + (hi - lo) * s / 3, z = lo + (hi - lo) * (s + 1) / 3;
-      make_batch(&b, a, z);
-      CHECK(prism_gpu_push_batch(part, &b.top) == 0, "push_batch");
+      make_batch(&b[s], a, z);
+      CHECK(prism_gpu_push_batch(part, &b[s].top) == 0, "push_batch");
     }
     CHECK(prism_gpu_finish(part, &states[p]) == 0, "finish");
     prism_gpu_part_free(part);
@@ -236,7 +374,10 @@ int main(void) {
     prism_gpu_state_free(s1);
   }
 
-  /* 4. errors come back as codes with a message, never as aborts */
+  /* 4. four threads streaming a partition each, 8192 rows at a time */
+  check_concurrent_streams(pplan);
+
+  /* 5. errors come back as codes with a message, never as aborts */
   prism_gpu_plan* bad = NULL;
   ex[0].column = 7; /* no such column */
   desc.mode = PRISM_MODE_SINGLE;
