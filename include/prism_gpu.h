@@ -402,6 +402,73 @@ void prism_gpu_state_free(prism_gpu_state* state);
 int prism_gpu_table_dictionary_digest(prism_gpu_table* table, int32_t column,
                                       uint64_t* digest, uint32_t* n_values);
 
+/* ---- the exchange inside the library: one call per rank -------------------
+ * The same merge as above, with the collectives issued by the library: the ranks (one
+ * process per GPU) join a communicator, and prism_gpu_execute_sharded runs
+ *
+ *   scan statistics of the rank's partitions  -> one small all-gather (the union's
+ *                                                 min / max / NULL counts, dictionary digests)
+ *   scan -> filter -> GROUP BY of the partitions (keys packed from the agreed statistics)
+ *   small key space (dense table):  reduce of the accumulator arrays onto `root`, in place
+ *                                   in HBM, one collective per run of slots that merge alike
+ *   large key space (hash table):   rows dealt to owner ranks by a hash of the packed key
+ *                                   (HIP kernels: count per owner, scatter), all-to-all,
+ *                                   merge at the owner, the owner's groups -- cut to the
+ *                                   leading ones when the plan has ORDER BY .. LIMIT -- sent
+ *                                   to `root`, which merges the disjoint slices
+ *   final rows on `root`            (ORDER BY / LIMIT applied)
+ *
+ * which is RepartitionExec(Hash) + AggregateExec(FinalPartitioned) + the coalescing of the
+ * output partitions in DataFusion's plan for the same query.  Every rank must make the
+ * same sequence of calls with the same plan.  Plans the device-resident state does not
+ * cover return PRISM_GPU_EUNSUPPORTED on every rank before any collective is issued.
+ *
+ * Two transports.  prism_gpu_comm_init joins an RCCL communicator (xGMI between the GPUs of
+ * a node; librccl is loaded on first use): rank 0 calls prism_gpu_comm_unique_id and hands
+ * the 128 bytes to the other ranks out of band.  prism_gpu_comm_init_callbacks runs the
+ * same exchange over three functions of the caller, on page-locked host copies of the
+ * buffers: for hosts with a fabric of their own, and for tests in which several ranks
+ * share one GPU (which RCCL does not allow).  Failures of the transport are reported as
+ * PRISM_GPU_ERCCL. */
+typedef struct prism_gpu_comm prism_gpu_comm;
+#define PRISM_GPU_COMM_ID_BYTES 128
+
+enum prism_gpu_reduce_op { PRISM_REDUCE_SUM = 0, PRISM_REDUCE_MIN = 1, PRISM_REDUCE_MAX = 2 };
+enum prism_gpu_reduce_type { PRISM_REDUCE_I64 = 0, PRISM_REDUCE_F64 = 1 };
+
+typedef struct prism_gpu_transport {
+  void* user;
+  /* Every rank contributes `bytes` bytes; `all` receives world * bytes, in rank order. */
+  int (*allgather)(void* user, const void* mine, void* all, size_t bytes);
+  /* Element-wise reduction of n 8-byte values (prism_gpu_reduce_type) with
+   * prism_gpu_reduce_op, in place; the result is needed on `root` only. */
+  int (*reduce)(void* user, void* buf, size_t n, int type, int op, int root);
+  /* 8-byte words: rank r receives send_counts[r] words of this rank's `send` (runs in rank
+   * order) and this rank receives recv_counts[s] words from rank s into `recv` (runs in
+   * rank order). */
+  int (*alltoallv)(void* user, const uint64_t* send, const uint64_t* send_counts,
+                   uint64_t* recv, const uint64_t* recv_counts);
+  /* Non-zero return values fail the call in progress with PRISM_GPU_ERCCL. */
+} prism_gpu_transport;
+
+typedef struct prism_gpu_comm_stats {
+  uint64_t collectives;   /* issued by this rank */
+  uint64_t bytes_sent;    /* payload this rank handed to the transport */
+  double exchange_ms;     /* host wall clock spent between the aggregate and the final rows */
+} prism_gpu_comm_stats;
+
+int prism_gpu_comm_unique_id(void* id_out /* PRISM_GPU_COMM_ID_BYTES */);
+int prism_gpu_comm_init(prism_gpu_ctx* ctx, const void* unique_id, int rank, int world,
+                        prism_gpu_comm** out);
+int prism_gpu_comm_init_callbacks(prism_gpu_ctx* ctx, const prism_gpu_transport* transport,
+                                  int rank, int world, prism_gpu_comm** out);
+void prism_gpu_comm_free(prism_gpu_comm* comm);
+/* *has_result = 1 on `root` (out is a final RecordBatch the caller releases), 0 elsewhere. */
+int prism_gpu_execute_sharded(prism_gpu_comm* comm, prism_gpu_plan* plan, prism_gpu_table* table,
+                              const uint32_t* partition_ids, size_t n_partitions, int root,
+                              struct ArrowArray* out, int* has_result);
+int prism_gpu_comm_get_stats(prism_gpu_comm* comm, prism_gpu_comm_stats* out);
+
 /* ---- measurement ---------------------------------------------------------
  * Per-kernel device time measured with HIP events on the stream the kernels run
  * on, accumulated since the last reset, for roofline reporting.  Profiling is

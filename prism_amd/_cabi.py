@@ -146,6 +146,33 @@ class StateInfo(C.Structure):
     ]
 
 
+REDUCE_SUM, REDUCE_MIN, REDUCE_MAX = 0, 1, 2
+REDUCE_I64, REDUCE_F64 = 0, 1
+
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int)
+ALLTOALLV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                           C.POINTER(C.c_uint64))
+
+
+class Transport(C.Structure):
+    """prism_gpu_transport"""
+    _fields_ = [
+        ("user", C.c_void_p),
+        ("allgather", ALLGATHER_FN),
+        ("reduce", REDUCE_FN),
+        ("alltoallv", ALLTOALLV_FN),
+    ]
+
+
+class CommStats(C.Structure):
+    _fields_ = [
+        ("collectives", C.c_uint64),
+        ("bytes_sent", C.c_uint64),
+        ("exchange_ms", C.c_double),
+    ]
+
+
 class KernelStat(C.Structure):
     _fields_ = [
         ("name", C.c_char * 48),

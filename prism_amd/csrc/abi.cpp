@@ -283,17 +283,50 @@ int prism_gpu_table_dictionary_digest(prism_gpu_table* table, int32_t column, ui
   return guarded([&] {
     require(table && digest && n_values, "null argument");
     require(column >= 0 && (size_t)column < table->fields.size(), "column out of range");
-    std::lock_guard<std::mutex> g(table->mu);
-    const prism::ColumnDict& d = table->dicts[column];
-    uint64_t h = 0xcbf29ce484222325ull;
-    auto mix = [&](uint8_t b) { h = (h ^ b) * 0x100000001b3ull; };
-    for (const std::string& v : d.values) {
-      for (unsigned char c : v) mix(c);
-      mix(0xff);  // separator: no UTF-8 byte
-    }
-    if (!d.alive) h = ~h;
-    *digest = h;
-    *n_values = (uint32_t)d.values.size();
+    prism::table_dictionary_digest(table, column, digest, n_values);
+  });
+}
+
+// ---- collectives ----
+
+int prism_gpu_comm_unique_id(void* id_out) {
+  return guarded([&] {
+    require(id_out != nullptr, "null argument");
+    prism::comm_unique_id(id_out);
+  });
+}
+
+int prism_gpu_comm_init(prism_gpu_ctx* ctx, const void* unique_id, int rank, int world, prism_gpu_comm** out) {
+  return guarded([&] {
+    require(ctx && unique_id && out, "null argument");
+    *out = prism::comm_create_rccl(ctx, unique_id, rank, world);
+  });
+}
+
+int prism_gpu_comm_init_callbacks(prism_gpu_ctx* ctx, const prism_gpu_transport* transport, int rank, int world,
+                                  prism_gpu_comm** out) {
+  return guarded([&] {
+    require(ctx && transport && out, "null argument");
+    *out = prism::comm_create_callbacks(ctx, transport, rank, world);
+  });
+}
+
+void prism_gpu_comm_free(prism_gpu_comm* comm) { prism::comm_destroy(comm); }
+
+int prism_gpu_execute_sharded(prism_gpu_comm* comm, prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids,
+                              size_t n_partitions, int root, struct ArrowArray* out, int* has_result) {
+  return guarded([&] {
+    require(comm && plan && table && out && has_result, "null argument");
+    require(plan->ctx != nullptr, "the plan was created without a context: it can be inspected, not run");
+    *has_result = 0;
+    *has_result = prism::execute_sharded(comm, plan, table, partition_ids, n_partitions, root, out);
+  });
+}
+
+int prism_gpu_comm_get_stats(prism_gpu_comm* comm, prism_gpu_comm_stats* out) {
+  return guarded([&] {
+    require(comm && out, "null argument");
+    prism::comm_stats(comm, out);
   });
 }
 

@@ -1,0 +1,400 @@
+// The exchange between the GPUs of a node, inside the library: a communicator per rank
+// (RCCL over xGMI, or three callbacks of the caller), and the sharded form of a GROUP BY
+// query on top of it (prism_gpu_execute_sharded).
+//
+// The reference has no multi-GPU code; what it has is DataFusion's plan shape for a
+// partitioned aggregate: AggregateExec(Partial) per partition, RepartitionExec(Hash) on the
+// group keys, AggregateExec(FinalPartitioned) per hash partition, then the output
+// partitions coalesced (every partition of src/prism-query/src/providers/
+// table_provider.rs:94-109 is such a unit).  Here a rank's partitions are aggregated into
+// one group table in HBM, and the tables meet without leaving device memory.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <chrono>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "context.hpp"
+#include "engine.hpp"
+#include "kernels.hpp"
+
+namespace prism {
+
+namespace {
+
+// librccl is loaded when the first communicator is made: the library itself has no link
+// dependency on it, and a process that already holds a copy (PyTorch ships one under the
+// same soname) shares that one.
+struct Rccl {
+  void* handle = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclReduce) Reduce = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+};
+
+Rccl& rccl() {
+  static Rccl r;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> g(mu);
+  if (r.handle) return r;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* h = nullptr;
+  std::string why;
+  for (const char* n : names) {
+    h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (h) break;
+    const char* e = dlerror();
+    why += std::string(why.empty() ? "" : "; ") + (e ? e : n);
+  }
+  if (!h) fail(PRISM_GPU_ERCCL, "librccl could not be loaded: " + why);
+  auto sym = [&](const char* name) {
+    void* p = dlsym(h, name);
+    if (!p) fail(PRISM_GPU_ERCCL, std::string("librccl has no ") + name);
+    return p;
+  };
+  r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+  r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+  r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+  r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+  r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+  r.Reduce = (decltype(r.Reduce))sym("ncclReduce");
+  r.Send = (decltype(r.Send))sym("ncclSend");
+  r.Recv = (decltype(r.Recv))sym("ncclRecv");
+  r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+  r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+  r.handle = h;
+  return r;
+}
+
+#define PRISM_RCCL(expr)                                                                                         \
+  do {                                                                                                           \
+    ncclResult_t _r = (expr);                                                                                    \
+    if (_r != ncclSuccess)                                                                                       \
+      ::prism::fail(PRISM_GPU_ERCCL, std::string(#expr) + " failed: " + rccl().GetErrorString(_r) + " (" + __FILE__ + ":" + \
+                                         std::to_string(__LINE__) + ")");                                       \
+  } while (0)
+
+static_assert(sizeof(ncclUniqueId) == PRISM_GPU_COMM_ID_BYTES, "the unique id is handed around as 128 bytes");
+
+}  // namespace
+
+}  // namespace prism
+
+struct prism_gpu_comm {
+  prism_gpu_ctx* ctx = nullptr;
+  int rank = 0, world = 1;
+  ncclComm_t nccl = nullptr;
+  bool callbacks = false;
+  prism_gpu_transport cb{};
+  std::mutex mu;
+  prism_gpu_comm_stats stats{};
+};
+
+namespace prism {
+
+namespace {
+
+// Page-locked host block for the callbacks transport (device buffers travel as host copies).
+struct Pinned {
+  void* p = nullptr;
+  explicit Pinned(size_t bytes) { PRISM_HIP(hipHostMalloc(&p, bytes ? bytes : 8, hipHostMallocDefault)); }
+  Pinned(const Pinned&) = delete;
+  Pinned& operator=(const Pinned&) = delete;
+  ~Pinned() { (void)hipHostFree(p); }
+  template <class T> T* as() const { return (T*)p; }
+};
+
+void account(prism_gpu_comm* c, uint64_t collectives, uint64_t bytes) {
+  std::lock_guard<std::mutex> g(c->mu);
+  c->stats.collectives += collectives;
+  c->stats.bytes_sent += bytes;
+}
+
+void cb_check(int rc, const char* what) {
+  if (rc != 0) fail(PRISM_GPU_ERCCL, std::string("the transport's ") + what + " returned " + std::to_string(rc));
+}
+
+// Small vectors of 8-byte values, one per rank, in host memory.
+void allgather_small(prism_gpu_comm* c, const int64_t* mine, size_t n, int64_t* all) {
+  account(c, 1, n * 8);
+  if (c->world == 1) {
+    std::memcpy(all, mine, n * 8);
+    return;
+  }
+  if (c->callbacks) {
+    cb_check(c->cb.allgather(c->cb.user, mine, all, n * 8), "allgather");
+    return;
+  }
+  prism_gpu_ctx* ctx = c->ctx;
+  Scratch d(ctx, n * 8 * (size_t)c->world);
+  PRISM_HIP(hipMemcpyAsync(d.as<int64_t>() + n * (size_t)c->rank, mine, n * 8, hipMemcpyHostToDevice, ctx->stream));
+  PRISM_RCCL(rccl().AllGather(d.as<int64_t>() + n * (size_t)c->rank, d.p, n, ncclInt64, c->nccl, ctx->stream));
+  PRISM_HIP(hipMemcpyAsync(all, d.p, n * 8 * (size_t)c->world, hipMemcpyDeviceToHost, ctx->stream));
+  PRISM_HIP(hipStreamSynchronize(ctx->stream));
+}
+
+// In-place reduction of a device array onto `root`.
+void reduce_device(prism_gpu_comm* c, void* dev, size_t n, int type, int op, int root) {
+  if (n == 0 || c->world == 1) return;
+  account(c, 1, n * 8);
+  prism_gpu_ctx* ctx = c->ctx;
+  if (c->callbacks) {
+    Pinned host(n * 8);
+    PRISM_HIP(hipMemcpyAsync(host.p, dev, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PRISM_HIP(hipStreamSynchronize(ctx->stream));
+    cb_check(c->cb.reduce(c->cb.user, host.p, n, type, op, root), "reduce");
+    if (c->rank == root) {
+      PRISM_HIP(hipMemcpyAsync(dev, host.p, n * 8, hipMemcpyHostToDevice, ctx->stream));
+      PRISM_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return;
+  }
+  const ncclRedOp_t rop = op == PRISM_REDUCE_MIN ? ncclMin : op == PRISM_REDUCE_MAX ? ncclMax : ncclSum;
+  PRISM_RCCL(rccl().Reduce(dev, dev, n, type == PRISM_REDUCE_F64 ? ncclFloat64 : ncclInt64, rop, root, c->nccl, ctx->stream));
+}
+
+// Columns of 8-byte words between all ranks.  Column k of the send block starts at
+// send + k * send_stride and holds, in rank order, send_counts[r] words for rank r; column
+// k of the receive block starts at recv + k * recv_stride and receives recv_counts[s] words
+// from rank s, in rank order.
+void alltoallv_columns(prism_gpu_comm* c, int n_cols, const uint64_t* send, uint64_t send_stride,
+                       const std::vector<uint64_t>& send_counts, uint64_t* recv, uint64_t recv_stride,
+                       const std::vector<uint64_t>& recv_counts) {
+  prism_gpu_ctx* ctx = c->ctx;
+  const int world = c->world;
+  uint64_t send_total = 0, recv_total = 0;
+  for (int r = 0; r < world; ++r) { send_total += send_counts[r]; recv_total += recv_counts[r]; }
+  account(c, (uint64_t)n_cols, (send_total - send_counts[c->rank]) * 8 * (uint64_t)n_cols);
+  if (c->callbacks) {
+    Pinned hs(send_total * 8), hr(recv_total * 8);
+    for (int k = 0; k < n_cols; ++k) {
+      if (send_total) PRISM_HIP(hipMemcpyAsync(hs.p, send + (uint64_t)k * send_stride, send_total * 8, hipMemcpyDeviceToHost, ctx->stream));
+      PRISM_HIP(hipStreamSynchronize(ctx->stream));
+      cb_check(c->cb.alltoallv(c->cb.user, hs.as<uint64_t>(), send_counts.data(), hr.as<uint64_t>(), recv_counts.data()), "alltoallv");
+      if (recv_total) PRISM_HIP(hipMemcpyAsync(recv + (uint64_t)k * recv_stride, hr.p, recv_total * 8, hipMemcpyHostToDevice, ctx->stream));
+      PRISM_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return;
+  }
+  // one group: every (column, peer) pair is a send and a receive; the rank's own run is a copy
+  std::vector<uint64_t> soff(world + 1, 0), roff(world + 1, 0);
+  for (int r = 0; r < world; ++r) { soff[r + 1] = soff[r] + send_counts[r]; roff[r + 1] = roff[r] + recv_counts[r]; }
+  PRISM_RCCL(rccl().GroupStart());
+  for (int k = 0; k < n_cols; ++k) {
+    for (int r = 0; r < world; ++r) {
+      if (r == c->rank) continue;
+      if (send_counts[r])
+        PRISM_RCCL(rccl().Send(send + (uint64_t)k * send_stride + soff[r], send_counts[r], ncclUint64, r, c->nccl, ctx->stream));
+      if (recv_counts[r])
+        PRISM_RCCL(rccl().Recv(recv + (uint64_t)k * recv_stride + roff[r], recv_counts[r], ncclUint64, r, c->nccl, ctx->stream));
+    }
+  }
+  PRISM_RCCL(rccl().GroupEnd());
+  if (send_counts[c->rank])
+    for (int k = 0; k < n_cols; ++k)
+      PRISM_HIP(hipMemcpyAsync(recv + (uint64_t)k * recv_stride + roff[c->rank], send + (uint64_t)k * send_stride + soff[c->rank],
+                               send_counts[c->rank] * 8, hipMemcpyDeviceToDevice, ctx->stream));
+}
+
+struct StateGuard {
+  prism_gpu_state* st = nullptr;
+  ~StateGuard() { state_free(st); }
+};
+
+int reduce_of(int slot_op) { return slot_op == kSlotMin ? PRISM_REDUCE_MIN : slot_op == kSlotMax ? PRISM_REDUCE_MAX : PRISM_REDUCE_SUM; }
+
+}  // namespace
+
+void comm_unique_id(void* out) {
+  ncclUniqueId id;
+  PRISM_RCCL(rccl().GetUniqueId(&id));
+  std::memcpy(out, &id, sizeof(id));
+}
+
+prism_gpu_comm* comm_create_rccl(prism_gpu_ctx* ctx, const void* unique_id, int rank, int world) {
+  if (world < 1 || world > 64 || rank < 0 || rank >= world) fail(PRISM_GPU_EINVAL, "rank / world out of range (at most 64 ranks)");
+  bind(ctx);
+  auto c = std::make_unique<prism_gpu_comm>();
+  c->ctx = ctx;
+  c->rank = rank;
+  c->world = world;
+  ncclUniqueId id;
+  std::memcpy(&id, unique_id, sizeof(id));
+  PRISM_RCCL(rccl().CommInitRank(&c->nccl, world, id, rank));
+  return c.release();
+}
+
+prism_gpu_comm* comm_create_callbacks(prism_gpu_ctx* ctx, const prism_gpu_transport* t, int rank, int world) {
+  if (world < 1 || world > 64 || rank < 0 || rank >= world) fail(PRISM_GPU_EINVAL, "rank / world out of range (at most 64 ranks)");
+  if (!t || !t->allgather || !t->reduce || !t->alltoallv) fail(PRISM_GPU_EINVAL, "the transport needs allgather, reduce and alltoallv");
+  auto c = std::make_unique<prism_gpu_comm>();
+  c->ctx = ctx;
+  c->rank = rank;
+  c->world = world;
+  c->callbacks = true;
+  c->cb = *t;
+  return c.release();
+}
+
+void comm_destroy(prism_gpu_comm* c) {
+  if (!c) return;
+  if (c->nccl) {
+    (void)hipSetDevice(c->ctx->device);
+    (void)hipStreamSynchronize(c->ctx->stream);
+    (void)rccl().CommDestroy(c->nccl);
+  }
+  delete c;
+}
+
+void comm_stats(prism_gpu_comm* c, prism_gpu_comm_stats* out) {
+  std::lock_guard<std::mutex> g(c->mu);
+  *out = c->stats;
+}
+
+int execute_sharded(prism_gpu_comm* c, prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids,
+                    size_t n_partitions, int root, ArrowArray* out) {
+  prism_gpu_ctx* ctx = c->ctx;
+  if (plan->ctx != ctx || table->ctx != ctx) fail(PRISM_GPU_EINVAL, "communicator, plan and table belong to different contexts");
+  if (root < 0 || root >= c->world) fail(PRISM_GPU_EINVAL, "root is not a rank of the communicator");
+  // what the device-resident state does not cover is refused before any collective, and for
+  // reasons every rank sees alike (the plan; the key width follows from the agreed statistics)
+  if (plan->keys.empty() || plan->distinct_plan)
+    fail(PRISM_GPU_EUNSUPPORTED, "the sharded form needs a GROUP BY without COUNT(DISTINCT)");
+  if (plan->mode != PRISM_MODE_SINGLE) fail(PRISM_GPU_EINVAL, "the sharded form runs plans in SINGLE mode: it does the merge itself");
+  bind(ctx);
+  const int world = c->world, rank = c->rank;
+  const size_t n_cols = plan->fields.size();
+
+  // ---- 1. the statistics the keys are packed from, agreed with one all-gather ----
+  std::vector<prism_gpu_col_stats> mine(n_cols), agreed(n_cols);
+  scan_stats(plan, table, partition_ids, n_partitions, mine.data());
+  std::vector<int> string_keys;
+  for (const KeyPlan& k : plan->keys)
+    if (plan->fields[k.column].is_string) string_keys.push_back(k.column);
+  const size_t vec_n = n_cols * 3 + string_keys.size();
+  std::vector<int64_t> vec(vec_n), all(vec_n * (size_t)world);
+  for (size_t i = 0; i < n_cols; ++i) {
+    vec[i * 3] = mine[i].min;
+    vec[i * 3 + 1] = mine[i].max;
+    vec[i * 3 + 2] = (int64_t)mine[i].nulls;
+  }
+  for (size_t i = 0; i < string_keys.size(); ++i) {
+    uint64_t digest = 0;
+    uint32_t n_values = 0;
+    table_dictionary_digest(table, string_keys[i], &digest, &n_values);
+    vec[n_cols * 3 + i] = (int64_t)digest;
+  }
+  allgather_small(c, vec.data(), vec_n, all.data());
+  for (size_t i = 0; i < n_cols; ++i) {
+    agreed[i] = {INT64_MAX, INT64_MIN, 0};
+    for (int r = 0; r < world; ++r) {
+      const int64_t* v = all.data() + (size_t)r * vec_n + i * 3;
+      if (v[0] > v[1]) { agreed[i].nulls += (uint64_t)v[2]; continue; }  // no value on that rank
+      agreed[i].min = std::min(agreed[i].min, v[0]);
+      agreed[i].max = std::max(agreed[i].max, v[1]);
+      agreed[i].nulls += (uint64_t)v[2];
+    }
+  }
+  for (size_t i = 0; i < string_keys.size(); ++i)
+    for (int r = 1; r < world; ++r)
+      if (all[(size_t)r * vec_n + n_cols * 3 + i] != all[n_cols * 3 + i])
+        fail(PRISM_GPU_EINVAL, "string key column `" + plan->fields[string_keys[i]].name +
+                                   "` has different dictionaries on different ranks (string keys travel as dictionary codes)");
+
+  // ---- 2. this rank's share ----
+  StateGuard local;
+  local.st = aggregate_state(plan, table, partition_ids, n_partitions, agreed.data());
+  const auto t0 = std::chrono::steady_clock::now();
+  auto done = [&](int has) {
+    std::lock_guard<std::mutex> g(c->mu);
+    c->stats.exchange_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return has;
+  };
+  StateView v = state_view(local.st);
+
+  // ---- 3a. small key space: the accumulator arrays are reduced in place ----
+  if (v.dense) {
+    for (int s = 0; s < v.n_slots;) {
+      int e = s + 1;
+      const bool f64 = v.slot_ops[s] == kSlotAddF64;
+      while (e < v.n_slots && reduce_of(v.slot_ops[e]) == reduce_of(v.slot_ops[s]) && (v.slot_ops[e] == kSlotAddF64) == f64) ++e;
+      // slot arrays lie dense_stride apart, one spare entry between two: a run of slots is one array
+      const size_t n = (size_t)(e - s) * v.dense_stride - (v.dense_stride - v.entries);
+      reduce_device(c, v.dense_state + (uint64_t)s * v.dense_stride, n, f64 ? PRISM_REDUCE_F64 : PRISM_REDUCE_I64, reduce_of(v.slot_ops[s]), root);
+      s = e;
+    }
+    PRISM_HIP(hipStreamSynchronize(ctx->stream));
+    if (rank != root) return done(0);
+    state_finish(local.st, out);
+    return done(1);
+  }
+  if (world == 1) {
+    state_finish(local.st, out);
+    return done(1);
+  }
+
+  // ---- 3b. large key space: rows to their owners, merge there, the owners' groups to root ----
+  const int width = 1 + v.n_slots;
+  const uint64_t n = v.entries;
+  Scratch d_counts(ctx, 8 * 64), send(ctx, std::max<uint64_t>(1, n) * 8 * (uint64_t)width);
+  launch_owner_count(ctx, v.keys, n, (uint32_t)world, d_counts.as<unsigned long long>());
+  std::vector<uint64_t> send_counts(world, 0), cursor(world, 0);
+  PRISM_HIP(hipMemcpyAsync(send_counts.data(), d_counts.p, 8 * (size_t)world, hipMemcpyDeviceToHost, ctx->stream));
+  PRISM_HIP(hipStreamSynchronize(ctx->stream));
+  for (int r = 1; r < world; ++r) cursor[r] = cursor[r - 1] + send_counts[r - 1];
+  PRISM_HIP(hipMemcpyAsync(d_counts.p, cursor.data(), 8 * (size_t)world, hipMemcpyHostToDevice, ctx->stream));
+  launch_owner_scatter(ctx, v.keys, v.state, n, v.n_slots, (uint32_t)world, d_counts.as<unsigned long long>(), send.as<uint64_t>(),
+                       send.as<int64_t>() + n);
+  // who sends how much to whom
+  std::vector<int64_t> counts_all((size_t)world * world);
+  allgather_small(c, (const int64_t*)send_counts.data(), (size_t)world, counts_all.data());
+  std::vector<uint64_t> recv_counts(world);
+  uint64_t recv_total = 0;
+  for (int s = 0; s < world; ++s) recv_total += recv_counts[s] = (uint64_t)counts_all[(size_t)s * world + rank];
+  Scratch recv(ctx, std::max<uint64_t>(1, recv_total) * 8 * (uint64_t)width);
+  alltoallv_columns(c, width, send.as<uint64_t>(), n, send_counts, recv.as<uint64_t>(), recv_total, recv_counts);
+  PRISM_HIP(hipStreamSynchronize(ctx->stream));
+  collect_timings(ctx);
+  send.reset();
+
+  // the owner's table: same key packing, no rows of its own
+  StateGuard owned;
+  const uint32_t no_partition = 0xFFFFFFFFu;
+  owned.st = aggregate_state(plan, table, &no_partition, 1, agreed.data());
+  state_merge(owned.st, recv.p, recv_total);
+  recv.reset();
+
+  // the owner's groups that can still make the result
+  Scratch lead_keys, lead_state;
+  const uint64_t n_lead = state_leading_rows(owned.st, lead_keys, lead_state);
+  std::vector<int64_t> lead_all(world);
+  const int64_t n_lead_i = (int64_t)n_lead;
+  allgather_small(c, &n_lead_i, 1, lead_all.data());
+  std::vector<uint64_t> to_root(world, 0), from_all(world, 0);
+  to_root[root] = n_lead;
+  uint64_t root_total = 0;
+  if (rank == root)
+    for (int s = 0; s < world; ++s) root_total += from_all[s] = (uint64_t)lead_all[s];
+  // keys and slot columns sit in two blocks: sent as two column sets
+  Scratch gathered(ctx, std::max<uint64_t>(1, root_total) * 8 * (uint64_t)width);
+  alltoallv_columns(c, 1, lead_keys.as<uint64_t>(), n_lead, to_root, gathered.as<uint64_t>(), root_total, from_all);
+  alltoallv_columns(c, v.n_slots, lead_state.as<uint64_t>(), n_lead, to_root, gathered.as<uint64_t>() + root_total, root_total, from_all);
+  PRISM_HIP(hipStreamSynchronize(ctx->stream));
+  if (rank != root) return done(0);
+  StateGuard final_state;
+  final_state.st = aggregate_state(plan, table, &no_partition, 1, agreed.data());
+  state_merge(final_state.st, gathered.p, root_total);
+  state_finish(final_state.st, out);
+  return done(1);
+}
+
+}  // namespace prism

@@ -200,6 +200,9 @@ StateView state_view(prism_gpu_state* st);
 // cut included).  Compact form in fresh blocks: keys[n], state[n_slots][n]; returns n.
 uint64_t state_leading_rows(prism_gpu_state* st, struct Scratch& out_keys, struct Scratch& out_state);
 
+// FNV-1a over the dictionary values of a string column, in code order.
+void table_dictionary_digest(prism_gpu_table* table, int column, uint64_t* digest, uint32_t* n_values);
+
 // ---- collectives between the GPUs of a node (comm.cpp) ----
 prism_gpu_comm* comm_create_rccl(prism_gpu_ctx* ctx, const void* unique_id, int rank, int world);
 prism_gpu_comm* comm_create_callbacks(prism_gpu_ctx* ctx, const prism_gpu_transport* t, int rank, int world);

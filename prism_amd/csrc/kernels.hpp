@@ -362,6 +362,14 @@ struct MergeParams {
 };
 void launch_merge_packed(prism_gpu_ctx* ctx, const MergeParams& p);
 
+// Compact group rows (keys[n], state[n_slots][n]) dealt to owner ranks by a hash of the key:
+// counts[world] receives the rows per owner; the scatter writes the rows grouped by owner,
+// in the same column layout, with cursor[world] holding each owner's first place on entry
+// (and one past its last on exit).
+void launch_owner_count(prism_gpu_ctx* ctx, const uint64_t* keys, uint64_t n, uint32_t world, unsigned long long* counts);
+void launch_owner_scatter(prism_gpu_ctx* ctx, const uint64_t* keys, const int64_t* state, uint64_t n, int n_slots, uint32_t world,
+                          unsigned long long* cursor, uint64_t* out_keys, int64_t* out_state);
+
 // Fills n entries with `value`.
 void launch_fill_i64(prism_gpu_ctx* ctx, int64_t* dst, uint64_t n, int64_t value);
 // Compacts the occupied entries of a table: out_keys[i], out_state[s * out_stride + i].

@@ -515,4 +515,18 @@ void table_sync_stats(prism_gpu_table* t) {
   }
 }
 
+void table_dictionary_digest(prism_gpu_table* table, int column, uint64_t* digest, uint32_t* n_values) {
+  std::lock_guard<std::mutex> g(table->mu);
+  const ColumnDict& d = table->dicts[column];
+  uint64_t h = 0xcbf29ce484222325ull;  // FNV-1a
+  auto mix = [&](uint8_t b) { h = (h ^ b) * 0x100000001b3ull; };
+  for (const std::string& v : d.values) {
+    for (unsigned char c : v) mix(c);
+    mix(0xff);  // separator: no UTF-8 byte
+  }
+  if (!d.alive) h = ~h;
+  *digest = h;
+  *n_values = (uint32_t)d.values.size();
+}
+
 }  // namespace prism

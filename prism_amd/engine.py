@@ -35,6 +35,8 @@ EXPORTED_SYMBOLS = [
     "prism_gpu_table_dictionary_digest",
     "prism_gpu_set_profiling", "prism_gpu_get_stats", "prism_gpu_reset_stats",
     "prism_gpu_set_option", "prism_gpu_execute_noalloc", "prism_gpu_plan_time_range",
+    "prism_gpu_comm_unique_id", "prism_gpu_comm_init", "prism_gpu_comm_init_callbacks", "prism_gpu_comm_free",
+    "prism_gpu_execute_sharded", "prism_gpu_comm_get_stats",
 ]
 
 _LIB: Optional[C.CDLL] = None
@@ -105,6 +107,13 @@ def load_library() -> C.CDLL:
     L.prism_gpu_set_option.argtypes = [V, C.c_char_p, C.c_int64]
     L.prism_gpu_plan_time_range.argtypes = [V, C.c_int32, P(C.c_int64), P(C.c_int64)]
     L.prism_gpu_execute_noalloc.argtypes = [V, V, P(C.c_uint32), C.c_size_t, V, V, C.c_uint64, P(C.c_uint64)]
+    L.prism_gpu_comm_unique_id.argtypes = [V]
+    L.prism_gpu_comm_init.argtypes = [V, V, C.c_int, C.c_int, P(V)]
+    L.prism_gpu_comm_init_callbacks.argtypes = [V, P(abi.Transport), C.c_int, C.c_int, P(V)]
+    L.prism_gpu_comm_free.argtypes = [V]
+    L.prism_gpu_comm_free.restype = None
+    L.prism_gpu_execute_sharded.argtypes = [V, V, V, P(C.c_uint32), C.c_size_t, C.c_int, P(abi.ArrowArray), P(C.c_int)]
+    L.prism_gpu_comm_get_stats.argtypes = [V, P(abi.CommStats)]
     _LIB = L
     return L
 
@@ -314,6 +323,18 @@ class Plan:
             arr[0] = 0xFFFFFFFF  # an id no partition has: scan nothing
         return arr, max(1, len(ids))
 
+    def execute_sharded(self, comm: "Comm", table: Table, partitions: Optional[Iterable[int]] = None,
+                        root: int = 0) -> Optional[pa.Table]:
+        """prism_gpu_execute_sharded: every rank aggregates its `partitions`; the final rows
+        arrive on rank `root` (None elsewhere).  The collectives are the library's own."""
+        arr, k = self._partition_args(partitions)
+        out = abi.ArrowArray()
+        has = C.c_int(0)
+        _check(self._lib.prism_gpu_execute_sharded(comm._h, self._h, table._h, arr, k, root, C.byref(out), C.byref(has)))
+        if not has.value:
+            return None
+        return pa.Table.from_batches([abi.import_batch(out, self.final_schema)])
+
     def scan_stats(self, table: Table, partitions: Optional[Iterable[int]] = None):
         """Per input column (min, max, nulls) of the scan, as an int64 array [n_columns, 3]
         (nulls reinterpreted as int64)."""
@@ -372,4 +393,63 @@ class State:
     def close(self) -> None:
         if self._h:
             self._lib.prism_gpu_state_free(self._h)
+            self._h = C.c_void_p()
+
+
+class Comm:
+    """prism_gpu_comm: the ranks of one sharded query (one process per GPU)."""
+
+    ID_BYTES = 128
+
+    def __init__(self, ctx: Context, handle, keep=None):
+        self._lib = ctx._lib
+        self._h = handle
+        self._keep = keep  # the callback objects must outlive the communicator
+
+    @staticmethod
+    def unique_id() -> bytes:
+        """128 bytes that rank 0 makes and hands to the other ranks out of band."""
+        buf = C.create_string_buffer(Comm.ID_BYTES)
+        _check(load_library().prism_gpu_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def rccl(cls, ctx: Context, unique_id: bytes, rank: int, world: int) -> "Comm":
+        """RCCL communicator over the GPUs of the node (xGMI)."""
+        h = C.c_void_p()
+        _check(ctx._lib.prism_gpu_comm_init(ctx._h, C.c_char_p(unique_id), rank, world, C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def from_process_group(cls, ctx: Context) -> "Comm":
+        """RCCL communicator with the ranks of the default torch.distributed group; torch is
+        used once, to hand rank 0's unique id to the others, and for nothing afterwards."""
+        import torch.distributed as dist
+
+        rank, world = dist.get_rank(), dist.get_world_size()
+        box = [cls.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        return cls.rccl(ctx, box[0], rank, world)
+
+    @classmethod
+    def from_callbacks(cls, ctx: Context, rank: int, world: int, allgather, reduce, alltoallv) -> "Comm":
+        """The callbacks transport (prism_gpu_transport): three Python callables with the C
+        signatures of the struct's members, returning 0 on success."""
+        t = abi.Transport()
+        keep = (abi.ALLGATHER_FN(allgather), abi.REDUCE_FN(reduce), abi.ALLTOALLV_FN(alltoallv))
+        t.user = None
+        t.allgather, t.reduce, t.alltoallv = keep
+        h = C.c_void_p()
+        _check(ctx._lib.prism_gpu_comm_init_callbacks(ctx._h, C.byref(t), rank, world, C.byref(h)))
+        return cls(ctx, h, keep)
+
+    def stats(self) -> dict:
+        st = abi.CommStats()
+        _check(self._lib.prism_gpu_comm_get_stats(self._h, C.byref(st)))
+        return {"collectives": st.collectives, "bytes_sent": st.bytes_sent, "exchange_ms": st.exchange_ms}
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.prism_gpu_comm_free(self._h)
             self._h = C.c_void_p()

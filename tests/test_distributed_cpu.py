@@ -84,54 +84,52 @@ def test_partition_assignment_balances_by_size():
 
 
 def _collective_worker(rank: int, world: int, port: int, q):
-    """Runs the collectives of the device-resident exchange on CPU tensors (gloo)."""
-    sys.path.insert(0, ROOT)
+    """The callbacks transport the library's exchange runs over when RCCL cannot be used,
+    driven directly (no GPU): what each callback must deliver, between two gloo ranks."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import ctypes as C
+
     import numpy as np
-    import torch
     import torch.distributed as dist
 
     from prism_amd import _cabi as abi
-    from prism_amd.distributed import agree_on_stats, gather_rows, reduce_dense_state
+    from prism_amd.distributed import torch_cpu_callbacks
 
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
-        dev = torch.device("cpu")
-        # statistics: min of mins, max of maxes, sum of NULL counts; equal digests
-        local = np.array([[10 * rank, 100 + rank, rank + 1], [2**62, -(2**62), 0]], dtype=np.int64)
-        stats, same = agree_on_stats(local, [0xFEEDFACECAFEBEEF], dev)
-        _, differ = agree_on_stats(local, [rank], dev)
-        # dense state: slots SUM_I64, SUM_I64 (wrapping), MAX, MIN, SUM_F64
-        entries = 5
-        merge = [abi.SLOT_SUM_I64, abi.SLOT_SUM_I64, abi.SLOT_MAX_I64, abi.SLOT_MIN_I64, abi.SLOT_SUM_F64]
-        buf = torch.zeros(len(merge) * entries, dtype=torch.int64)
-        buf[0:5] = torch.arange(5) + rank
-        buf[5:10] = torch.tensor([2**62, 2**62, 1, 2, 3]) if rank == 0 else torch.tensor([2**62, 2**62, 1, 2, 3])
-        buf[10:15] = torch.tensor([rank * 7, -rank, 3, 3, -(2**63)])
-        buf[15:20] = torch.tensor([rank * 7, -rank, 3, 3, 2**63 - 1])
-        buf[20:25] = torch.tensor([0.5 + rank, -1.25, 0.0, 1e300, 3.0], dtype=torch.float64).view(torch.int64)
-        reduce_dense_state(buf, merge, entries, dst=0)
-        # hash rows: rank r sends r + 1 rows of (key, 2 slots)
-        n = rank + 1
-        rows = torch.cat([torch.arange(n) + 100 * rank, torch.full((n,), rank), torch.full((n,), -rank)]).to(torch.int64)
-        parts = gather_rows(rows, n, 2, dst=0)
-        # all-to-all by key hash: every key must arrive at exactly one rank, with its slots
-        from prism_amd.distributed import exchange_rows_all_to_all
+        allgather, reduce, alltoallv = torch_cpu_callbacks()
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        u64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint64))  # noqa: E731
 
-        keys = torch.arange(50, dtype=torch.int64) * 1_000_003 + rank  # 50 keys per rank, disjoint
-        cols = torch.cat([keys, keys * 2, keys * 3])
-        got = exchange_rows_all_to_all(cols, 50, 2)
-        m = got.numel() // 3
-        gk, g1, g2 = got[:m], got[m:2 * m], got[2 * m:]
-        a2a_ok = bool((g1 == gk * 2).all() and (g2 == gk * 3).all())
-        q.put((rank, stats.tolist(), same, differ, buf.tolist() if rank == 0 else None,
-               [(p.tolist(), k) for p, k in parts] if parts is not None else None, gk.tolist(), a2a_ok))
+        # all-gather: rank order
+        mine = np.array([10 * rank, 100 + rank, rank + 1], dtype=np.int64)
+        all_ = np.zeros(3 * world, dtype=np.int64)
+        rc_gather = allgather(None, ptr(mine), ptr(all_), mine.nbytes)
+
+        # reductions onto rank 0: wrapping int64 sums, min, max, float64 sums
+        s = np.array([2**62, 2**62, rank, -rank, 3], dtype=np.int64)
+        mx = np.array([rank * 7, -rank, 3, 3, -(2**63)], dtype=np.int64)
+        mn = np.array([rank * 7, -rank, 3, 3, 2**63 - 1], dtype=np.int64)
+        f = np.array([0.5 + rank, -1.25, 0.0, 1e300, 3.0], dtype=np.float64)
+        rcs = [reduce(None, ptr(s), 5, abi.REDUCE_I64, abi.REDUCE_SUM, 0), reduce(None, ptr(mx), 5, abi.REDUCE_I64, abi.REDUCE_MAX, 0),
+               reduce(None, ptr(mn), 5, abi.REDUCE_I64, abi.REDUCE_MIN, 0), reduce(None, ptr(f), 5, abi.REDUCE_F64, abi.REDUCE_SUM, 0)]
+
+        # all-to-all with uneven runs: rank r sends (r + 1) words to rank 0 and 2 * (r + 1) to rank 1, none to itself's ... 
+        send_counts = np.array([rank + 1, 2 * (rank + 1)], dtype=np.uint64)
+        send = (np.arange(int(send_counts.sum()), dtype=np.uint64) + 1000 * rank)
+        recv_counts = np.array([(s_ + 1) * (1 if rank == 0 else 2) for s_ in range(world)], dtype=np.uint64)
+        recv = np.zeros(int(recv_counts.sum()), dtype=np.uint64)
+        rc_a2a = alltoallv(None, u64(send), u64(send_counts), u64(recv), u64(recv_counts))
+        # an empty exchange is legal
+        zero = np.zeros(world, dtype=np.uint64)
+        empty = np.zeros(1, dtype=np.uint64)
+        rc_empty = alltoallv(None, u64(empty), u64(zero), u64(empty), u64(zero))
+        q.put((rank, [rc_gather, *rcs, rc_a2a, rc_empty], all_.tolist(), s.tolist(), mx.tolist(), mn.tolist(), f.tolist(), recv.tolist()))
     finally:
         dist.destroy_process_group()
 
 
-def test_state_exchange_collectives_two_ranks():
-    import struct
-
+def test_callbacks_transport_two_ranks():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -146,23 +144,13 @@ def test_state_exchange_collectives_two_ranks():
         p.join(timeout=60)
         assert p.exitcode == 0
     for r in (0, 1):
-        stats, same, differ = out[r][0], out[r][1], out[r][2]
-        assert stats == [[0, 101, 3], [2**62, -(2**62), 0]]
-        assert same is True and differ is False
-    buf = out[0][3]
-    assert buf[0:5] == [1, 3, 5, 7, 9]
-    assert buf[5:10] == [-(2**63), -(2**63), 2, 4, 6]          # 2^62 + 2^62 wraps
-    assert buf[10:15] == [7, 0, 3, 3, -(2**63)]
-    assert buf[15:20] == [0, -1, 3, 3, 2**63 - 1]
-    f = [struct.unpack("<d", struct.pack("<q", v))[0] for v in buf[20:25]]
+        assert out[r][0] == [0] * 7
+        assert out[r][1] == [0, 100, 1, 10, 101, 2]
+    _, _, s, mx, mn, f, _ = out[0]
+    assert s == [-(2**63), -(2**63), 1, -1, 6]          # 2^62 + 2^62 wraps
+    assert mx == [7, 0, 3, 3, -(2**63)]
+    assert mn == [0, -1, 3, 3, 2**63 - 1]
     assert f == [2.0, -2.5, 0.0, 2e300, 6.0]
-    parts = out[0][4]
-    assert out[1][4] is None
-    assert parts[0] == ([0, 0, 0], 1)
-    assert parts[1] == ([100, 101, 1, 1, -1, -1], 2)
-    # all-to-all: the two ranks' slices are disjoint, cover all 100 keys, and rows stayed intact
-    k0, k1 = out[0][5], out[1][5]
-    assert out[0][6] and out[1][6]
-    assert not set(k0) & set(k1)
-    assert sorted(k0 + k1) == sorted([i * 1_000_003 + r for i in range(50) for r in (0, 1)])
-    assert len(k0) > 10 and len(k1) > 10
+    # rank 0 receives word 0 of rank 0 and words 0..1 of rank 1; rank 1 the rest, in rank order
+    assert out[0][6] == [0, 1000, 1001]
+    assert out[1][6] == [1, 2, 1002, 1003, 1004, 1005]

@@ -1,0 +1,181 @@
+"""The exchange inside the library (prism_gpu_comm_*, prism_gpu_execute_sharded): a one-rank
+RCCL communicator on the real GPU, two and three ranks that share the GPU over the callbacks
+transport (RCCL refuses two ranks on one device; the exchange code above the transport is the
+same), and the error paths.  Results equal the CPU oracle's over all ranks' rows: bit-exact
+for keys, counts and integer aggregates, 1e-9 relative for AVG."""
+import pytest
+
+from tests import helpers
+from tests.helpers import assert_tables_match
+
+pytestmark = pytest.mark.gpu
+
+from prism_amd import _cabi as abi  # noqa: E402
+from prism_amd.plan import QueryPlan, avg, col, count, count_distinct, count_star, date_bin, max_, min_, sum_  # noqa: E402
+
+AGGS = [count_star(), sum_("value"), min_("i32"), max_("u16"), avg("value"), count("i32")]
+
+
+@pytest.fixture(scope="module")
+def loaded(gpu_ctx):
+    from prism_amd.engine import Table
+
+    t = helpers.random_table(60_000, seed=12, nulls=True)
+    g = Table(gpu_ctx, t.schema)
+    g.append_table(t, 4)
+    yield t, g
+    g.close()
+
+
+def test_one_rank_rccl_communicator(gpu_ctx, loaded):
+    """ncclCommInitRank with world 1: librccl is found and loaded, and both shapes of state
+    (dense, hash) finish through the sharded entry point."""
+    from oracle import pyoracle
+    from prism_amd.engine import Comm, Plan
+
+    t, g = loaded
+    uid = Comm.unique_id()
+    assert len(uid) == Comm.ID_BYTES
+    comm = Comm.rccl(gpu_ctx, uid, 0, 1)
+    try:
+        for keys, n_keys in [(["service", "i16"], 2), (["user"], 1)]:
+            q = QueryPlan(AGGS, keys=keys, predicate=col("i32") > -900)
+            plan = Plan(gpu_ctx, t.schema, q)
+            try:
+                got = plan.execute_sharded(comm, g)
+            finally:
+                plan.close()
+            assert_tables_match(got, pyoracle.execute(t, q), n_keys)
+        assert comm.stats()["collectives"] >= 2
+    finally:
+        comm.close()
+
+
+def test_plans_without_device_state_are_refused_before_any_collective(gpu_ctx, loaded):
+    from prism_amd.engine import Comm, Plan, PrismGpuError
+
+    t, g = loaded
+    comm = Comm.rccl(gpu_ctx, Comm.unique_id(), 0, 1)
+    try:
+        for q in (QueryPlan([count_star()]), QueryPlan([count_distinct("user")], keys=["service"])):
+            plan = Plan(gpu_ctx, t.schema, q)
+            try:
+                with pytest.raises(PrismGpuError) as e:
+                    plan.execute_sharded(comm, g)
+                assert e.value.code == abi.EUNSUPPORTED
+            finally:
+                plan.close()
+        assert comm.stats()["collectives"] == 0
+    finally:
+        comm.close()
+
+
+def test_a_failing_transport_is_reported_as_erccl(gpu_ctx, loaded):
+    import ctypes as C
+
+    from prism_amd.engine import Comm, Plan, PrismGpuError
+
+    t, g = loaded
+    tr = abi.Transport()
+    keep = (abi.ALLGATHER_FN(lambda *_: 7), abi.REDUCE_FN(lambda *_: 7), abi.ALLTOALLV_FN(lambda *_: 7))
+    tr.allgather, tr.reduce, tr.alltoallv = keep
+    h = C.c_void_p()
+    rc = gpu_ctx._lib.prism_gpu_comm_init_callbacks(gpu_ctx._h, C.byref(tr), 0, 2, C.byref(h))
+    assert rc == 0
+    comm = Comm(gpu_ctx, h, keep)
+    plan = Plan(gpu_ctx, t.schema, QueryPlan([count_star()], keys=["service"]))
+    try:
+        with pytest.raises(PrismGpuError) as e:
+            plan.execute_sharded(comm, g)
+        assert e.value.code == abi.ERCCL and "allgather" in e.value.msg
+    finally:
+        plan.close()
+        comm.close()
+    # rank outside the world
+    rc = gpu_ctx._lib.prism_gpu_comm_init_callbacks(gpu_ctx._h, C.byref(tr), 2, 2, C.byref(h))
+    assert rc == abi.EINVAL
+
+
+def _rank_worker(rank: int, world: int, port: int, q):
+    """One of `world` processes sharing GPU 0: its own context, its own share of the tables,
+    the exchange over the callbacks transport; the root checks against the oracle."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+
+    from oracle import pyoracle
+    from prism_amd import workloads
+    from prism_amd.distributed import exchange_and_finish, make_comm
+    from prism_amd.engine import Context, Plan
+    from prism_amd.plan import QueryPlan as Q, avg as avg_, count_star as cs, max_ as mx, min_ as mn, sum_ as sm
+    from tests.helpers import assert_tables_match, assert_topk_match
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    ctx = Context(0)
+    comm = make_comm(ctx)
+    try:
+        c3 = workloads.c3(id_bits=16)
+        c2 = workloads.c2()
+        cases = [
+            (c2, c2.query, 400_000, 2, 0),                                                        # dense: in-place reduce
+            (c3, c3.query, 300_000, 1, 0),                                                        # hash, ORDER BY .. LIMIT
+            (c3, Q([cs(), mx("UserID"), avg_("UserID"), mn("UserID"), sm("UserID")], keys=["UserID"]), 300_000, 1, world - 1),
+            (c3, Q([cs()], keys=["UserID"], order_by=0, descending=False, limit=5), 200_000, 1, 0),  # ordered by the key
+        ]
+        for wl, query, rows, n_keys, root in cases:
+            total = rows * world
+            table = workloads.build_gpu_table(ctx, wl, rows * rank, rows, total, 4)
+            plan = Plan(ctx, wl.schema, query)
+            try:
+                # the last rank of a three-rank world scans nothing in the first case
+                parts = [] if (world == 3 and rank == 2 and wl is c2) else None
+                got = exchange_and_finish(plan, table, parts, comm, root)
+            finally:
+                plan.close()
+                table.close()
+            if rank == root:
+                n_have = total if not (world == 3 and wl is c2) else rows * 2
+                st = pyoracle.SynthTable(wl.schema, wl.make_cols(), wl.seed, 0, n_have, total, n_parts=4)
+                try:
+                    want, _ = st.execute(query)
+                finally:
+                    st.close()
+                want = workloads.decode_dictionary_columns(wl, want)
+                if query.limit is not None:
+                    assert_topk_match(got, want, query.order_by)
+                else:
+                    assert_tables_match(got, want, n_keys)
+            else:
+                assert got is None
+        assert comm.stats()["bytes_sent"] > 0
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+
+        q.put((rank, traceback.format_exc() + repr(e)))
+    finally:
+        comm.close()
+        ctx.close()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_share_the_gpu_and_exchange_inside_the_library(world):
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert results == {r: "ok" for r in range(world)}, results

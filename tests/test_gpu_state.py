@@ -174,110 +174,3 @@ def test_unsupported_plans_say_so(gpu_ctx, loaded):
             assert e.value.code == -2
         finally:
             plan.close()
-
-
-def test_exchange_and_finish_single_rank_group(gpu_ctx, loaded):
-    """The torch.distributed path (backend nccl = RCCL) with a one-rank group."""
-    import torch
-    import torch.distributed as dist
-
-    from oracle import pyoracle
-    from prism_amd.distributed import exchange_and_finish
-    from prism_amd.engine import Plan
-
-    t, g = loaded
-    created = False
-    if not dist.is_initialized():
-        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29617", rank=0, world_size=1,
-                                device_id=torch.device("cuda", 0))
-        created = True
-    try:
-        for keys, n_keys in [(["service", "i16"], 2), (["user"], 1)]:
-            q = QueryPlan(AGGS, keys=keys)
-            plan = Plan(gpu_ctx, t.schema, q)
-            try:
-                got = exchange_and_finish(plan, g, None, torch.device("cuda", 0))
-            finally:
-                plan.close()
-            assert_tables_match(got, pyoracle.execute(t, q), n_keys)
-    finally:
-        if created:
-            dist.destroy_process_group()
-
-
-def _two_rank_worker(rank: int, world: int, port: int, q):
-    """One of two processes sharing GPU 0: its own context, its own half of the tables, the
-    exchange over gloo (staged through the host); rank 0 checks against the oracle."""
-    import os
-    import sys
-
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    import torch
-    import torch.distributed as dist
-
-    from oracle import pyoracle
-    from prism_amd import workloads
-    from prism_amd.distributed import exchange_and_finish
-    from prism_amd.engine import Context, Plan
-    from tests.helpers import assert_tables_match, assert_topk_match
-
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-    ctx = Context(0)
-    try:
-        dev = torch.device("cuda", 0)
-        from prism_amd.plan import QueryPlan as Q, avg as avg_, count_star as cs, max_ as mx
-
-        c3 = workloads.c3(id_bits=16)
-        cases = [(workloads.c2(), workloads.c2().query, 400_000, 2), (c3, c3.query, 300_000, 1),
-                 (c3, Q([cs(), mx("UserID"), avg_("UserID")], keys=["UserID"]), 300_000, 1)]
-        for wl, query, rows, n_keys in cases:
-            total = rows * world
-            table = workloads.build_gpu_table(ctx, wl, rows * rank, rows, total, 4)
-            plan = Plan(ctx, wl.schema, query)
-            try:
-                got = exchange_and_finish(plan, table, None, dev)
-            finally:
-                plan.close()
-                table.close()
-            if rank == 0:
-                st = pyoracle.SynthTable(wl.schema, wl.make_cols(), wl.seed, 0, total, total, n_parts=4)
-                try:
-                    want, _ = st.execute(query)
-                finally:
-                    st.close()
-                want = workloads.decode_dictionary_columns(wl, want)
-                if query.limit is not None:
-                    assert_topk_match(got, want, query.order_by)
-                else:
-                    assert_tables_match(got, want, n_keys)
-            else:
-                assert got is None
-        q.put((rank, "ok"))
-    except Exception as e:  # noqa: BLE001
-        import traceback
-
-        q.put((rank, traceback.format_exc() + repr(e)))
-    finally:
-        ctx.close()
-        dist.destroy_process_group()
-
-
-def test_two_processes_share_the_gpu_and_exchange_states():
-    """The N > 1 choreography end to end on the real library: two ranks (processes), each
-    with a slice of the C2 / C3 tables in HBM; dense reduce for C2, row gather + merge for C3."""
-    import socket
-
-    import torch.multiprocessing as mp
-
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    results = dict(q.get(timeout=240) for _ in procs)
-    for p in procs:
-        p.join(timeout=60)
-    assert results == {0: "ok", 1: "ok"}, results
