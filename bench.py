@@ -246,16 +246,29 @@ def main() -> int:
             groups = result.num_rows if wl.n_keys else 1
             alg = rows * wl.bytes_per_row + (groups * wl.bytes_per_group if world == 1 else 0)
             achieved = alg / avg_s / 1e9
-            traffic = None
-            try:  # HBM bytes per launch from the committed PMC profile of this exact configuration
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r1", f"{wl.name.lower()}_1b_traffic.json")))
-                if tj["config"]["rows_per_gpu"] == rows and tj["config"]["partitions_per_gpu"] == parts and world == 1:
-                    traffic = tj["hbm_bytes_per_launch"]
-            except (OSError, KeyError, ValueError):
+            # HBM bytes per launch of this kernel: PMC passes (FETCH_SIZE, WRITE_SIZE) cannot run
+            # inside this process, so the figure is the one scripts/profile_workload.sh measured
+            # for this exact command line and committed; null when the configuration differs.
+            traffic = traffic_source = profile_avg_ms = None
+            tag = {("C2", 1_000_000_000, 64): "c2_1b", ("C3", 100_000_000, 100): "c3", ("C1", 1_000_000_000, 64): "c1_1b",
+                   ("C4", 100_000_000, wl.default_partitions): "c4", ("C5", 1_250_000_000, 64): "c5_1p25b"}.get((wl.name, rows, parts))
+            symbol = {"group_by": ("k_group_by_stream", "k_part_agg", "k_part_scatter", "k_part_hist", "k_part_offsets",
+                                   "k_part_plan", "k_group_by_wide", "k_group_by"),
+                      "filter_count": ("k_cmp_leaf",), "like_contains": ("k_contains_find", "k_contains_mark")}[kname]
+            try:
+                if tag and world == 1:
+                    tj = json.load(open(os.path.join(ROOT, "profiles", "r2", f"{tag}_traffic.json")))
+                    ks_prof = [tj["kernels"][k] for k in symbol if k in tj["kernels"] and tj["kernels"][k]["calls"] >= 5]
+                    if ks_prof:
+                        traffic = sum((k["fetch_bytes_per_launch"] or 0) + (k["write_bytes_per_launch"] or 0) for k in ks_prof)
+                        profile_avg_ms = sum(k["avg_ns"] for k in ks_prof) / 1e6
+                        traffic_source = f"profiles/r2/{tag}_traffic.json (rocprofv3 --pmc passes of the same command, not collected in this run)"
+            except (OSError, KeyError, ValueError, TypeError):
                 pass
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
-                        "kernel_avg_ms": avg_s * 1e3, "algorithmic_bytes_per_launch": alg}
+                        "kernel_avg_ms": avg_s * 1e3, "algorithmic_bytes_per_launch": alg,
+                        "traffic_source": traffic_source, "profile_kernel_avg_ms": profile_avg_ms}
             try:  # the streaming-read rate a plain sum kernel reaches on this part (committed measurement)
                 ceil_gbs = json.load(open(os.path.join(ROOT, "profiles", "r1", "read_ceiling.json")))["read_GBps"]
                 roofline["measured_read_ceiling"] = ceil_gbs

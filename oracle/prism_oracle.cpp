@@ -55,6 +55,7 @@
 #include <vector>
 
 #include "../include/prism_gpu.h"
+#include "../include/prism_gpu_synth.h"
 #include "../include/prism_synth.h"
 
 namespace {

@@ -8,6 +8,7 @@
 #include <string>
 
 #include "../../include/prism_gpu.h"
+#include "../../include/prism_gpu_synth.h"
 
 namespace prism {
 
