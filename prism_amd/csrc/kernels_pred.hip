@@ -5,6 +5,10 @@
 // Fixed-width leaves stream the column with 16-byte loads per lane, so a wave
 // instruction moves 1 KiB; result bits are packed to bytes with cross-lane
 // shuffles and stored as bytes of the little-endian bitmap words.
+#include <algorithm>
+#include <cstdint>
+#include <type_traits>
+
 #include "device_utils.hpp"
 
 namespace prism {
@@ -173,18 +177,28 @@ __device__ __forceinline__ void leaf_body(const ScanDesc& sd, const ColPtr* col,
   if (count) block_count_add(local, count);
 }
 
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_cmp_leaf(ScanDesc sd, const ColPtr* col, int cmp_mask, long long lit, int cmp_mask2,
-                                                    long long lit2, uint64_t* bits, unsigned long long* count) {
-  const bool want_lt = cmp_mask & kLt, want_eq = cmp_mask & kEq, want_gt = cmp_mask & kGt;
-  // a second comparison on the same column, AND-ed in (a range in one pass); all orderings = none
-  const bool want_lt2 = cmp_mask2 & kLt, want_eq2 = cmp_mask2 & kEq, want_gt2 = cmp_mask2 & kGt;
+// A comparison with a literal (and optionally a second one on the same column, AND-ed in: a
+// range in one pass) arrives as range tests worked out on the host: the value passes test i
+// when ((u - lo_i) <= span_i) != neg_i, with u the value in the unsigned type U of its
+// promoted width.  Two instructions per value and test, in 32 bits for columns of up to 4
+// bytes; comparing in 64 bits against three flags per ordering cost ten times that and made
+// a 2-byte column compute bound.
+template <typename T, bool TWO>
+__global__ __launch_bounds__(kBlock) void k_cmp_leaf(ScanDesc sd, const ColPtr* col, unsigned long long lo1, unsigned long long span1,
+                                                    int neg1, unsigned long long lo2, unsigned long long span2, int neg2,
+                                                    uint64_t* bits, unsigned long long* count) {
+  using U = typename std::conditional<sizeof(T) == 8, unsigned long long, uint32_t>::type;
+  using P = typename std::conditional<sizeof(T) == 8, long long,
+                                      typename std::conditional<std::is_signed<T>::value, int32_t, uint32_t>::type>::type;
+  const U l1 = (U)lo1, s1 = (U)span1, l2 = (U)lo2, s2 = (U)span2;
+  const bool n1 = neg1 != 0, n2 = neg2 != 0;
   leaf_body<T>(
       sd, col,
       [=](T x) {
-        long long v = (long long)x;
-        return ((v < lit && want_lt) || (v == lit && want_eq) || (v > lit && want_gt)) &&
-               ((v < lit2 && want_lt2) || (v == lit2 && want_eq2) || (v > lit2 && want_gt2));
+        const U u = (U)(P)x;
+        bool pass = ((U)(u - l1) <= s1) != n1;
+        if (TWO) pass = pass && (((U)(u - l2) <= s2) != n2);
+        return pass;
       },
       bits, count);
 }
@@ -343,17 +357,63 @@ __global__ __launch_bounds__(kBlock) void k_bitmap_count(const uint64_t* bits, u
 
 }  // namespace
 
+namespace {
+
+// The values of a column of type [tmin, tmax] that satisfy `v <cmp> literal`, as one range
+// test: pass iff ((v - lo) <= span) != neg, in unsigned arithmetic of the column's promoted width.
+struct RangeTest {
+  unsigned long long lo = 0, span = ~0ull;
+  int neg = 0;
+};
+
+RangeTest range_test(int cmp_mask, int64_t lit, int64_t tmin, int64_t tmax) {
+  const bool lt = cmp_mask & kLt, eq = cmp_mask & kEq, gt = cmp_mask & kGt;
+  RangeTest never;
+  never.neg = 1;  // NOT (everything)
+  RangeTest all;
+  if (lt && eq && gt) return all;
+  if (!lt && !eq && !gt) return never;
+  bool negate = false;
+  int64_t a, b;  // inclusive
+  if (lt && gt) { negate = true; a = b = lit; }           // <>
+  else if (lt) { a = INT64_MIN; if (eq) b = lit; else { if (lit == INT64_MIN) return never; b = lit - 1; } }
+  else if (gt) { b = INT64_MAX; if (eq) a = lit; else { if (lit == INT64_MAX) return never; a = lit + 1; } }
+  else { a = b = lit; }
+  a = std::max(a, tmin);
+  b = std::min(b, tmax);
+  if (a > b) return negate ? all : never;  // no value of the type lies in the range
+  RangeTest r;
+  r.lo = (unsigned long long)a;
+  r.span = (unsigned long long)b - (unsigned long long)a;
+  r.neg = negate ? 1 : 0;
+  return r;
+}
+
+template <typename T>
+void launch_cmp_leaf_t(prism_gpu_ctx* ctx, const ScanDesc& sd, const ColPtr* col, const RangeTest& r1, const RangeTest& r2, bool two,
+                       uint64_t* bits, unsigned long long* count) {
+  dim3 grid(leaf_grid(ctx, sd.n_tiles)), block(kBlock);
+  if (two) k_cmp_leaf<T, true><<<grid, block, 0, ctx->stream>>>(sd, col, r1.lo, r1.span, r1.neg, r2.lo, r2.span, r2.neg, bits, count);
+  else k_cmp_leaf<T, false><<<grid, block, 0, ctx->stream>>>(sd, col, r1.lo, r1.span, r1.neg, r2.lo, r2.span, r2.neg, bits, count);
+}
+
+}  // namespace
+
 void launch_cmp_leaf(prism_gpu_ctx* ctx, const ScanDesc& sd, const ColPtr* col, int width, bool is_unsigned,
                      int cmp_mask, int64_t literal, uint64_t* bits, unsigned long long* count, int cmp_mask2, int64_t literal2) {
   if (sd.n_tiles == 0) return;
-  dim3 grid(leaf_grid(ctx, sd.n_tiles)), block(kBlock);
-  const long long l1 = literal, l2 = literal2;
-  if (width == 2 && !is_unsigned) k_cmp_leaf<int16_t><<<grid, block, 0, ctx->stream>>>(sd, col, cmp_mask, l1, cmp_mask2, l2, bits, count);
-  else if (width == 2) k_cmp_leaf<uint16_t><<<grid, block, 0, ctx->stream>>>(sd, col, cmp_mask, l1, cmp_mask2, l2, bits, count);
-  else if (width == 4 && !is_unsigned) k_cmp_leaf<int32_t><<<grid, block, 0, ctx->stream>>>(sd, col, cmp_mask, l1, cmp_mask2, l2, bits, count);
-  else if (width == 4) k_cmp_leaf<uint32_t><<<grid, block, 0, ctx->stream>>>(sd, col, cmp_mask, l1, cmp_mask2, l2, bits, count);
-  else if (width == 8 && !is_unsigned) k_cmp_leaf<int64_t><<<grid, block, 0, ctx->stream>>>(sd, col, cmp_mask, l1, cmp_mask2, l2, bits, count);
+  int64_t tmin, tmax;
+  if (width == 2) { tmin = is_unsigned ? 0 : INT16_MIN; tmax = is_unsigned ? UINT16_MAX : INT16_MAX; }
+  else if (width == 4) { tmin = is_unsigned ? 0 : INT32_MIN; tmax = is_unsigned ? (int64_t)UINT32_MAX : INT32_MAX; }
+  else if (width == 8 && !is_unsigned) { tmin = INT64_MIN; tmax = INT64_MAX; }
   else fail(PRISM_GPU_EUNSUPPORTED, "comparison on this column type is not supported");
+  const RangeTest r1 = range_test(cmp_mask, literal, tmin, tmax), r2 = range_test(cmp_mask2, literal2, tmin, tmax);
+  const bool two = (cmp_mask2 & (kLt | kEq | kGt)) != (kLt | kEq | kGt);
+  if (width == 2 && !is_unsigned) launch_cmp_leaf_t<int16_t>(ctx, sd, col, r1, r2, two, bits, count);
+  else if (width == 2) launch_cmp_leaf_t<uint16_t>(ctx, sd, col, r1, r2, two, bits, count);
+  else if (width == 4 && !is_unsigned) launch_cmp_leaf_t<int32_t>(ctx, sd, col, r1, r2, two, bits, count);
+  else if (width == 4) launch_cmp_leaf_t<uint32_t>(ctx, sd, col, r1, r2, two, bits, count);
+  else launch_cmp_leaf_t<int64_t>(ctx, sd, col, r1, r2, two, bits, count);
   PRISM_HIP(hipGetLastError());
 }
 
