@@ -198,6 +198,9 @@ void prism_gpu_ctx_free(prism_gpu_ctx* ctx);
  *                    before it is aggregated (default 4194304)
  *   "part_force"     1: partition whenever the plan's shape allows it, without waiting for
  *                    the streaming kernel to report that its rows scatter (default 0)
+ *   "contains_windows" 0: LIKE '%needle%' over a column without a dictionary always uses the
+ *                    byte-wise prefilter; 1 (default): needles of 4 bytes and more are found by
+ *                    comparing 4-byte windows with the needle's leading words
  * Unknown names are PRISM_GPU_EINVAL. */
 int prism_gpu_set_option(prism_gpu_ctx* ctx, const char* name, int64_t value);
 

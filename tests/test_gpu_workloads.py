@@ -137,6 +137,17 @@ def test_c4_like_on_high_cardinality_strings(gpu_ctx, oracle):
             (QueryPlan([count_star()], predicate=col("URL").not_like("%google%")), 0),
             (QueryPlan([count_star()], predicate=col("URL").like("%e%")), 0),
             (QueryPlan([count_star()], predicate=col("URL").like("%google.google.google%")), 0),
+            # every needle length class of the byte-stream search (1-3 bytes; 4; 5-6; 7 and more),
+            # needles at the start and at the end of a row, and one that overlaps itself
+            (QueryPlan([count_star()], predicate=col("URL").like("%go%")), 0),
+            (QueryPlan([count_star()], predicate=col("URL").like("%oog%")), 0),
+            (QueryPlan([count_star()], predicate=col("URL").like("%goog%")), 0),
+            (QueryPlan([count_star()], predicate=col("URL").like("%oogle%")), 0),
+            (QueryPlan([count_star()], predicate=col("URL").like("%e.bing.%")), 0),
+            (QueryPlan([count_star()], predicate=col("URL").like("%http://g%")), 0),
+            (QueryPlan([count_star()], predicate=col("URL").like("%/p77%")), 0),
+            (QueryPlan([count_star()], predicate=col("URL").like("%oo%")), 0),
+            (QueryPlan([count_star()], predicate=col("URL").like("%.google.goo%")), 0),
             (QueryPlan([count_star()], predicate=col("URL").like("http://goo%/p1%")), 0),
             (QueryPlan([count_star()], predicate=col("URL").like("%/p12_")), 0),
             (QueryPlan([count_star()], predicate=col("URL").ilike("%GoOgLe.bing%")), 0),
