@@ -335,9 +335,11 @@ int prism_gpu_plan_final_schema(const prism_gpu_plan* plan,
  *   prism_gpu_state_merge    hash table: merges groups exported by another rank
  *   prism_gpu_state_finish   final rows (ORDER BY / LIMIT applied), as prism_gpu_merge
  *
- * Supported for plans with at least one GROUP BY key, no COUNT(DISTINCT) and a
- * packed key of at most 64 bits; otherwise PRISM_GPU_EUNSUPPORTED, and the caller
- * exchanges PARTIAL batches through prism_gpu_merge instead.  String keys travel
+ * Supported for plans with at least one GROUP BY key (otherwise PRISM_GPU_EUNSUPPORTED,
+ * and the caller exchanges PARTIAL batches through prism_gpu_merge instead).  States of
+ * COUNT(DISTINCT) plans (the set of (value, group) pairs) and of keys wider than 64 bits can
+ * be finished but have no export layout: describe / export / import / merge return
+ * PRISM_GPU_EUNSUPPORTED for them; prism_gpu_execute_sharded exchanges them itself.  String keys travel
  * as dictionary codes: the ranks must hold the same dictionary for the column
  * (compare prism_gpu_table_dictionary_digest).  The table must outlive the state.
  * Device buffers are read and written on the library's own stream, and the calls return
@@ -399,9 +401,11 @@ int prism_gpu_table_dictionary_digest(prism_gpu_table* table, int32_t column,
  *   final rows on `root`            (ORDER BY / LIMIT applied)
  *
  * which is RepartitionExec(Hash) + AggregateExec(FinalPartitioned) + the coalescing of the
- * output partitions in DataFusion's plan for the same query.  Every rank must make the
- * same sequence of calls with the same plan.  Plans the device-resident state does not
- * cover return PRISM_GPU_EUNSUPPORTED on every rank before any collective is issued.
+ * output partitions in DataFusion's plan for the same query.  COUNT(DISTINCT x) plans deal
+ * the (x, group) pairs to the owner of the *group*, which merges them into its set, counts
+ * them per group and passes (group, count) rows on; keys wider than 64 bits travel as two
+ * words.  Every rank must make the same sequence of calls with the same plan.  Plans
+ * without GROUP BY return PRISM_GPU_EUNSUPPORTED on every rank before any collective.
  *
  * Two transports.  prism_gpu_comm_init joins an RCCL communicator (xGMI between the GPUs of
  * a node; librccl is loaded on first use): rank 0 calls prism_gpu_comm_unique_id and hands

@@ -267,8 +267,7 @@ int execute_sharded(prism_gpu_comm* c, prism_gpu_plan* plan, prism_gpu_table* ta
   if (root < 0 || root >= c->world) fail(PRISM_GPU_EINVAL, "root is not a rank of the communicator");
   // what the device-resident state does not cover is refused before any collective, and for
   // reasons every rank sees alike (the plan; the key width follows from the agreed statistics)
-  if (plan->keys.empty() || plan->distinct_plan)
-    fail(PRISM_GPU_EUNSUPPORTED, "the sharded form needs a GROUP BY without COUNT(DISTINCT)");
+  if (plan->keys.empty()) fail(PRISM_GPU_EUNSUPPORTED, "the sharded form needs a GROUP BY (ungrouped aggregates exchange PARTIAL batches)");
   if (plan->mode != PRISM_MODE_SINGLE) fail(PRISM_GPU_EINVAL, "the sharded form runs plans in SINGLE mode: it does the merge itself");
   bind(ctx);
   const int world = c->world, rank = c->rank;
@@ -343,17 +342,31 @@ int execute_sharded(prism_gpu_comm* c, prism_gpu_plan* plan, prism_gpu_table* ta
   }
 
   // ---- 3b. large key space: rows to their owners, merge there, the owners' groups to root ----
-  const int width = 1 + v.n_slots;
+  // Rows travel in compact column form: keys, high words (two-word keys), one column per slot.
+  const bool two = v.key_words == 2;
+  const int width = 1 + (two ? 1 : 0) + v.n_slots;
   const uint64_t n = v.entries;
+  OwnerParams op{};
+  op.keys = v.keys;
+  op.keys_hi = v.keys_hi;
+  op.state = v.state;
+  op.n = n;
+  op.n_slots = v.n_slots;
+  op.world = (uint32_t)world;
+  // all pairs of a COUNT(DISTINCT) group must meet on one rank: the owner follows from the group alone
+  op.owner_of = v.distinct == 1 ? (two ? kOwnerHighWord : kOwnerHighBits) : kOwnerKey;
+  op.shift = v.pair_shift;
   Scratch d_counts(ctx, 8 * 64), send(ctx, std::max<uint64_t>(1, n) * 8 * (uint64_t)width);
-  launch_owner_count(ctx, v.keys, n, (uint32_t)world, d_counts.as<unsigned long long>());
+  launch_owner_count(ctx, op, d_counts.as<unsigned long long>());
   std::vector<uint64_t> send_counts(world, 0), cursor(world, 0);
   PRISM_HIP(hipMemcpyAsync(send_counts.data(), d_counts.p, 8 * (size_t)world, hipMemcpyDeviceToHost, ctx->stream));
   PRISM_HIP(hipStreamSynchronize(ctx->stream));
   for (int r = 1; r < world; ++r) cursor[r] = cursor[r - 1] + send_counts[r - 1];
   PRISM_HIP(hipMemcpyAsync(d_counts.p, cursor.data(), 8 * (size_t)world, hipMemcpyHostToDevice, ctx->stream));
-  launch_owner_scatter(ctx, v.keys, v.state, n, v.n_slots, (uint32_t)world, d_counts.as<unsigned long long>(), send.as<uint64_t>(),
-                       send.as<int64_t>() + n);
+  uint64_t* const send_keys = send.as<uint64_t>();
+  uint64_t* const send_hi = two ? send_keys + n : nullptr;
+  int64_t* const send_state = (int64_t*)(send_keys + (two ? 2 : 1) * n);
+  launch_owner_scatter(ctx, op, d_counts.as<unsigned long long>(), send_keys, send_hi, send_state);
   // who sends how much to whom
   std::vector<int64_t> counts_all((size_t)world * world);
   allgather_small(c, (const int64_t*)send_counts.data(), (size_t)world, counts_all.data());
@@ -361,7 +374,7 @@ int execute_sharded(prism_gpu_comm* c, prism_gpu_plan* plan, prism_gpu_table* ta
   uint64_t recv_total = 0;
   for (int s = 0; s < world; ++s) recv_total += recv_counts[s] = (uint64_t)counts_all[(size_t)s * world + rank];
   Scratch recv(ctx, std::max<uint64_t>(1, recv_total) * 8 * (uint64_t)width);
-  alltoallv_columns(c, width, send.as<uint64_t>(), n, send_counts, recv.as<uint64_t>(), recv_total, recv_counts);
+  alltoallv_columns(c, width, send_keys, n, send_counts, recv.as<uint64_t>(), recv_total, recv_counts);
   PRISM_HIP(hipStreamSynchronize(ctx->stream));
   collect_timings(ctx);
   send.reset();
@@ -370,12 +383,35 @@ int execute_sharded(prism_gpu_comm* c, prism_gpu_plan* plan, prism_gpu_table* ta
   StateGuard owned;
   const uint32_t no_partition = 0xFFFFFFFFu;
   owned.st = aggregate_state(plan, table, &no_partition, 1, agreed.data());
-  state_merge(owned.st, recv.p, recv_total);
+  {
+    const uint64_t* rk = recv.as<uint64_t>();
+    state_merge_rows(owned.st, rk, two ? rk + recv_total : nullptr, (const int64_t*)(rk + (two ? 2 : 1) * recv_total), recv_total);
+  }
   recv.reset();
 
+  // COUNT(DISTINCT): the owner holds every pair of its groups, so it can count them; what goes
+  // on to the root are (group, count) rows of groups no other rank has
+  StateGuard outer;
+  prism_gpu_state* work = owned.st;
+  if (v.distinct == 1) {
+    outer.st = state_distinct_outer(owned.st);
+    work = outer.st;
+  }
+  StateView w = state_view(work);
+  if (w.dense) {
+    for (int s = 0; s < w.n_slots; ++s)
+      reduce_device(c, w.dense_state + (uint64_t)s * w.dense_stride, w.entries, PRISM_REDUCE_I64, reduce_of(w.slot_ops[s]), root);
+    PRISM_HIP(hipStreamSynchronize(ctx->stream));
+    if (rank != root) return done(0);
+    state_finish(work, out);
+    return done(1);
+  }
+
   // the owner's groups that can still make the result
-  Scratch lead_keys, lead_state;
-  const uint64_t n_lead = state_leading_rows(owned.st, lead_keys, lead_state);
+  const bool wtwo = w.key_words == 2;
+  const int wwidth = 1 + (wtwo ? 1 : 0) + w.n_slots;
+  Scratch lead_keys, lead_hi, lead_state;
+  const uint64_t n_lead = state_leading_rows(work, lead_keys, lead_hi, lead_state);
   std::vector<int64_t> lead_all(world);
   const int64_t n_lead_i = (int64_t)n_lead;
   allgather_small(c, &n_lead_i, 1, lead_all.data());
@@ -384,15 +420,22 @@ int execute_sharded(prism_gpu_comm* c, prism_gpu_plan* plan, prism_gpu_table* ta
   uint64_t root_total = 0;
   if (rank == root)
     for (int s = 0; s < world; ++s) root_total += from_all[s] = (uint64_t)lead_all[s];
-  // keys and slot columns sit in two blocks: sent as two column sets
-  Scratch gathered(ctx, std::max<uint64_t>(1, root_total) * 8 * (uint64_t)width);
-  alltoallv_columns(c, 1, lead_keys.as<uint64_t>(), n_lead, to_root, gathered.as<uint64_t>(), root_total, from_all);
-  alltoallv_columns(c, v.n_slots, lead_state.as<uint64_t>(), n_lead, to_root, gathered.as<uint64_t>() + root_total, root_total, from_all);
+  // keys, high words and slot columns sit in separate blocks: sent as separate column sets
+  Scratch gathered(ctx, std::max<uint64_t>(1, root_total) * 8 * (uint64_t)wwidth);
+  uint64_t* const gk = gathered.as<uint64_t>();
+  alltoallv_columns(c, 1, lead_keys.as<uint64_t>(), n_lead, to_root, gk, root_total, from_all);
+  if (wtwo) alltoallv_columns(c, 1, lead_hi.as<uint64_t>(), n_lead, to_root, gk + root_total, root_total, from_all);
+  alltoallv_columns(c, w.n_slots, lead_state.as<uint64_t>(), n_lead, to_root, gk + (wtwo ? 2 : 1) * root_total, root_total, from_all);
   PRISM_HIP(hipStreamSynchronize(ctx->stream));
   if (rank != root) return done(0);
-  StateGuard final_state;
-  final_state.st = aggregate_state(plan, table, &no_partition, 1, agreed.data());
-  state_merge(final_state.st, gathered.p, root_total);
+  StateGuard empty_inner, final_state;
+  if (v.distinct == 1) {
+    empty_inner.st = aggregate_state(plan, table, &no_partition, 1, agreed.data());
+    final_state.st = state_distinct_outer(empty_inner.st);
+  } else {
+    final_state.st = aggregate_state(plan, table, &no_partition, 1, agreed.data());
+  }
+  state_merge_rows(final_state.st, gk, wtwo ? gk + root_total : nullptr, (const int64_t*)(gk + (wtwo ? 2 : 1) * root_total), root_total);
   state_finish(final_state.st, out);
   return done(1);
 }

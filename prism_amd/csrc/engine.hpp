@@ -191,14 +191,23 @@ struct StateView {
   int64_t* dense_state = nullptr;
   uint64_t dense_stride = 0;
   const uint64_t* keys = nullptr;
+  const uint64_t* keys_hi = nullptr;  // two-word keys
   const int64_t* state = nullptr;
   std::vector<int> slot_ops;  // SlotOp per slot
+  int key_words = 1;
+  int distinct = 0;    // 1: the set of (x, group) pairs of a COUNT(DISTINCT) plan, 2: its per-group counts
+  int pair_shift = 0;  // distinct == 1, one-word pairs: the group key sits above this bit
 };
 StateView state_view(prism_gpu_state* st);
+// Rows in compact form merged into a state (high words for two-word keys, else null).
+void state_merge_rows(prism_gpu_state* st, const uint64_t* src_keys, const uint64_t* src_keys_hi, const int64_t* src_state,
+                      uint64_t n_groups);
+// COUNT(DISTINCT): the pair set folded into a new state that counts the pairs per group.
+prism_gpu_state* state_distinct_outer(prism_gpu_state* inner);
 // The groups of a hash state that can still appear in the plan's result: all of them, or,
 // with ORDER BY .. LIMIT over a column the device can rank, the leading ones (ties at the
 // cut included).  Compact form in fresh blocks: keys[n], state[n_slots][n]; returns n.
-uint64_t state_leading_rows(prism_gpu_state* st, struct Scratch& out_keys, struct Scratch& out_state);
+uint64_t state_leading_rows(prism_gpu_state* st, struct Scratch& out_keys, struct Scratch& out_keys_hi, struct Scratch& out_state);
 
 // FNV-1a over the dictionary values of a string column, in code order.
 void table_dictionary_digest(prism_gpu_table* table, int column, uint64_t* digest, uint32_t* n_values);

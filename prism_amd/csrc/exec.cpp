@@ -1231,6 +1231,92 @@ uint64_t partitioned_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, AggParam
   return groups;
 }
 
+// ---- COUNT(DISTINCT x) GROUP BY keys: the outer level over the set of (x, keys) pairs ----
+// The pair is packed with x in the low bits of a one-word key (the group key above it), or
+// x alone in the low word of a two-word key.
+struct DistinctShape {
+  bool two_words;
+  int x_bits, k_bits, x_null_bit;
+};
+
+DistinctShape distinct_shape(const KeyLayout& layout) {
+  const KeyField& xf = layout.fields[0];
+  DistinctShape d;
+  d.two_words = layout.words == 2;
+  d.x_bits = d.two_words ? 0 : xf.bits + (xf.null_bit >= 0 ? 1 : 0);
+  d.k_bits = d.two_words ? layout.word_bits[1] : layout.total_bits - d.x_bits;
+  d.x_null_bit = xf.null_bit;
+  return d;
+}
+
+// Allocates the outer table (group key -> {pairs seen, pairs with a non-NULL x}) for pairs of this layout.
+void distinct_outer_alloc(prism_gpu_ctx* ctx, const KeyLayout& layout, uint64_t selected, GroupTable& q) {
+  const DistinctShape d = distinct_shape(layout);
+  const bool qdense = d.k_bits <= kDenseMaxBits;
+  const uint64_t qcap = qdense ? (1ull << d.k_bits)
+                               : pow2_ceil(std::max<uint64_t>(1024, 2 * std::min<uint64_t>(selected, d.k_bits < 63 ? (1ull << d.k_bits) : selected)));
+  table_alloc(ctx, q, qdense, qcap, {kSlotAddOne, kSlotAddOne});
+}
+
+// Counts the pairs of the set `gt` per group into a fresh outer table `q`.
+void distinct_fold_outer(prism_gpu_ctx* ctx, const KeyLayout& layout, uint64_t selected, const GroupTable& gt, GroupTable& q) {
+  const DistinctShape d = distinct_shape(layout);
+  distinct_outer_alloc(ctx, layout, selected, q);
+  DistinctFoldParams fp{};
+  fp.set_keys = gt.dense ? nullptr : gt.keys.as<uint64_t>();
+  fp.set_keys_hi = d.two_words ? gt.keys_hi.as<uint64_t>() : nullptr;
+  fp.set_capacity = gt.capacity + 1;
+  fp.set_special = gt.capacity;
+  fp.set_rowcount = gt.state.as<int64_t>();
+  fp.x_bits = d.x_bits;
+  fp.x_null_bit = d.x_null_bit;
+  fp.dense = q.dense ? 1 : 0;
+  fp.capacity = q.capacity;
+  fp.g_keys = q.keys.as<uint64_t>();
+  fp.g_state = q.state.as<int64_t>();
+  fp.overflow = q.overflow.as<uint32_t>();
+  fp.k_bits = d.k_bits;
+  if (gt.dense) {
+    // a dense (k, x) set has no key array; materialise its occupied entries first
+    GroupRows pairs = table_read(ctx, gt);
+    Scratch d_pairs(ctx, std::max<uint64_t>(1, pairs.n) * 8);
+    if (pairs.n) PRISM_HIP(hipMemcpyAsync(d_pairs.p, pairs.keys.data(), pairs.n * 8, hipMemcpyHostToDevice, ctx->stream));
+    fp.set_keys = d_pairs.as<uint64_t>();
+    fp.set_capacity = pairs.n;
+    fp.set_special = ~0ull;
+    if (pairs.n) launch_distinct_fold(ctx, fp);
+    PRISM_HIP(hipStreamSynchronize(ctx->stream));
+  } else {
+    launch_distinct_fold(ctx, fp);
+  }
+  if (table_overflowed(ctx, q)) fail(PRISM_GPU_EINTERNAL, "distinct group table overflow");
+}
+
+// Reads the outer table and appends the result rows (group keys, then the distinct count for
+// every aggregate of the plan).  Returns the number of groups.
+uint64_t distinct_emit_outer(prism_gpu_ctx* ctx, const prism_gpu_plan* plan, const prism_gpu_table* table,
+                             const std::vector<KeySrc>& keys, const KeyLayout& layout, const GroupTable& q, std::vector<OutColumn>& cols) {
+  const DistinctShape d = distinct_shape(layout);
+  GroupRows g = table_read(ctx, q);
+  // unpack keys from the high bits: shift the layout down by x_bits
+  KeyLayout kl;
+  for (size_t i = 1; i < layout.fields.size(); ++i) {
+    KeyField f = layout.fields[i];
+    f.word = 0;  // the outer table's key is the group key alone, in one word
+    if (f.bits) f.bit_pos -= d.x_bits;
+    if (f.null_bit >= 0) f.null_bit -= d.x_bits;
+    kl.fields.push_back(f);
+  }
+  append_key_columns(table, keys, kl, 0, g, cols, 0);
+  for (size_t a = 0; a < plan->aggs.size(); ++a) {
+    OutColumn& oc = cols[keys.size() + a];
+    const int64_t* v = g.state.data() + (size_t)g.n;  // slot 1 = distinct count
+    oc.i64.insert(oc.i64.end(), v, v + g.n);
+    oc.valid.resize(oc.valid.size() + g.n, 1);
+  }
+  return g.n;
+}
+
 }  // namespace
 
 }  // namespace prism
@@ -1244,10 +1330,14 @@ struct prism_gpu_state {
   prism::Lowered low;
   prism::GroupTable gt;
   std::vector<int> slot_ops;
-  // the occupied groups in compact form (hash tables): [n] keys, [n_slots][n] accumulators
+  // the occupied groups in compact form (hash tables): [n] keys ([n] high words), [n_slots][n] accumulators
   bool compacted = false;
   uint64_t c_n = 0;
-  prism::Scratch c_keys, c_state;
+  prism::Scratch c_keys, c_keys_hi, c_state;
+  // COUNT(DISTINCT): 1 = the table is the set of (x, group) pairs, 2 = the table counts the
+  // pairs per group (slot 0: pairs folded in, slot 1: the distinct count)
+  int distinct = 0;
+  uint64_t selected = 0;  // rows that went into the set (sizes the outer table)
 };
 
 namespace prism {
@@ -1410,8 +1500,7 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
   // (ctx_override: a child context of the plan's, for partitions that stream concurrently)
   prism_gpu_ctx* ctx = ctx_override ? ctx_override : plan->ctx;
   bind(ctx);
-  if (capture && (plan->keys.empty() || plan->distinct_plan))
-    fail(PRISM_GPU_EUNSUPPORTED, "device-resident aggregate state needs a GROUP BY without COUNT(DISTINCT)");
+  if (capture && plan->keys.empty()) fail(PRISM_GPU_EUNSUPPORTED, "device-resident aggregate state needs a GROUP BY");
   HostTimer whole(ctx, "host:execute");
   if (table->ctx != ctx) fail(PRISM_GPU_EINVAL, "plan and table belong to different contexts");
   const std::vector<FieldType>& expect = merge_input ? plan->partial_fields : plan->fields;
@@ -1777,7 +1866,6 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
     // lands with the next synchronisation of the stream (every path below has one before the statistics)
     if (fused) PRISM_HIP(hipMemcpyAsync(&fused_selected, d_scalar.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     if (capture) {
-      if (layout.words != 1) fail(PRISM_GPU_EUNSUPPORTED, "device-resident aggregate state needs a packed key of at most 64 bits");
       PRISM_HIP(hipStreamSynchronize(ctx->stream));
       collect_timings(ctx);
       auto st = std::make_unique<prism_gpu_state>();
@@ -1789,6 +1877,8 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       st->gt = std::move(gt);
       st->slot_ops = slot_ops;
       if (fused) selected = fused_selected;
+      st->distinct = plan->distinct_plan ? 1 : 0;
+      st->selected = selected;
       {
         std::lock_guard<std::mutex> g(ctx->mu);
         ctx->stats.rows_scanned += ss.rows;
@@ -1807,61 +1897,9 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       groups_out = g.n;
     } else {
       // outer GROUP BY keys: COUNT(x) over the distinct pairs
-      const KeyField& xf = layout.fields[0];
-      const bool two_words = layout.words == 2;
-      int x_bits = two_words ? 0 : xf.bits + (xf.null_bit >= 0 ? 1 : 0);
-      int k_bits = two_words ? layout.word_bits[1] : total_bits - x_bits;
       GroupTable q;
-      bool qdense = k_bits <= kDenseMaxBits;
-      uint64_t qcap = qdense ? (1ull << k_bits) : pow2_ceil(std::max<uint64_t>(1024, 2 * std::min<uint64_t>(selected, k_bits < 63 ? (1ull << k_bits) : selected)));
-      table_alloc(ctx, q, qdense, qcap, {kSlotAddOne, kSlotAddOne});
-      DistinctFoldParams fp{};
-      fp.set_keys = gt.dense ? nullptr : gt.keys.as<uint64_t>();
-      fp.set_keys_hi = two_words ? gt.keys_hi.as<uint64_t>() : nullptr;
-      fp.set_capacity = gt.capacity + 1;
-      fp.set_special = gt.capacity;
-      fp.set_rowcount = gt.state.as<int64_t>();
-      fp.x_bits = x_bits;
-      fp.x_null_bit = xf.null_bit;
-      fp.dense = qdense ? 1 : 0;
-      fp.capacity = qcap;
-      fp.g_keys = q.keys.as<uint64_t>();
-      fp.g_state = q.state.as<int64_t>();
-      fp.overflow = q.overflow.as<uint32_t>();
-      fp.k_bits = k_bits;
-      GroupRows pairs;  // dense sets are folded on the host side of the emit: read them as rows
-      if (gt.dense) {
-        // a dense (k, x) set has no key array; materialise its occupied entries first
-        pairs = table_read(ctx, gt);
-        Scratch d_pairs(ctx, std::max<uint64_t>(1, pairs.n) * 8);
-        if (pairs.n) PRISM_HIP(hipMemcpyAsync(d_pairs.p, pairs.keys.data(), pairs.n * 8, hipMemcpyHostToDevice, ctx->stream));
-        fp.set_keys = d_pairs.as<uint64_t>();
-        fp.set_capacity = pairs.n;
-        fp.set_special = ~0ull;
-        if (pairs.n) launch_distinct_fold(ctx, fp);
-        PRISM_HIP(hipStreamSynchronize(ctx->stream));
-      } else {
-        launch_distinct_fold(ctx, fp);
-      }
-      if (table_overflowed(ctx, q)) fail(PRISM_GPU_EINTERNAL, "distinct group table overflow");
-      GroupRows g = table_read(ctx, q);
-      // unpack keys from the high bits: shift the layout down by x_bits
-      KeyLayout kl;
-      for (size_t i = 1; i < layout.fields.size(); ++i) {
-        KeyField f = layout.fields[i];
-        f.word = 0;  // the outer table's key is the group key alone, in one word
-        if (f.bits) f.bit_pos -= x_bits;
-        if (f.null_bit >= 0) f.null_bit -= x_bits;
-        kl.fields.push_back(f);
-      }
-      append_key_columns(table, keys, kl, 0, g, cols, 0);
-      for (size_t a = 0; a < plan->aggs.size(); ++a) {
-        OutColumn& oc = cols[keys.size() + a];
-        const int64_t* v = g.state.data() + (size_t)g.n;  // slot 1 = distinct count
-        oc.i64.insert(oc.i64.end(), v, v + g.n);
-        oc.valid.resize(oc.valid.size() + g.n, 1);
-      }
-      groups_out = g.n;
+      distinct_fold_outer(ctx, layout, selected, gt, q);
+      groups_out = distinct_emit_outer(ctx, plan, table, keys, layout, q, cols);
     }
   }
   PRISM_HIP(hipStreamSynchronize(ctx->stream));
@@ -2000,18 +2038,21 @@ void state_compact(prism_gpu_state* st) {
   const GroupTable& g = st->gt;
   Scratch d_count(ctx, 256);
   PRISM_HIP(hipMemsetAsync(d_count.p, 0, 8, ctx->stream));
-  launch_emit(ctx, g.dense, g.capacity, g.keys.as<uint64_t>(), nullptr, g.state.as<int64_t>(), g.n_slots, nullptr, nullptr,
-              nullptr, 0, d_count.as<unsigned long long>());
+  const bool two = g.key_words == 2;
+  launch_emit(ctx, g.dense, g.capacity, g.keys.as<uint64_t>(), two ? g.keys_hi.as<uint64_t>() : nullptr, g.state.as<int64_t>(),
+              g.n_slots, nullptr, nullptr, nullptr, 0, d_count.as<unsigned long long>());
   unsigned long long n = 0;
   PRISM_HIP(hipMemcpyAsync(&n, d_count.p, 8, hipMemcpyDeviceToHost, ctx->stream));
   PRISM_HIP(hipStreamSynchronize(ctx->stream));
   st->c_n = n;
   st->c_keys = Scratch(ctx, std::max<uint64_t>(1, n) * 8);
+  st->c_keys_hi = two ? Scratch(ctx, std::max<uint64_t>(1, n) * 8) : Scratch();
   st->c_state = Scratch(ctx, std::max<uint64_t>(1, n) * 8 * g.n_slots);
   if (n) {
     PRISM_HIP(hipMemsetAsync(d_count.p, 0, 8, ctx->stream));
-    launch_emit(ctx, g.dense, g.capacity, g.keys.as<uint64_t>(), nullptr, g.state.as<int64_t>(), g.n_slots,
-                st->c_keys.as<uint64_t>(), nullptr, st->c_state.as<int64_t>(), n, d_count.as<unsigned long long>());
+    launch_emit(ctx, g.dense, g.capacity, g.keys.as<uint64_t>(), two ? g.keys_hi.as<uint64_t>() : nullptr, g.state.as<int64_t>(),
+                g.n_slots, st->c_keys.as<uint64_t>(), two ? st->c_keys_hi.as<uint64_t>() : nullptr, st->c_state.as<int64_t>(), n,
+                d_count.as<unsigned long long>());
     PRISM_HIP(hipStreamSynchronize(ctx->stream));
   }
   st->compacted = true;
@@ -2022,6 +2063,7 @@ MergeParams merge_params(const prism_gpu_state* st, const GroupTable& g) {
   mp.dense = g.dense ? 1 : 0;
   mp.capacity = g.capacity;
   mp.g_keys = g.keys.as<uint64_t>();
+  mp.g_keys_hi = g.key_words == 2 ? g.keys_hi.as<uint64_t>() : nullptr;
   mp.g_state = g.state.as<int64_t>();
   mp.overflow = g.overflow.as<uint32_t>();
   mp.n_slots = g.n_slots;
@@ -2060,6 +2102,9 @@ prism_gpu_state* aggregate_state(prism_gpu_plan* plan, prism_gpu_table* table, c
 
 void state_describe(prism_gpu_state* st, prism_gpu_state_info* out) {
   bind(st->plan->ctx);
+  if (st->distinct || st->gt.key_words != 1)
+    fail(PRISM_GPU_EUNSUPPORTED, "states of COUNT(DISTINCT) plans and of keys wider than 64 bits are exchanged by "
+                                 "prism_gpu_execute_sharded only: they can be finished, not exported");
   std::memset(out, 0, sizeof(*out));
   out->dense = st->gt.dense ? 1 : 0;
   out->n_slots = st->gt.n_slots;
@@ -2113,20 +2158,27 @@ void state_import(prism_gpu_state* st, const void* device_src, size_t bytes) {
 }
 
 void state_merge(prism_gpu_state* st, const void* device_src, uint64_t n_groups) {
+  if (st->distinct || st->gt.key_words != 1)
+    fail(PRISM_GPU_EUNSUPPORTED, "rows can be merged into states of plain GROUP BY plans with keys of at most 64 bits");
+  state_merge_rows(st, (const uint64_t*)device_src, nullptr, (const int64_t*)device_src + n_groups, n_groups);
+}
+
+void state_merge_rows(prism_gpu_state* st, const uint64_t* src_keys, const uint64_t* src_keys_hi, const int64_t* src_state,
+                      uint64_t n_groups) {
   prism_gpu_ctx* ctx = st->plan->ctx;
   bind(ctx);
   if (n_groups == 0) return;
-  const uint64_t* src_keys = (const uint64_t*)device_src;
-  const int64_t* src_state = (const int64_t*)device_src + n_groups;
+  if ((st->gt.key_words == 2) != (src_keys_hi != nullptr)) fail(PRISM_GPU_EINTERNAL, "merged rows and state differ in key width");
   if (!st->gt.dense) {
     // room for every incoming group being new; otherwise rebuild a larger table first
     state_compact(st);
     const uint64_t need = st->c_n + n_groups;
     if (st->gt.list || need * 2 > st->gt.capacity) {
       GroupTable bigger;
-      table_alloc(ctx, bigger, false, pow2_ceil(std::max<uint64_t>(1024, need * 2)), st->slot_ops, 1);
+      table_alloc(ctx, bigger, false, pow2_ceil(std::max<uint64_t>(1024, need * 2)), st->slot_ops, st->gt.key_words);
       MergeParams own = merge_params(st, bigger);
       own.src_keys = st->c_keys.as<uint64_t>();
+      own.src_keys_hi = st->gt.key_words == 2 ? st->c_keys_hi.as<uint64_t>() : nullptr;
       own.src_state = st->c_state.as<int64_t>();
       own.n = st->c_n;
       launch_merge_packed(ctx, own);
@@ -2136,6 +2188,7 @@ void state_merge(prism_gpu_state* st, const void* device_src, uint64_t n_groups)
   }
   MergeParams mp = merge_params(st, st->gt);
   mp.src_keys = src_keys;
+  mp.src_keys_hi = src_keys_hi;
   mp.src_state = src_state;
   mp.n = n_groups;
   launch_merge_packed(ctx, mp);
@@ -2157,7 +2210,16 @@ void state_finish(prism_gpu_state* st, ArrowArray* out) {
   bind(ctx);
   HostTimer whole(ctx, "host:state_finish");
   std::vector<OutColumn> cols = make_columns(plan->final_fields);
-  const uint64_t groups = emit_groups(ctx, plan, st->table, st->keys, st->layout, st->low, st->gt, false, cols);
+  uint64_t groups;
+  if (st->distinct == 1) {
+    GroupTable q;
+    distinct_fold_outer(ctx, st->layout, st->selected, st->gt, q);
+    groups = distinct_emit_outer(ctx, plan, st->table, st->keys, st->layout, q, cols);
+  } else if (st->distinct == 2) {
+    groups = distinct_emit_outer(ctx, plan, st->table, st->keys, st->layout, st->gt, cols);
+  } else {
+    groups = emit_groups(ctx, plan, st->table, st->keys, st->layout, st->low, st->gt, false, cols);
+  }
   PRISM_HIP(hipStreamSynchronize(ctx->stream));
   collect_timings(ctx);
   sort_and_limit(plan, cols);
@@ -2173,6 +2235,25 @@ void state_free(prism_gpu_state* st) {
   delete st;
 }
 
+prism_gpu_state* state_distinct_outer(prism_gpu_state* inner) {
+  if (inner->distinct != 1) fail(PRISM_GPU_EINTERNAL, "not the pair set of a COUNT(DISTINCT) plan");
+  prism_gpu_ctx* ctx = inner->plan->ctx;
+  bind(ctx);
+  auto st = std::make_unique<prism_gpu_state>();
+  st->plan = inner->plan;
+  st->table = inner->table;
+  st->keys = inner->keys;
+  st->layout = inner->layout;  // (the pairs' layout: the outer rows are unpacked relative to it)
+  st->low = inner->low;
+  st->slot_ops = {kSlotAddOne, kSlotAddOne};
+  st->distinct = 2;
+  st->selected = inner->selected;
+  distinct_fold_outer(ctx, inner->layout, inner->selected, inner->gt, st->gt);
+  PRISM_HIP(hipStreamSynchronize(ctx->stream));
+  collect_timings(ctx);
+  return st.release();
+}
+
 StateView state_view(prism_gpu_state* st) {
   bind(st->plan->ctx);
   StateView v;
@@ -2180,6 +2261,9 @@ StateView state_view(prism_gpu_state* st) {
   v.dense = st->gt.dense;
   v.n_slots = st->gt.n_slots;
   v.slot_ops = st->slot_ops;
+  v.key_words = st->gt.key_words;
+  v.distinct = st->distinct;
+  if (st->distinct == 1) v.pair_shift = distinct_shape(st->layout).x_bits;
   if (v.dense) {
     v.entries = st->gt.capacity;
     v.dense_state = st->gt.state.as<int64_t>();
@@ -2188,12 +2272,13 @@ StateView state_view(prism_gpu_state* st) {
     state_compact(st);
     v.entries = st->c_n;
     v.keys = st->c_keys.as<uint64_t>();
+    v.keys_hi = st->gt.key_words == 2 ? st->c_keys_hi.as<uint64_t>() : nullptr;
     v.state = st->c_state.as<int64_t>();
   }
   return v;
 }
 
-uint64_t state_leading_rows(prism_gpu_state* st, Scratch& out_keys, Scratch& out_state) {
+uint64_t state_leading_rows(prism_gpu_state* st, Scratch& out_keys, Scratch& out_keys_hi, Scratch& out_state) {
   prism_gpu_plan* plan = st->plan;
   prism_gpu_ctx* ctx = plan->ctx;
   bind(ctx);
@@ -2202,10 +2287,16 @@ uint64_t state_leading_rows(prism_gpu_state* st, Scratch& out_keys, Scratch& out
   const uint64_t entries = g.capacity + 1;
   TopKOrder order;
   std::vector<OutColumn> cols = make_columns(plan->final_fields);
-  if (!(entries >= kTopKMinEntries && topk_order(plan, st->table, st->keys, st->layout, st->low, cols, order))) {
+  // (the device ranks groups of plain one-word states; the others send every group)
+  if (st->distinct || g.key_words != 1 ||
+      !(entries >= kTopKMinEntries && topk_order(plan, st->table, st->keys, st->layout, st->low, cols, order))) {
     state_compact(st);
     out_keys = Scratch(ctx, std::max<uint64_t>(1, st->c_n) * 8);
     out_state = Scratch(ctx, std::max<uint64_t>(1, st->c_n) * 8 * (uint64_t)g.n_slots);
+    if (g.key_words == 2) {
+      out_keys_hi = Scratch(ctx, std::max<uint64_t>(1, st->c_n) * 8);
+      if (st->c_n) PRISM_HIP(hipMemcpyAsync(out_keys_hi.p, st->c_keys_hi.p, st->c_n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    }
     if (st->c_n) {
       PRISM_HIP(hipMemcpyAsync(out_keys.p, st->c_keys.p, st->c_n * 8, hipMemcpyDeviceToDevice, ctx->stream));
       PRISM_HIP(hipMemcpyAsync(out_state.p, st->c_state.p, st->c_n * 8 * (uint64_t)g.n_slots, hipMemcpyDeviceToDevice, ctx->stream));

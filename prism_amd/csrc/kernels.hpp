@@ -359,6 +359,9 @@ struct MergeParams {
   const uint64_t* src_keys;
   const int64_t* src_state;
   uint64_t n;
+  // two-word keys (null otherwise): the table's and the source's high words
+  uint64_t* g_keys_hi;
+  const uint64_t* src_keys_hi;
 };
 void launch_merge_packed(prism_gpu_ctx* ctx, const MergeParams& p);
 
@@ -366,9 +369,24 @@ void launch_merge_packed(prism_gpu_ctx* ctx, const MergeParams& p);
 // counts[world] receives the rows per owner; the scatter writes the rows grouped by owner,
 // in the same column layout, with cursor[world] holding each owner's first place on entry
 // (and one past its last on exit).
-void launch_owner_count(prism_gpu_ctx* ctx, const uint64_t* keys, uint64_t n, uint32_t world, unsigned long long* counts);
-void launch_owner_scatter(prism_gpu_ctx* ctx, const uint64_t* keys, const int64_t* state, uint64_t n, int n_slots, uint32_t world,
-                          unsigned long long* cursor, uint64_t* out_keys, int64_t* out_state);
+// What a row's owner is derived from: the key (kOwnerKey; both words of a two-word key), or the
+// part of it that names the group of a COUNT(DISTINCT) pair, so that all pairs of a group meet
+// on one rank: the bits above `shift` of a one-word pair (kOwnerHighBits), the high word of a
+// two-word pair (kOwnerHighWord).
+enum OwnerOf { kOwnerKey = 0, kOwnerHighBits = 1, kOwnerHighWord = 2 };
+struct OwnerParams {
+  const uint64_t* keys;
+  const uint64_t* keys_hi;  // null: one-word keys
+  const int64_t* state;
+  uint64_t n;
+  int n_slots;
+  uint32_t world;
+  int owner_of;  // OwnerOf
+  int shift;
+};
+void launch_owner_count(prism_gpu_ctx* ctx, const OwnerParams& p, unsigned long long* counts);
+void launch_owner_scatter(prism_gpu_ctx* ctx, const OwnerParams& p, unsigned long long* cursor, uint64_t* out_keys,
+                          uint64_t* out_keys_hi, int64_t* out_state);
 
 // Fills n entries with `value`.
 void launch_fill_i64(prism_gpu_ctx* ctx, int64_t* dst, uint64_t n, int64_t value);

@@ -437,7 +437,17 @@ __global__ __launch_bounds__(kBlock) void k_merge_packed(MergeParams p) {
     // a dense table is indexed by the key itself: a key beyond it comes from a state that
     // was packed from other statistics, and must not be written anywhere
     if (p.dense && key >= p.capacity) { *p.overflow = 2u; continue; }
-    const uint64_t e = global_entry_raw(p.dense, p.capacity, p.g_keys, p.overflow, key);
+    uint64_t e;
+    if (p.g_keys_hi) {
+      AggParams t{};  // what the two-word look-up reads of its parameters
+      t.capacity = p.capacity;
+      t.g_keys = p.g_keys;
+      t.g_keys_hi = p.g_keys_hi;
+      t.overflow = p.overflow;
+      e = global_entry2(t, key, p.src_keys_hi[i]);
+    } else {
+      e = global_entry_raw(p.dense, p.capacity, p.g_keys, p.overflow, key);
+    }
     if (e == ~0ull) continue;
     for (int s = 0; s < p.n_slots; ++s) {
       const int op = p.ops[s];

@@ -57,15 +57,36 @@ def test_plans_without_device_state_are_refused_before_any_collective(gpu_ctx, l
     t, g = loaded
     comm = Comm.rccl(gpu_ctx, Comm.unique_id(), 0, 1)
     try:
-        for q in (QueryPlan([count_star()]), QueryPlan([count_distinct("user")], keys=["service"])):
+        plan = Plan(gpu_ctx, t.schema, QueryPlan([count_star(), sum_("value")]))  # no GROUP BY
+        try:
+            with pytest.raises(PrismGpuError) as e:
+                plan.execute_sharded(comm, g)
+            assert e.value.code == abi.EUNSUPPORTED
+        finally:
+            plan.close()
+        assert comm.stats()["collectives"] == 0
+    finally:
+        comm.close()
+
+
+def test_count_distinct_and_wide_keys_through_the_sharded_entry_point(gpu_ctx, loaded):
+    """One rank: the pair set is folded where it is; keys wider than 64 bits keep both words."""
+    from oracle import pyoracle
+    from prism_amd.engine import Comm, Plan
+
+    t, g = loaded
+    comm = Comm.rccl(gpu_ctx, Comm.unique_id(), 0, 1)
+    try:
+        for q, n_keys in [(QueryPlan([count_distinct("user")], keys=["service"]), 1),
+                          (QueryPlan([count_distinct("i16")], keys=["service"]), 1),
+                          (QueryPlan([count_distinct("value")], keys=[date_bin(3_600_000, "ts"), "service"]), 2),
+                          (QueryPlan([count_star(), max_("i32")], keys=["user", "value", "ts"]), 3)]:
             plan = Plan(gpu_ctx, t.schema, q)
             try:
-                with pytest.raises(PrismGpuError) as e:
-                    plan.execute_sharded(comm, g)
-                assert e.value.code == abi.EUNSUPPORTED
+                got = plan.execute_sharded(comm, g)
             finally:
                 plan.close()
-        assert comm.stats()["collectives"] == 0
+            assert_tables_match(got, pyoracle.execute(t, q), n_keys)
     finally:
         comm.close()
 
@@ -109,7 +130,8 @@ def _rank_worker(rank: int, world: int, port: int, q):
     from prism_amd import workloads
     from prism_amd.distributed import exchange_and_finish, make_comm
     from prism_amd.engine import Context, Plan
-    from prism_amd.plan import QueryPlan as Q, avg as avg_, count_star as cs, max_ as mx, min_ as mn, sum_ as sm
+    from prism_amd.plan import (QueryPlan as Q, avg as avg_, count_distinct as cd, count_star as cs, date_bin as db, max_ as mx,
+                                min_ as mn, sum_ as sm)
     from tests.helpers import assert_tables_match, assert_topk_match
 
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
@@ -118,11 +140,18 @@ def _rank_worker(rank: int, world: int, port: int, q):
     try:
         c3 = workloads.c3(id_bits=16)
         c2 = workloads.c2()
+        c5 = workloads.c5(n_services=16, user_bits=14)
         cases = [
             (c2, c2.query, 400_000, 2, 0),                                                        # dense: in-place reduce
             (c3, c3.query, 300_000, 1, 0),                                                        # hash, ORDER BY .. LIMIT
             (c3, Q([cs(), mx("UserID"), avg_("UserID"), mn("UserID"), sm("UserID")], keys=["UserID"]), 300_000, 1, world - 1),
             (c3, Q([cs()], keys=["UserID"], order_by=0, descending=False, limit=5), 200_000, 1, 0),  # ordered by the key
+            # COUNT(DISTINCT): pairs dealt to the owner of their group, counted there.  One-word pairs
+            # in a dense set (reduced in place), in a hash set; two-word pairs (a 63-bit id): C5's shape
+            (c2, Q([cd("value")], keys=["service"]), 200_000, 1, 0),
+            (c2, Q([cd("value")], keys=[db(60_000, "timestamp"), "service"]), 200_000, 2, world - 1),
+            (c5, c5.query, 300_000, 2, 0),
+            (c5, Q([cs()], keys=["user", "service"]), 200_000, 2, 0),                              # plain two-word keys
         ]
         for wl, query, rows, n_keys, root in cases:
             total = rows * world
@@ -130,13 +159,13 @@ def _rank_worker(rank: int, world: int, port: int, q):
             plan = Plan(ctx, wl.schema, query)
             try:
                 # the last rank of a three-rank world scans nothing in the first case
-                parts = [] if (world == 3 and rank == 2 and wl is c2) else None
+                parts = [] if (world == 3 and rank == 2 and query is c2.query) else None
                 got = exchange_and_finish(plan, table, parts, comm, root)
             finally:
                 plan.close()
                 table.close()
             if rank == root:
-                n_have = total if not (world == 3 and wl is c2) else rows * 2
+                n_have = total if not (world == 3 and query is c2.query) else rows * 2
                 st = pyoracle.SynthTable(wl.schema, wl.make_cols(), wl.seed, 0, n_have, total, n_parts=4)
                 try:
                     want, _ = st.execute(query)

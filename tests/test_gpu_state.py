@@ -163,14 +163,28 @@ def test_state_finish_applies_order_by_limit(gpu_ctx, loaded):
 
 
 def test_unsupported_plans_say_so(gpu_ctx, loaded):
+    from oracle import pyoracle
     from prism_amd.engine import Plan, PrismGpuError
 
     t, g = loaded
-    for q in (QueryPlan([count_star()]), QueryPlan([count_distinct("user")], keys=["service"])):
-        plan = Plan(gpu_ctx, t.schema, q)
+    plan = Plan(gpu_ctx, t.schema, QueryPlan([count_star()]))  # no GROUP BY: no group table to keep
+    try:
+        with pytest.raises(PrismGpuError) as e:
+            plan.aggregate(g)
+        assert e.value.code == -2
+    finally:
+        plan.close()
+    # COUNT(DISTINCT): the state (the set of pairs) can be finished, but has no export layout
+    q = QueryPlan([count_distinct("user")], keys=["service"])
+    plan = Plan(gpu_ctx, t.schema, q)
+    try:
+        st = plan.aggregate(g)
         try:
             with pytest.raises(PrismGpuError) as e:
-                plan.aggregate(g)
+                st.describe()
             assert e.value.code == -2
+            assert_tables_match(st.finish(), pyoracle.execute(t, q), 1)
         finally:
-            plan.close()
+            st.close()
+    finally:
+        plan.close()
