@@ -223,6 +223,24 @@ int prism_gpu_table_num_rows(const prism_gpu_table* table, uint64_t* out);
 int prism_gpu_table_num_partitions(const prism_gpu_table* table, uint32_t* out);
 void prism_gpu_table_free(prism_gpu_table* table);
 
+/* Parquet files decoded by the library itself: what ParquetExec does for the reference
+ * (table_provider.rs:110-131) on files shaped like prism-ingest's (ingest.rs:98-101: data
+ * page v2, dictionary pages with PLAIN fallback, Snappy).  `file` is the whole object in
+ * host memory (what one object_store GET returns).  Covered: flat schemas; INT32 / INT64 /
+ * BYTE_ARRAY columns (Int16 / UInt16 / Int32 / Int64 / Timestamp / Utf8 / Binary), required
+ * or optional; data pages v1 and v2; PLAIN and dictionary encodings; UNCOMPRESSED and SNAPPY;
+ * anything else is PRISM_GPU_EUNSUPPORTED and names the column.
+ *
+ * prism_gpu_table_append_parquet appends every row group as a chunk of `partition_id`;
+ * columns are matched to the table's by name (a table column the file lacks reads as NULLs;
+ * Binary / Utf8 and Int64 / Timestamp stand in for each other).
+ * prism_gpu_parquet_read only decodes, into one host RecordBatch with the file's own schema
+ * (no GPU involved; out_schema may be NULL). */
+int prism_gpu_table_append_parquet(prism_gpu_table* table, uint32_t partition_id,
+                                   const void* file, size_t file_len);
+int prism_gpu_parquet_read(const void* file, size_t file_len, struct ArrowSchema* out_schema,
+                           struct ArrowArray* out);
+
 /* ---- plans ---------------------------------------------------------------
  * Replaces the physical planning DataFusion does after TableProvider::scan
  * (table_provider.rs:73-132): FilterExec + AggregateExec (+ SortExec/Limit). */

@@ -287,6 +287,20 @@ int prism_gpu_table_dictionary_digest(prism_gpu_table* table, int32_t column, ui
   });
 }
 
+int prism_gpu_table_append_parquet(prism_gpu_table* table, uint32_t partition_id, const void* file, size_t file_len) {
+  return guarded([&] {
+    require(table && file, "null argument");
+    prism::table_append_parquet(table, partition_id, file, file_len);
+  });
+}
+
+int prism_gpu_parquet_read(const void* file, size_t file_len, struct ArrowSchema* out_schema, struct ArrowArray* out) {
+  return guarded([&] {
+    require(file && out, "null argument");
+    prism::parquet_read(file, file_len, out_schema, out);
+  });
+}
+
 // ---- collectives ----
 
 int prism_gpu_comm_unique_id(void* id_out) {

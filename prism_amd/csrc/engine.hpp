@@ -209,6 +209,10 @@ prism_gpu_state* state_distinct_outer(prism_gpu_state* inner);
 // cut included).  Compact form in fresh blocks: keys[n], state[n_slots][n]; returns n.
 uint64_t state_leading_rows(prism_gpu_state* st, struct Scratch& out_keys, struct Scratch& out_keys_hi, struct Scratch& out_state);
 
+// Parquet (parquet.cpp): decode on the host; append row groups as chunks.
+void parquet_read(const void* file, size_t len, ArrowSchema* out_schema, ArrowArray* out);
+void table_append_parquet(prism_gpu_table* table, uint32_t partition_id, const void* file, size_t len);
+
 // FNV-1a over the dictionary values of a string column, in code order.
 void table_dictionary_digest(prism_gpu_table* table, int column, uint64_t* digest, uint32_t* n_values);
 

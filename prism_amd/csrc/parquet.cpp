@@ -1,0 +1,718 @@
+// Parquet -> Arrow columns on the host, for files shaped like the ones prism-ingest writes
+// (src/prism-ingest/src/ingest.rs:98-101: writer version 2.0, i.e. data page v2; dictionary
+// pages with PLAIN fallback; Snappy) and the ones ParquetExec reads for the reference
+// (src/prism-query/src/providers/table_provider.rs:110-131).  It replaces, for this path, the
+// parquet 47.0.0 crate's reader (an un-vendored dependency, Cargo.lock:2114-2115): the
+// published format is restated here -- Thrift compact protocol for the footer and the page
+// headers, the RLE / bit-packed hybrid for definition levels and dictionary indices, PLAIN
+// values, raw Snappy blocks.
+//
+// Covered: flat schemas; INT32 / INT64 / BYTE_ARRAY columns, required or optional; data pages
+// v1 and v2; PLAIN, PLAIN_DICTIONARY / RLE_DICTIONARY; UNCOMPRESSED and SNAPPY.  Anything else
+// (nested columns, other physical types, encodings or codecs) is PRISM_GPU_EUNSUPPORTED and
+// names the column.
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "engine.hpp"
+
+namespace prism {
+
+namespace {
+
+[[noreturn]] void bad(const std::string& what) { fail(PRISM_GPU_EINVAL, "parquet: " + what); }
+[[noreturn]] void unsupported(const std::string& what) { fail(PRISM_GPU_EUNSUPPORTED, "parquet: " + what); }
+
+// ---- Thrift compact protocol ----------------------------------------------------------------
+struct Thrift {
+  const uint8_t* p;
+  const uint8_t* end;
+  uint8_t byte() {
+    if (p >= end) bad("truncated metadata");
+    return *p++;
+  }
+  uint64_t varint() {
+    uint64_t v = 0;
+    for (int shift = 0; shift < 64; shift += 7) {
+      const uint8_t b = byte();
+      v |= (uint64_t)(b & 0x7f) << shift;
+      if (!(b & 0x80)) return v;
+    }
+    bad("varint too long");
+  }
+  int64_t zigzag() {
+    const uint64_t v = varint();
+    return (int64_t)(v >> 1) ^ -(int64_t)(v & 1);
+  }
+  std::string binary() {
+    const uint64_t n = varint();
+    if (n > (uint64_t)(end - p)) bad("truncated string");
+    std::string s((const char*)p, (size_t)n);
+    p += n;
+    return s;
+  }
+  // Next field of a struct: false at the stop byte.  `type` is the compact type code.
+  bool field(int16_t& id, int& type) {
+    const uint8_t b = byte();
+    if (b == 0) return false;
+    type = b & 0x0f;
+    const int delta = b >> 4;
+    id = delta ? (int16_t)(id + delta) : (int16_t)zigzag();
+    return true;
+  }
+  void list_header(int& elem_type, uint64_t& n) {
+    const uint8_t b = byte();
+    elem_type = b & 0x0f;
+    n = b >> 4;
+    if (n == 15) n = varint();
+  }
+  void skip(int type) {
+    switch (type) {
+      case 1: case 2: return;  // booleans live in the field header
+      case 3: byte(); return;
+      case 4: case 5: case 6: varint(); return;
+      case 7: for (int i = 0; i < 8; ++i) byte(); return;
+      case 8: binary(); return;
+      case 9: case 10: {
+        int et; uint64_t n;
+        list_header(et, n);
+        for (uint64_t i = 0; i < n; ++i) {
+          if (et == 1 || et == 2) byte();  // booleans in a list take a byte each
+          else skip(et);
+        }
+        return;
+      }
+      case 11: {
+        const uint64_t n = varint();
+        if (n == 0) return;
+        const uint8_t kv = byte();
+        for (uint64_t i = 0; i < n; ++i) { skip(kv >> 4); skip(kv & 0x0f); }
+        return;
+      }
+      case 12: {
+        int16_t id = 0; int t;
+        while (field(id, t)) skip(t);
+        return;
+      }
+      default: bad("unknown thrift type");
+    }
+  }
+};
+
+// ---- file metadata --------------------------------------------------------------------------
+enum Physical { kBoolean = 0, kInt32 = 1, kInt64 = 2, kInt96 = 3, kFloat = 4, kDouble = 5, kByteArray = 6, kFixed = 7 };
+
+struct Leaf {
+  std::string name;
+  int physical = -1;
+  bool optional = true;
+  int converted = -1;
+  // logicalType union
+  bool is_string = false;
+  int ts_unit = 0;       // 1 ms, 2 us, 3 ns
+  int int_bits = 0;      // INTEGER(bitWidth, isSigned)
+  bool int_signed = true;
+};
+
+struct ChunkMeta {
+  int physical = -1;
+  int codec = 0;
+  int64_t num_values = 0, total_compressed = 0, data_page_offset = 0, dictionary_page_offset = 0;
+};
+
+struct RowGroupMeta {
+  int64_t num_rows = 0;
+  std::vector<ChunkMeta> chunks;
+};
+
+struct FileMeta {
+  std::vector<Leaf> leaves;
+  std::vector<RowGroupMeta> groups;
+  int64_t num_rows = 0;
+};
+
+void read_logical_type(Thrift& t, Leaf& leaf) {
+  int16_t id = 0; int ty;
+  while (t.field(id, ty)) {
+    if (id == 1 && ty == 12) { leaf.is_string = true; t.skip(ty); }
+    else if (id == 8 && ty == 12) {  // TimestampType {1: isAdjustedToUTC, 2: unit}
+      int16_t id2 = 0; int ty2;
+      while (t.field(id2, ty2)) {
+        if (id2 == 2 && ty2 == 12) {
+          int16_t id3 = 0; int ty3;
+          while (t.field(id3, ty3)) { leaf.ts_unit = id3; t.skip(ty3); }
+        } else t.skip(ty2);
+      }
+    } else if (id == 10 && ty == 12) {  // IntType {1: bitWidth (byte), 2: isSigned}
+      int16_t id2 = 0; int ty2;
+      while (t.field(id2, ty2)) {
+        if (id2 == 1 && ty2 == 3) leaf.int_bits = (int8_t)t.byte();
+        else if (id2 == 2 && (ty2 == 1 || ty2 == 2)) leaf.int_signed = ty2 == 1;
+        else t.skip(ty2);
+      }
+    } else t.skip(ty);
+  }
+}
+
+FileMeta read_footer(const uint8_t* file, size_t len) {
+  if (len < 12 || std::memcmp(file, "PAR1", 4) != 0 || std::memcmp(file + len - 4, "PAR1", 4) != 0) bad("not a Parquet file (magic bytes)");
+  uint32_t meta_len;
+  std::memcpy(&meta_len, file + len - 8, 4);
+  if ((uint64_t)meta_len + 12 > len) bad("footer length beyond the file");
+  Thrift t{file + len - 8 - meta_len, file + len - 8};
+  FileMeta fm;
+  int root_children = -1;
+  int16_t id = 0; int ty;
+  while (t.field(id, ty)) {
+    if (id == 2 && ty == 9) {  // schema
+      int et; uint64_t n;
+      t.list_header(et, n);
+      for (uint64_t i = 0; i < n; ++i) {
+        Leaf leaf;
+        int num_children = 0, repetition = 0;
+        int16_t id2 = 0; int ty2;
+        while (t.field(id2, ty2)) {
+          if (id2 == 1) leaf.physical = (int)t.zigzag();
+          else if (id2 == 3) repetition = (int)t.zigzag();
+          else if (id2 == 4) leaf.name = t.binary();
+          else if (id2 == 5) num_children = (int)t.zigzag();
+          else if (id2 == 6) leaf.converted = (int)t.zigzag();
+          else if (id2 == 10 && ty2 == 12) read_logical_type(t, leaf);
+          else t.skip(ty2);
+        }
+        if (i == 0) { root_children = num_children; continue; }
+        if (num_children > 0) unsupported("nested column `" + leaf.name + "`");
+        if (repetition == 2) unsupported("repeated column `" + leaf.name + "`");
+        leaf.optional = repetition == 1;
+        fm.leaves.push_back(leaf);
+      }
+    } else if (id == 3) {
+      fm.num_rows = t.zigzag();
+    } else if (id == 4 && ty == 9) {  // row groups
+      int et; uint64_t n;
+      t.list_header(et, n);
+      for (uint64_t g = 0; g < n; ++g) {
+        RowGroupMeta rg;
+        int16_t id2 = 0; int ty2;
+        while (t.field(id2, ty2)) {
+          if (id2 == 1 && ty2 == 9) {
+            int et2; uint64_t nc;
+            t.list_header(et2, nc);
+            for (uint64_t c = 0; c < nc; ++c) {
+              ChunkMeta cm;
+              int16_t id3 = 0; int ty3;
+              while (t.field(id3, ty3)) {
+                if (id3 == 3 && ty3 == 12) {  // ColumnMetaData
+                  int16_t id4 = 0; int ty4;
+                  while (t.field(id4, ty4)) {
+                    if (id4 == 1) cm.physical = (int)t.zigzag();
+                    else if (id4 == 4) cm.codec = (int)t.zigzag();
+                    else if (id4 == 5) cm.num_values = t.zigzag();
+                    else if (id4 == 7) cm.total_compressed = t.zigzag();
+                    else if (id4 == 9) cm.data_page_offset = t.zigzag();
+                    else if (id4 == 11) cm.dictionary_page_offset = t.zigzag();
+                    else t.skip(ty4);
+                  }
+                } else t.skip(ty3);
+              }
+              rg.chunks.push_back(cm);
+            }
+          } else if (id2 == 3) rg.num_rows = t.zigzag();
+          else t.skip(ty2);
+        }
+        fm.groups.push_back(rg);
+      }
+    } else t.skip(ty);
+  }
+  if (root_children < 0 || (size_t)root_children != fm.leaves.size()) bad("schema is not a flat list of columns");
+  for (const RowGroupMeta& rg : fm.groups)
+    if (rg.chunks.size() != fm.leaves.size()) bad("a row group does not hold every column");
+  return fm;
+}
+
+// The Arrow type a leaf reads as (what arrow-rs gives ParquetExec for it).
+FieldType leaf_field(const Leaf& l) {
+  const char* fmt = nullptr;
+  if (l.physical == kInt64) {
+    const bool ts = l.ts_unit != 0 || l.converted == 9 || l.converted == 10;
+    fmt = ts ? "tsm:" : "l";
+    if (!ts && (l.converted == 14 || (l.int_bits == 64 && !l.int_signed))) unsupported("UInt64 column `" + l.name + "`");
+  } else if (l.physical == kInt32) {
+    int bits = l.int_bits, sign = l.int_signed;
+    if (!bits) {
+      if (l.converted == 15) { bits = 8; sign = true; } else if (l.converted == 16) { bits = 16; sign = true; }
+      else if (l.converted == 11) { bits = 8; sign = false; } else if (l.converted == 12) { bits = 16; sign = false; }
+      else if (l.converted == 13) { bits = 32; sign = false; } else { bits = 32; sign = true; }
+    }
+    if (bits == 32 && !sign) unsupported("UInt32 column `" + l.name + "`");
+    fmt = bits <= 16 ? (sign ? "s" : "S") : "i";
+  } else if (l.physical == kByteArray) {
+    fmt = (l.is_string || l.converted == 0) ? "u" : "z";
+  } else {
+    unsupported("column `" + l.name + "` has a physical type other than INT32 / INT64 / BYTE_ARRAY");
+  }
+  FieldType f = field_from_format(fmt);
+  f.name = l.name;
+  f.nullable = true;
+  return f;
+}
+
+// ---- Snappy (raw block format) --------------------------------------------------------------
+void snappy_decompress(const uint8_t* src, size_t n, std::vector<uint8_t>& out, size_t expect) {
+  Thrift v{src, src + n};
+  const uint64_t total = v.varint();
+  if (total != expect) bad("Snappy block announces another size than the page header");
+  out.resize((size_t)total);
+  const uint8_t* p = v.p;
+  const uint8_t* end = src + n;
+  size_t o = 0;
+  while (p < end) {
+    const uint8_t tag = *p++;
+    if ((tag & 3) == 0) {
+      size_t l = tag >> 2;
+      if (l >= 60) {
+        const int extra = (int)l - 59;
+        if (end - p < extra) bad("truncated Snappy literal");
+        l = 0;
+        for (int i = 0; i < extra; ++i) l |= (size_t)p[i] << (8 * i);
+        p += extra;
+      }
+      l += 1;
+      if ((size_t)(end - p) < l || o + l > out.size()) bad("Snappy literal overruns");
+      std::memcpy(&out[o], p, l);
+      p += l;
+      o += l;
+    } else {
+      size_t l, off;
+      if ((tag & 3) == 1) {
+        if (end - p < 1) bad("truncated Snappy copy");
+        l = ((tag >> 2) & 7) + 4;
+        off = ((size_t)(tag >> 5) << 8) | *p++;
+      } else if ((tag & 3) == 2) {
+        if (end - p < 2) bad("truncated Snappy copy");
+        l = (tag >> 2) + 1;
+        off = (size_t)p[0] | ((size_t)p[1] << 8);
+        p += 2;
+      } else {
+        if (end - p < 4) bad("truncated Snappy copy");
+        l = (tag >> 2) + 1;
+        off = (size_t)p[0] | ((size_t)p[1] << 8) | ((size_t)p[2] << 16) | ((size_t)p[3] << 24);
+        p += 4;
+      }
+      if (off == 0 || off > o || o + l > out.size()) bad("Snappy copy out of range");
+      for (size_t i = 0; i < l; ++i) out[o + i] = out[o - off + i];  // may overlap: byte by byte
+      o += l;
+    }
+  }
+  if (o != out.size()) bad("Snappy block shorter than announced");
+}
+
+// ---- RLE / bit-packed hybrid ------------------------------------------------------------------
+// Decodes `count` values of `bit_width` bits from [p, end).
+void rle_decode(const uint8_t* p, const uint8_t* end, int bit_width, size_t count, std::vector<uint32_t>& out) {
+  out.resize(count);
+  if (bit_width == 0) { std::fill(out.begin(), out.end(), 0u); return; }
+  if (bit_width > 32) bad("bit width above 32");
+  size_t n = 0;
+  Thrift v{p, end};
+  const int value_bytes = (bit_width + 7) / 8;
+  while (n < count) {
+    const uint64_t h = v.varint();
+    if (h & 1) {  // bit-packed: groups of 8 values
+      const uint64_t groups = h >> 1;
+      const uint64_t bytes = groups * (uint64_t)bit_width;
+      if (bytes > (uint64_t)(v.end - v.p)) bad("bit-packed run beyond the page");
+      const uint8_t* b = v.p;
+      uint64_t bitpos = 0;
+      const uint64_t values = groups * 8;
+      for (uint64_t i = 0; i < values && n < count; ++i, bitpos += bit_width) {
+        uint64_t word = 0;
+        const uint64_t byte0 = bitpos >> 3;
+        const int avail = (int)std::min<uint64_t>(8, bytes - byte0);
+        std::memcpy(&word, b + byte0, avail);
+        out[n++] = (uint32_t)((word >> (bitpos & 7)) & ((1ull << bit_width) - 1ull));
+      }
+      v.p += bytes;
+    } else {
+      const uint64_t run = h >> 1;
+      if (v.end - v.p < value_bytes) bad("RLE run beyond the page");
+      uint32_t value = 0;
+      std::memcpy(&value, v.p, value_bytes);
+      v.p += value_bytes;
+      for (uint64_t i = 0; i < run && n < count; ++i) out[n++] = value;
+      if (run == 0) bad("empty RLE run");
+    }
+  }
+}
+
+// ---- one column of one row group ----------------------------------------------------------------
+struct PqColumn {
+  FieldType type;
+  std::vector<uint8_t> values;    // fixed width: type.width bytes per row
+  std::vector<int32_t> offsets;   // strings: rows + 1
+  std::vector<uint8_t> bytes;
+  std::vector<uint8_t> validity;  // bit per row, all rows present
+  int64_t nulls = 0;
+  int64_t rows = 0;
+};
+
+struct PageHeader {
+  int type = -1;
+  int32_t uncompressed = 0, compressed = 0;
+  int32_t num_values = 0, encoding = 0;
+  // v2
+  int32_t def_len = 0, rep_len = 0;
+  bool is_compressed = true;
+};
+
+PageHeader read_page_header(Thrift& t) {
+  PageHeader h;
+  int16_t id = 0; int ty;
+  while (t.field(id, ty)) {
+    if (id == 1) h.type = (int)t.zigzag();
+    else if (id == 2) h.uncompressed = (int32_t)t.zigzag();
+    else if (id == 3) h.compressed = (int32_t)t.zigzag();
+    else if ((id == 5 || id == 7) && ty == 12) {  // DataPageHeader / DictionaryPageHeader
+      int16_t id2 = 0; int ty2;
+      while (t.field(id2, ty2)) {
+        if (id2 == 1) h.num_values = (int32_t)t.zigzag();
+        else if (id2 == 2) h.encoding = (int)t.zigzag();
+        else t.skip(ty2);
+      }
+    } else if (id == 8 && ty == 12) {  // DataPageHeaderV2
+      int16_t id2 = 0; int ty2;
+      while (t.field(id2, ty2)) {
+        if (id2 == 1) h.num_values = (int32_t)t.zigzag();
+        else if (id2 == 4) h.encoding = (int)t.zigzag();
+        else if (id2 == 5) h.def_len = (int32_t)t.zigzag();
+        else if (id2 == 6) h.rep_len = (int32_t)t.zigzag();
+        else if (id2 == 7 && (ty2 == 1 || ty2 == 2)) h.is_compressed = ty2 == 1;
+        else t.skip(ty2);
+      }
+    } else t.skip(ty);
+  }
+  return h;
+}
+
+struct Dictionary {
+  std::vector<int64_t> ints;                          // INT32 / INT64
+  std::vector<std::pair<uint32_t, uint32_t>> spans;   // BYTE_ARRAY: offset, length into `bytes`
+  std::vector<uint8_t> bytes;
+  size_t size() const { return ints.empty() ? spans.size() : ints.size(); }
+};
+
+void store_fixed(PqColumn& col, int64_t v, const Leaf& leaf) {
+  if (leaf.ts_unit == 2 || (leaf.ts_unit == 0 && leaf.converted == 10)) v /= 1000;  // us -> ms, as arrow's cast does
+  else if (leaf.ts_unit == 3) v /= 1000000;
+  const int w = col.type.width;
+  const size_t at = col.values.size();
+  col.values.resize(at + w);
+  std::memcpy(&col.values[at], &v, w);  // little endian: the low bytes are the narrow value
+}
+
+void decode_chunk(const uint8_t* file, size_t len, const Leaf& leaf, const ChunkMeta& cm, int64_t rows, PqColumn& col) {
+  if (cm.codec != 0 && cm.codec != 1) unsupported("column `" + leaf.name + "` uses a codec other than UNCOMPRESSED / SNAPPY");
+  if (cm.physical != leaf.physical) bad("column chunk and schema disagree on the type of `" + leaf.name + "`");
+  const bool strings = leaf.physical == kByteArray;
+  int64_t pos = cm.data_page_offset;
+  if (cm.dictionary_page_offset > 0 && cm.dictionary_page_offset < pos) pos = cm.dictionary_page_offset;
+  const int64_t chunk_end = pos + cm.total_compressed;
+  if (pos < 4 || chunk_end > (int64_t)len) bad("column chunk of `" + leaf.name + "` lies outside the file");
+  Dictionary dict;
+  std::vector<uint8_t> page, levels_buf;
+  std::vector<uint32_t> def, idx;
+  int64_t seen = 0;
+  if (strings) col.offsets.push_back(0);
+  col.validity.assign((size_t)(rows + 7) / 8, 0);
+  while (seen < cm.num_values) {
+    if (pos >= chunk_end) bad("column chunk of `" + leaf.name + "` ends before its values do");
+    Thrift t{file + pos, file + chunk_end};
+    const PageHeader h = read_page_header(t);
+    const uint8_t* body = t.p;
+    if (h.compressed < 0 || h.uncompressed < 0 || body + h.compressed > file + chunk_end) bad("page of `" + leaf.name + "` lies outside its chunk");
+    pos = (int64_t)(body - file) + h.compressed;
+    if (h.type != 0 && h.type != 2 && h.type != 3) continue;  // index pages and the like
+
+    // the page's value bytes, decompressed
+    const uint8_t* vals = nullptr;
+    const uint8_t* vals_end = nullptr;
+    const uint8_t* def_p = nullptr;
+    const uint8_t* def_end = nullptr;
+    if (h.type == 3) {
+      if (h.rep_len != 0) unsupported("repetition levels in `" + leaf.name + "`");
+      const int64_t lv = (int64_t)h.def_len + h.rep_len;
+      if (lv > h.compressed) bad("levels longer than the page");
+      def_p = body;
+      def_end = body + h.def_len;
+      const uint8_t* data = body + lv;
+      const size_t data_comp = (size_t)(h.compressed - lv), data_raw = (size_t)(h.uncompressed - lv);
+      if (cm.codec == 1 && h.is_compressed && data_raw > 0) {
+        snappy_decompress(data, data_comp, page, data_raw);
+        vals = page.data();
+        vals_end = vals + page.size();
+      } else {
+        vals = data;
+        vals_end = data + data_comp;
+      }
+    } else {
+      if (cm.codec == 1) {
+        snappy_decompress(body, (size_t)h.compressed, page, (size_t)h.uncompressed);
+        vals = page.data();
+        vals_end = vals + page.size();
+      } else {
+        vals = body;
+        vals_end = body + h.compressed;
+      }
+      if (h.type == 0 && leaf.optional) {  // v1: 4-byte length, then the hybrid
+        if (vals_end - vals < 4) bad("page too short for its definition levels");
+        uint32_t l;
+        std::memcpy(&l, vals, 4);
+        if ((uint64_t)l + 4 > (uint64_t)(vals_end - vals)) bad("definition levels longer than the page");
+        def_p = vals + 4;
+        def_end = def_p + l;
+        vals = def_end;
+      }
+    }
+
+    if (h.type == 2) {  // dictionary page: PLAIN values
+      if (h.encoding != 0 && h.encoding != 2) unsupported("dictionary page encoding of `" + leaf.name + "`");
+      const uint8_t* p = vals;
+      for (int32_t i = 0; i < h.num_values; ++i) {
+        if (strings) {
+          if (vals_end - p < 4) bad("dictionary page too short");
+          uint32_t l;
+          std::memcpy(&l, p, 4);
+          p += 4;
+          if ((uint64_t)l > (uint64_t)(vals_end - p)) bad("dictionary value beyond the page");
+          dict.spans.emplace_back((uint32_t)dict.bytes.size(), l);
+          dict.bytes.insert(dict.bytes.end(), p, p + l);
+          p += l;
+        } else {
+          const int w = leaf.physical == kInt32 ? 4 : 8;
+          if (vals_end - p < w) bad("dictionary page too short");
+          int64_t v = 0;
+          if (w == 4) { int32_t x; std::memcpy(&x, p, 4); v = x; } else std::memcpy(&v, p, 8);
+          dict.ints.push_back(v);
+          p += w;
+        }
+      }
+      continue;
+    }
+
+    // ---- a data page ----
+    const size_t n = (size_t)h.num_values;
+    if (seen + (int64_t)n > rows) bad("more values than rows in `" + leaf.name + "`");
+    size_t present = n;
+    if (leaf.optional) {
+      rle_decode(def_p, def_end, 1, n, def);
+      present = 0;
+      for (size_t i = 0; i < n; ++i) present += def[i];
+    }
+    const bool by_dict = h.encoding == 2 || h.encoding == 8;
+    if (!by_dict && h.encoding != 0) unsupported("encoding " + std::to_string(h.encoding) + " in column `" + leaf.name + "`");
+    if (by_dict) {
+      if (vals_end - vals < 1) bad("dictionary-encoded page without a bit width");
+      rle_decode(vals + 1, vals_end, vals[0], present, idx);
+      for (uint32_t k : idx)
+        if (k >= dict.size()) bad("dictionary index out of range in `" + leaf.name + "`");
+    }
+    const uint8_t* p = vals;
+    size_t k = 0;  // position among the present values
+    for (size_t i = 0; i < n; ++i) {
+      const int64_t row = seen + (int64_t)i;
+      const bool ok = !leaf.optional || def[i] != 0;
+      if (ok) col.validity[(size_t)row >> 3] |= (uint8_t)(1u << (row & 7));
+      else ++col.nulls;
+      if (strings) {
+        if (ok) {
+          const uint8_t* s;
+          uint32_t l;
+          if (by_dict) {
+            s = dict.bytes.data() + dict.spans[idx[k]].first;
+            l = dict.spans[idx[k]].second;
+          } else {
+            if (vals_end - p < 4) bad("page of `" + leaf.name + "` ends inside a value");
+            std::memcpy(&l, p, 4);
+            p += 4;
+            if ((uint64_t)l > (uint64_t)(vals_end - p)) bad("value beyond the page in `" + leaf.name + "`");
+            s = p;
+            p += l;
+          }
+          if (col.bytes.size() + l > 0x7fffffffull) unsupported("more than 2 GiB of string data in one row group of `" + leaf.name + "`");
+          col.bytes.insert(col.bytes.end(), s, s + l);
+          ++k;
+        }
+        col.offsets.push_back((int32_t)col.bytes.size());
+      } else {
+        int64_t v = 0;
+        if (ok) {
+          if (by_dict) {
+            v = dict.ints[idx[k]];
+          } else if (leaf.physical == kInt32) {
+            if (vals_end - p < 4) bad("page of `" + leaf.name + "` ends inside a value");
+            int32_t x;
+            std::memcpy(&x, p, 4);
+            v = x;
+            p += 4;
+          } else {
+            if (vals_end - p < 8) bad("page of `" + leaf.name + "` ends inside a value");
+            std::memcpy(&v, p, 8);
+            p += 8;
+          }
+          ++k;
+        }
+        store_fixed(col, v, leaf);
+      }
+    }
+    seen += (int64_t)n;
+  }
+  if (seen != rows) bad("column `" + leaf.name + "` holds " + std::to_string(seen) + " values for " + std::to_string(rows) + " rows");
+  col.rows = rows;
+}
+
+// ---- Arrow export of decoded row groups ---------------------------------------------------------
+struct PqOwner {
+  std::vector<PqColumn> cols;
+  std::vector<ArrowArray> children;
+  std::vector<ArrowArray*> child_ptrs;
+  std::vector<std::vector<const void*>> buffers;
+  const void* top_buffers[1] = {nullptr};
+};
+
+void release_pq(ArrowArray* a) {
+  delete (PqOwner*)a->private_data;
+  a->release = nullptr;
+}
+void release_pq_child(ArrowArray* a) { a->release = nullptr; }
+
+void export_columns(std::vector<PqColumn>&& cols, int64_t rows, ArrowArray* out) {
+  auto owner = std::make_unique<PqOwner>();
+  owner->cols = std::move(cols);
+  const size_t n = owner->cols.size();
+  owner->children.resize(n);
+  owner->child_ptrs.resize(n);
+  owner->buffers.resize(n);
+  for (size_t c = 0; c < n; ++c) {
+    PqColumn& col = owner->cols[c];
+    ArrowArray& a = owner->children[c];
+    std::memset(&a, 0, sizeof(a));
+    auto& b = owner->buffers[c];
+    b.push_back(col.nulls ? (const void*)col.validity.data() : nullptr);
+    if (col.type.is_string) {
+      b.push_back(col.offsets.data());
+      b.push_back(col.bytes.empty() ? (const void*)"" : (const void*)col.bytes.data());
+    } else {
+      b.push_back(col.values.empty() ? (const void*)"" : (const void*)col.values.data());
+    }
+    a.length = rows;
+    a.null_count = col.nulls;
+    a.n_buffers = (int64_t)b.size();
+    a.buffers = b.data();
+    a.release = release_pq_child;
+    owner->child_ptrs[c] = &a;
+  }
+  std::memset(out, 0, sizeof(*out));
+  out->length = rows;
+  out->n_buffers = 1;
+  out->buffers = owner->top_buffers;
+  out->n_children = (int64_t)n;
+  out->children = owner->child_ptrs.data();
+  out->release = release_pq;
+  out->private_data = owner.release();
+}
+
+void append_column(PqColumn& dst, PqColumn&& src) {
+  if (dst.rows == 0 && dst.values.empty() && dst.offsets.empty()) {
+    FieldType t = dst.type;
+    dst = std::move(src);
+    dst.type = t;
+    return;
+  }
+  // validity: re-align the bits behind dst.rows
+  dst.validity.resize((size_t)(dst.rows + src.rows + 7) / 8, 0);
+  for (int64_t i = 0; i < src.rows; ++i)
+    if (src.validity[(size_t)i >> 3] >> (i & 7) & 1) dst.validity[(size_t)(dst.rows + i) >> 3] |= (uint8_t)(1u << ((dst.rows + i) & 7));
+  if (dst.type.is_string) {
+    const int32_t base = dst.offsets.back();
+    if ((uint64_t)base + src.bytes.size() > 0x7fffffffull) unsupported("more than 2 GiB of string data in one column; read the file per row group");
+    for (size_t i = 1; i < src.offsets.size(); ++i) dst.offsets.push_back(base + src.offsets[i]);
+    dst.bytes.insert(dst.bytes.end(), src.bytes.begin(), src.bytes.end());
+  } else {
+    dst.values.insert(dst.values.end(), src.values.begin(), src.values.end());
+  }
+  dst.nulls += src.nulls;
+  dst.rows += src.rows;
+}
+
+}  // namespace
+
+void parquet_read(const void* file_, size_t len, ArrowSchema* out_schema, ArrowArray* out) {
+  const uint8_t* file = (const uint8_t*)file_;
+  const FileMeta fm = read_footer(file, len);
+  std::vector<FieldType> fields;
+  for (const Leaf& l : fm.leaves) fields.push_back(leaf_field(l));
+  std::vector<PqColumn> all(fields.size());
+  for (size_t c = 0; c < fields.size(); ++c) {
+    all[c].type = fields[c];
+    if (fields[c].is_string) all[c].offsets.push_back(0);
+  }
+  int64_t rows = 0;
+  for (const RowGroupMeta& rg : fm.groups) {
+    if (rg.num_rows == 0) continue;
+    for (size_t c = 0; c < fields.size(); ++c) {
+      PqColumn col;
+      col.type = fields[c];
+      decode_chunk(file, len, fm.leaves[c], rg.chunks[c], rg.num_rows, col);
+      if (rows == 0) { col.type = fields[c]; all[c] = std::move(col); }
+      else append_column(all[c], std::move(col));
+    }
+    rows += rg.num_rows;
+  }
+  for (size_t c = 0; c < fields.size(); ++c) all[c].rows = rows;
+  if (out_schema) export_schema(fields, out_schema);
+  export_columns(std::move(all), rows, out);
+}
+
+void table_append_parquet(prism_gpu_table* table, uint32_t partition_id, const void* file_, size_t len) {
+  const uint8_t* file = (const uint8_t*)file_;
+  const FileMeta fm = read_footer(file, len);
+  // The file's columns are matched to the table's by name, as ParquetExec's schema adapter
+  // does; a table column the file lacks reads as NULLs.  Types must agree, except that Binary
+  // and Utf8 stand in for each other, and Int64 for Timestamp(ms).
+  std::vector<int> leaf_of(table->fields.size(), -1);
+  for (size_t f = 0; f < table->fields.size(); ++f) {
+    for (size_t l = 0; l < fm.leaves.size(); ++l)
+      if (fm.leaves[l].name == table->fields[f].name) leaf_of[f] = (int)l;
+    if (leaf_of[f] < 0) continue;
+    const FieldType have = leaf_field(fm.leaves[leaf_of[f]]);
+    const FieldType& want = table->fields[f];
+    const bool same = have.format == want.format || (have.is_string && want.is_string) ||
+                      (have.width == 8 && want.width == 8 && !have.is_float && !want.is_float && !have.is_string && !want.is_string);
+    if (!same)
+      unsupported("column `" + want.name + "` is " + have.format + " in the file and " + want.format + " in the table");
+  }
+  for (const RowGroupMeta& rg : fm.groups) {
+    if (rg.num_rows == 0) continue;
+    std::vector<PqColumn> cols(table->fields.size());
+    for (size_t f = 0; f < table->fields.size(); ++f) {
+      PqColumn& col = cols[f];
+      col.type = table->fields[f];
+      if (leaf_of[f] >= 0) {
+        decode_chunk(file, len, fm.leaves[leaf_of[f]], rg.chunks[leaf_of[f]], rg.num_rows, col);
+      } else {
+        col.rows = rg.num_rows;
+        col.nulls = rg.num_rows;
+        col.validity.assign((size_t)(rg.num_rows + 7) / 8, 0);
+        if (col.type.is_string) col.offsets.assign((size_t)rg.num_rows + 1, 0);
+        else col.values.assign((size_t)rg.num_rows * col.type.width, 0);
+      }
+    }
+    ArrowArray batch;
+    export_columns(std::move(cols), rg.num_rows, &batch);
+    table_append(table, partition_id, &batch, true);  // moves the batch
+  }
+}
+
+}  // namespace prism

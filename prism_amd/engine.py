@@ -37,6 +37,7 @@ EXPORTED_SYMBOLS = [
     "prism_gpu_set_option", "prism_gpu_execute_noalloc", "prism_gpu_plan_time_range",
     "prism_gpu_comm_unique_id", "prism_gpu_comm_init", "prism_gpu_comm_init_callbacks", "prism_gpu_comm_free",
     "prism_gpu_execute_sharded", "prism_gpu_comm_get_stats",
+    "prism_gpu_table_append_parquet", "prism_gpu_parquet_read",
 ]
 
 _LIB: Optional[C.CDLL] = None
@@ -107,6 +108,8 @@ def load_library() -> C.CDLL:
     L.prism_gpu_set_option.argtypes = [V, C.c_char_p, C.c_int64]
     L.prism_gpu_plan_time_range.argtypes = [V, C.c_int32, P(C.c_int64), P(C.c_int64)]
     L.prism_gpu_execute_noalloc.argtypes = [V, V, P(C.c_uint32), C.c_size_t, V, V, C.c_uint64, P(C.c_uint64)]
+    L.prism_gpu_table_append_parquet.argtypes = [V, C.c_uint32, C.c_char_p, C.c_size_t]
+    L.prism_gpu_parquet_read.argtypes = [C.c_char_p, C.c_size_t, P(abi.ArrowSchema), P(abi.ArrowArray)]
     L.prism_gpu_comm_unique_id.argtypes = [V]
     L.prism_gpu_comm_init.argtypes = [V, V, C.c_int, C.c_int, P(V)]
     L.prism_gpu_comm_init_callbacks.argtypes = [V, P(abi.Transport), C.c_int, C.c_int, P(V)]
@@ -191,6 +194,10 @@ class Table:
             lo, hi = n * p // n_partitions, n * (p + 1) // n_partitions
             for b in table.slice(lo, hi - lo).combine_chunks().to_batches():
                 self.append(p, b)
+
+    def append_parquet(self, partition_id: int, file_bytes: bytes) -> None:
+        """prism_gpu_table_append_parquet: the library decodes the file (every row group a chunk)."""
+        _check(self._lib.prism_gpu_table_append_parquet(self._h, partition_id, file_bytes, len(file_bytes)))
 
     def set_dictionary(self, column: str, values: Sequence[str]) -> None:
         enc = [v.encode("utf-8") for v in values]
@@ -394,6 +401,15 @@ class State:
         if self._h:
             self._lib.prism_gpu_state_free(self._h)
             self._h = C.c_void_p()
+
+
+def parquet_read(file_bytes: bytes) -> pa.Table:
+    """prism_gpu_parquet_read: the library's own Parquet decode, as a pyarrow table (host only)."""
+    lib = load_library()
+    schema, arr = abi.ArrowSchema(), abi.ArrowArray()
+    _check(lib.prism_gpu_parquet_read(file_bytes, len(file_bytes), C.byref(schema), C.byref(arr)))
+    sch = abi.import_schema(schema)
+    return pa.Table.from_batches([abi.import_batch(arr, sch)])
 
 
 class Comm:

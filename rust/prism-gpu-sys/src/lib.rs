@@ -182,6 +182,8 @@ extern "C" {
     pub fn prism_gpu_table_num_rows(table: *const prism_gpu_table, out: *mut u64) -> c_int;
     pub fn prism_gpu_table_num_partitions(table: *const prism_gpu_table, out: *mut u32) -> c_int;
     pub fn prism_gpu_table_free(table: *mut prism_gpu_table);
+    pub fn prism_gpu_table_append_parquet(table: *mut prism_gpu_table, partition_id: u32, file: *const c_void, file_len: usize) -> c_int;
+    pub fn prism_gpu_parquet_read(file: *const c_void, file_len: usize, out_schema: *mut FFI_ArrowSchema, out: *mut FFI_ArrowArray) -> c_int;
 
     // ---- plans ----
     pub fn prism_gpu_plan_create(ctx: *mut prism_gpu_ctx, input_schema: *const FFI_ArrowSchema, desc: *const prism_gpu_plan_desc, out: *mut *mut prism_gpu_plan) -> c_int;

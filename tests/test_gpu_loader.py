@@ -78,3 +78,66 @@ def test_projection_leaves_other_columns_null(gpu_ctx, tmp_path):
             plan.close()
     finally:
         g.close()
+
+
+def test_library_decodes_the_parquet_files_itself(gpu_ctx):
+    """prism_gpu_table_append_parquet: the same files, decoded by the library's own reader
+    (no pyarrow between the bytes and HBM), one file per partition, every row group a chunk."""
+    import io
+
+    from oracle import pyoracle
+    from prism_amd.engine import Plan, PrismGpuError, Table
+
+    t = helpers.random_table(30_000, seed=23, nulls=True)
+    n_files = 3
+    g = Table(gpu_ctx, t.schema)
+    try:
+        for i in range(n_files):
+            lo, hi = t.num_rows * i // n_files, t.num_rows * (i + 1) // n_files
+            sink = io.BytesIO()
+            pq.write_table(t.slice(lo, hi - lo), sink, version="2.6", data_page_version="2.0", compression="snappy",
+                           use_dictionary=True, row_group_size=4000)
+            g.append_parquet(i, sink.getvalue())
+        assert g.num_partitions == n_files and g.num_rows == t.num_rows
+        for q, n_keys in [
+            (QueryPlan([count_star(), sum_("value"), max_("u16"), avg("i32")], keys=[date_bin(600_000, "ts"), "service"]), 2),
+            (QueryPlan([count_star()], predicate=col("url").like("%google%") & (col("i16") != 0)), 0),
+            (QueryPlan([count_star()], keys=["user"], predicate=col("service") == "svc-01"), 1),
+        ]:
+            plan = Plan(gpu_ctx, t.schema, q)
+            try:
+                got = plan.execute(g)
+                one = plan.execute(g, [1])
+            finally:
+                plan.close()
+            assert_tables_match(got, pyoracle.execute(t, q), n_keys)
+            lo, hi = t.num_rows // n_files, t.num_rows * 2 // n_files
+            assert_tables_match(one, pyoracle.execute(t.slice(lo, hi - lo), q), n_keys)
+    finally:
+        g.close()
+
+    # a file without some of the table's columns: they read as NULLs; a column of another type is refused
+    some = t.select(["ts", "value"]).slice(0, 5000)
+    sink = io.BytesIO()
+    pq.write_table(some, sink, data_page_version="2.0", compression="snappy")
+    g = Table(gpu_ctx, t.schema)
+    try:
+        g.append_parquet(0, sink.getvalue())
+        q = QueryPlan([count_star(), sum_("value")], keys=[date_bin(3_600_000, "ts")])
+        plan = Plan(gpu_ctx, t.schema, q)
+        try:
+            assert_tables_match(plan.execute(g), pyoracle.execute(t.slice(0, 5000), q), 1)
+        finally:
+            plan.close()
+        plan = Plan(gpu_ctx, t.schema, QueryPlan([count_star()], predicate=col("i32").is_null()))
+        try:
+            assert plan.execute(g).column(0).to_pylist() == [5000]
+        finally:
+            plan.close()
+        wrong = io.BytesIO()
+        pq.write_table(pa.table({"value": pa.array(["a", "b"])}), wrong)
+        with pytest.raises(PrismGpuError) as e:
+            g.append_parquet(1, wrong.getvalue())
+        assert e.value.code == -2 and "`value`" in e.value.msg
+    finally:
+        g.close()

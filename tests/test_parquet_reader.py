@@ -1,0 +1,105 @@
+"""The library's own Parquet decode (prism_gpu_parquet_read, host only) against pyarrow's, on
+files written the way prism-ingest writes them (src/prism-ingest/src/ingest.rs:98-101: data
+page v2, dictionary with PLAIN fallback, Snappy) and on the other shapes the reader claims:
+data page v1, no dictionary, no compression, several row groups, required columns, all-NULL
+and empty columns, dictionary overflow into PLAIN pages.  Bit-exact."""
+import io
+
+import numpy as np
+import pyarrow as pa
+import pyarrow.parquet as pq
+import pytest
+
+from prism_amd import _cabi as abi
+from prism_amd import engine
+
+
+def _table(n: int, seed: int, nulls: bool = True) -> pa.Table:
+    rng = np.random.default_rng(seed)
+
+    def mask(p):
+        return (rng.random(n) < p) if nulls else None
+
+    words = ["GET", "POST", "", "a much longer method name that repeats", "ünï©ode", "x" * 300]
+    urls = [f"http://host{int(i) % 977}/p{int(i)}?q={'z' * (int(i) % 37)}" for i in rng.integers(0, 10**9, n)]
+    return pa.table({
+        "i64": pa.array(rng.integers(-2**62, 2**62, n), type=pa.int64(), mask=mask(0.1)),
+        "small64": pa.array(rng.integers(0, 50, n), type=pa.int64(), mask=mask(0.5)),
+        "i32": pa.array(rng.integers(-2**31, 2**31 - 1, n), type=pa.int32(), mask=mask(0.05)),
+        "i16": pa.array(rng.integers(-2**15, 2**15 - 1, n).astype(np.int16), mask=mask(0.2)),
+        "u16": pa.array(rng.integers(0, 2**16 - 1, n).astype(np.uint16), mask=mask(0.2)),
+        "ts": pa.array(rng.integers(1_600_000_000_000, 1_700_000_000_000, n), type=pa.timestamp("ms"), mask=mask(0.1)),
+        "method": pa.array([words[int(i)] for i in rng.integers(0, len(words), n)], type=pa.string(), mask=mask(0.3)),
+        "url": pa.array(urls, type=pa.string(), mask=mask(0.02)),
+        "blob": pa.array([bytes(rng.integers(0, 256, int(l)).astype(np.uint8)) for l in rng.integers(0, 40, n)], type=pa.binary(),
+                         mask=mask(0.1)),
+        "all_null": pa.array([None] * n, type=pa.int64()),
+    })
+
+
+def _write(t: pa.Table, **kw) -> bytes:
+    sink = io.BytesIO()
+    pq.write_table(t, sink, **kw)
+    return sink.getvalue()
+
+
+CASES = {
+    "like_prism_ingest": dict(data_page_version="2.0", compression="snappy", use_dictionary=True),
+    "v1_snappy_dict": dict(data_page_version="1.0", compression="snappy", use_dictionary=True),
+    "v2_plain_uncompressed": dict(data_page_version="2.0", compression="none", use_dictionary=False),
+    "v1_plain_snappy_small_pages": dict(data_page_version="1.0", compression="snappy", use_dictionary=False, data_page_size=4096),
+    "v2_row_groups": dict(data_page_version="2.0", compression="snappy", use_dictionary=True, row_group_size=1500),
+    "v2_dictionary_falls_back_to_plain": dict(data_page_version="2.0", compression="snappy", use_dictionary=True,
+                                              dictionary_pagesize_limit=2048, data_page_size=8192),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+@pytest.mark.parametrize("nulls", [True, False])
+def test_decode_matches_pyarrow(case, nulls):
+    t = _table(7000, seed=len(case), nulls=nulls)
+    data = _write(t, **CASES[case])
+    got = engine.parquet_read(data)
+    want = pq.read_table(io.BytesIO(data))
+    assert got.schema.names == want.schema.names
+    for name in want.schema.names:
+        assert got.column(name).type == want.column(name).type, name
+        assert got.column(name).combine_chunks().equals(want.column(name).combine_chunks()), name
+
+
+def test_required_columns_empty_file_and_timestamp_units():
+    schema = pa.schema([pa.field("a", pa.int64(), nullable=False), pa.field("s", pa.string(), nullable=False),
+                        pa.field("us", pa.timestamp("us")), pa.field("ns", pa.timestamp("ns"))])
+    t = pa.table({"a": pa.array([1, -2, 3], pa.int64()), "s": pa.array(["x", "", "yz"]),
+                  "us": pa.array([1_700_000_000_123_456, None, -1_999], pa.timestamp("us")),
+                  "ns": pa.array([1_700_000_000_123_456_789, 5, None], pa.timestamp("ns"))}, schema=schema)
+    data = _write(t, data_page_version="2.0", compression="snappy", coerce_timestamps=None, version="2.6")
+    got = engine.parquet_read(data)
+    assert got.column("a").to_pylist() == [1, -2, 3] and got.column("s").to_pylist() == ["x", "", "yz"]
+    # other units read as Timestamp(ms), divided the way arrow's cast does (towards zero)
+    assert got.column("us").type == pa.timestamp("ms") and got.column("us").cast(pa.int64()).to_pylist() == [1_700_000_000_123, None, -1]
+    assert got.column("ns").cast(pa.int64()).to_pylist() == [1_700_000_000_123, 0, None]
+    empty = _write(t.slice(0, 0), data_page_version="2.0", compression="snappy")
+    assert engine.parquet_read(empty).num_rows == 0
+
+
+def test_what_is_not_covered_says_so():
+    with pytest.raises(engine.PrismGpuError) as e:
+        engine.parquet_read(b"PAR1 not really PAR1")
+    assert e.value.code == abi.EINVAL
+    with pytest.raises(engine.PrismGpuError) as e:
+        engine.parquet_read(_write(pa.table({"f": pa.array([1.5, 2.5])})))
+    assert e.value.code == abi.EUNSUPPORTED and "`f`" in e.value.msg
+    with pytest.raises(engine.PrismGpuError) as e:
+        engine.parquet_read(_write(pa.table({"l": pa.array([[1, 2], [3]])})))
+    assert e.value.code == abi.EUNSUPPORTED
+    with pytest.raises(engine.PrismGpuError) as e:
+        engine.parquet_read(_write(pa.table({"a": pa.array([1, 2, 3])}), compression="zstd"))
+    assert e.value.code == abi.EUNSUPPORTED and "codec" in e.value.msg
+    # truncated in the middle of the pages: an error, not a crash
+    good = _write(_table(500, 3), data_page_version="2.0", compression="snappy")
+    broken = good[:200] + b"\x00" * 64 + good[264:]
+    try:
+        engine.parquet_read(broken)
+    except engine.PrismGpuError as err:
+        assert err.code in (abi.EINVAL, abi.EUNSUPPORTED)
