@@ -268,6 +268,7 @@ int execute_sharded(prism_gpu_comm* c, prism_gpu_plan* plan, prism_gpu_table* ta
   // what the device-resident state does not cover is refused before any collective, and for
   // reasons every rank sees alike (the plan; the key width follows from the agreed statistics)
   if (plan->keys.empty()) fail(PRISM_GPU_EUNSUPPORTED, "the sharded form needs a GROUP BY (ungrouped aggregates exchange PARTIAL batches)");
+  if (plan->mixed) fail(PRISM_GPU_EUNSUPPORTED, "COUNT(DISTINCT) next to other aggregates runs on one GPU only");
   if (plan->mode != PRISM_MODE_SINGLE) fail(PRISM_GPU_EINVAL, "the sharded form runs plans in SINGLE mode: it does the merge itself");
   bind(ctx);
   const int world = c->world, rank = c->rank;

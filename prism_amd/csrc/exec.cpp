@@ -1476,11 +1476,16 @@ bool try_fuse_predicate(const prism_gpu_plan* plan, const prism_gpu_table* table
 
 void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions,
                   bool merge_input, ArrowArray* out, const prism_gpu_col_stats* stats_override, prism_gpu_state** capture,
-                  bool emit_partial = false, prism_gpu_ctx* ctx_override = nullptr);
+                  bool emit_partial = false, prism_gpu_ctx* ctx_override = nullptr, std::vector<OutColumn>* cols_out = nullptr);
+void execute_mixed(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions, ArrowArray* out);
 }
 
 void execute_plan(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions,
                   bool merge_input, ArrowArray* out) {
+  if (plan->mixed && !merge_input) {
+    execute_mixed(plan, table, partition_ids, n_partitions, out);
+    return;
+  }
   execute_impl(plan, table, partition_ids, n_partitions, merge_input, out, nullptr, nullptr);
 }
 
@@ -1496,7 +1501,8 @@ namespace {
 // statistics so that every rank of a multi-GPU query packs keys the same way.
 void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions,
                   bool merge_input, ArrowArray* out, const prism_gpu_col_stats* stats_override, prism_gpu_state** capture,
-                  bool emit_partial, prism_gpu_ctx* ctx_override) {
+                  bool emit_partial, prism_gpu_ctx* ctx_override, std::vector<OutColumn>* cols_out) {
+  if (plan->mixed) fail(PRISM_GPU_EUNSUPPORTED, "COUNT(DISTINCT) next to other aggregates runs through prism_gpu_execute only");
   // (ctx_override: a child context of the plan's, for partitions that stream concurrently)
   prism_gpu_ctx* ctx = ctx_override ? ctx_override : plan->ctx;
   bind(ctx);
@@ -1636,7 +1642,8 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       ctx->stats.rows_selected += c;
       ctx->stats.groups_out += 1;
     }
-    export_record_batch(cols, out);
+    if (cols_out) *cols_out = std::move(cols);
+    else export_record_batch(cols, out);
     return;
   }
   Scratch selvec;
@@ -1667,7 +1674,8 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
         ctx->stats.rows_selected += selected;
         ctx->stats.groups_out += 1;
       }
-      export_record_batch(count_cols, out);
+      if (cols_out) *cols_out = std::move(count_cols);
+      else export_record_batch(count_cols, out);
       return;
     }
     ap.row_mode = kRowsBitmap;
@@ -1855,7 +1863,8 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
         selvec.reset();
         PRISM_HIP(hipStreamSynchronize(ctx->stream));
         collect_timings(ctx);
-        execute_impl(plan, table, partition_ids, n_partitions, merge_input, out, stats_override, capture, emit_partial, ctx_override);
+        execute_impl(plan, table, partition_ids, n_partitions, merge_input, out, stats_override, capture, emit_partial, ctx_override,
+                     cols_out);
         return;
       }
       if (dense || flag == 0u) break;
@@ -1912,7 +1921,81 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
     ctx->stats.rows_selected += selected;
     ctx->stats.groups_out += groups_out;
   }
+  if (cols_out) {
+    *cols_out = std::move(cols);
+    return;
+  }
   HostTimer ht(ctx, "host:export");
+  export_record_batch(cols, out);
+}
+
+// One row's group keys as bytes (validity byte, then the value: 8 bytes, or length + bytes).
+void append_row_key(const std::vector<OutColumn>& cols, size_t n_keys, size_t row, std::string& key) {
+  key.clear();
+  for (size_t c = 0; c < n_keys; ++c) {
+    const OutColumn& oc = cols[c];
+    const bool ok = oc.valid_data()[row] != 0;
+    key.push_back(ok ? 1 : 0);
+    if (!ok) continue;
+    if (oc.type.is_string) {
+      const std::string& v = oc.dict ? (*oc.dict)[oc.code_at(row)] : oc.str[row];
+      const uint32_t l = (uint32_t)v.size();
+      key.append((const char*)&l, 4);
+      key.append(v);
+    } else {
+      const int64_t v = oc.i64_data()[row];
+      key.append((const char*)&v, 8);
+    }
+  }
+}
+
+// COUNT(DISTINCT) next to other aggregates: both sub-plans see the same rows and therefore
+// the same groups; the distinct counts are looked up by group key and placed beside the
+// other aggregates, in the order the plan lists them.
+void execute_mixed(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions, ArrowArray* out) {
+  std::vector<OutColumn> a, b;
+  execute_impl(plan->sub_plain.get(), table, partition_ids, n_partitions, false, nullptr, nullptr, nullptr, false, nullptr, &a);
+  execute_impl(plan->sub_distinct.get(), table, partition_ids, n_partitions, false, nullptr, nullptr, nullptr, false, nullptr, &b);
+  const size_t n_keys = plan->keys.size();
+  const size_t rows = a.empty() ? 0 : a[0].rows();
+  if ((b.empty() ? 0 : b[0].rows()) != rows) fail(PRISM_GPU_EINTERNAL, "the two halves of the plan found different groups");
+  std::vector<size_t> b_row(rows);
+  if (n_keys == 0 || rows <= 1) {
+    for (size_t i = 0; i < rows; ++i) b_row[i] = i;
+  } else {
+    std::unordered_map<std::string, size_t> where;
+    where.reserve(rows * 2);
+    std::string key;
+    for (size_t i = 0; i < rows; ++i) {
+      append_row_key(b, n_keys, i, key);
+      where.emplace(key, i);
+    }
+    for (size_t i = 0; i < rows; ++i) {
+      append_row_key(a, n_keys, i, key);
+      auto it = where.find(key);
+      if (it == where.end()) fail(PRISM_GPU_EINTERNAL, "the two halves of the plan found different groups");
+      b_row[i] = it->second;
+    }
+  }
+  std::vector<OutColumn> cols = make_columns(plan->final_fields);
+  for (size_t c = 0; c < n_keys; ++c) {
+    FieldType t = cols[c].type;
+    cols[c] = std::move(a[c]);
+    cols[c].type = t;
+  }
+  for (size_t i = 0; i < plan->aggs.size(); ++i) {
+    OutColumn& dst = cols[n_keys + i];
+    const auto [which, idx] = plan->mixed_map[i];
+    if (which == 0) {
+      FieldType t = dst.type;
+      dst = std::move(a[n_keys + (size_t)idx]);
+      dst.type = t;
+    } else {
+      const OutColumn& src = b[n_keys + (size_t)idx];
+      for (size_t r = 0; r < rows; ++r) dst.push_int(src.i64_data()[b_row[r]]);
+    }
+  }
+  sort_and_limit(plan, cols);
   export_record_batch(cols, out);
 }
 
@@ -1927,7 +2010,7 @@ void execute_noalloc(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_
   prism_gpu_ctx* ctx = plan->ctx;
   bind(ctx);
   if (table->ctx != ctx) fail(PRISM_GPU_EINVAL, "plan and table belong to different contexts");
-  if (plan->keys.empty() || plan->distinct_plan || plan->mode != PRISM_MODE_SINGLE || plan->order_by >= 0 || plan->limit >= 0)
+  if (plan->keys.empty() || plan->distinct_plan || plan->mixed || plan->mode != PRISM_MODE_SINGLE || plan->order_by >= 0 || plan->limit >= 0)
     fail(PRISM_GPU_EUNSUPPORTED, "the allocation-free entry point runs GROUP BY plans in SINGLE mode without COUNT(DISTINCT), ORDER BY or LIMIT");
   if (table->fields.size() != plan->fields.size()) fail(PRISM_GPU_EINVAL, "table schema does not match the plan's input schema");
   for (size_t i = 0; i < plan->fields.size(); ++i)

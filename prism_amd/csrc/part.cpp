@@ -137,6 +137,8 @@ void stage_pending(prism_gpu_part* part) {
 }  // namespace
 
 std::unique_ptr<prism_gpu_part> part_open(prism_gpu_plan* plan, uint32_t partition) {
+  if (plan->mixed)
+    fail(PRISM_GPU_EUNSUPPORTED, "COUNT(DISTINCT) next to other aggregates has no PARTIAL form: it runs over resident partitions (prism_gpu_execute)");
   auto part = std::make_unique<prism_gpu_part>();
   part->plan = plan;
   part->partition = partition;

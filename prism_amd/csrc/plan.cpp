@@ -221,9 +221,29 @@ std::unique_ptr<prism_gpu_plan> plan_create(prism_gpu_ctx* ctx, const ArrowSchem
     ap.name = a.name ? a.name : default_agg_name(*plan, ap);
     plan->aggs.push_back(ap);
   }
-  if (n_distinct) {
+  if (n_distinct && n_distinct != d->n_aggs) {
+    // COUNT(DISTINCT) next to other aggregates: two plans over the same rows, joined on the keys
+    if (d->mode != PRISM_MODE_SINGLE)
+      fail(PRISM_GPU_EUNSUPPORTED, "COUNT(DISTINCT) next to other aggregates is supported in SINGLE mode only");
+    std::vector<prism_gpu_agg> plain, distinct;
+    for (uint32_t i = 0; i < d->n_aggs; ++i) {
+      const bool is_d = d->aggs[i].func == PRISM_AGG_COUNT_DISTINCT;
+      plan->mixed_map.emplace_back(is_d ? 1 : 0, (int)(is_d ? distinct.size() : plain.size()));
+      (is_d ? distinct : plain).push_back(d->aggs[i]);
+    }
+    prism_gpu_plan_desc sub = *d;
+    sub.order_by = -1;
+    sub.limit = -1;
+    sub.aggs = plain.data();
+    sub.n_aggs = (uint32_t)plain.size();
+    plan->sub_plain = plan_create(ctx, schema, &sub);
+    sub.aggs = distinct.data();
+    sub.n_aggs = (uint32_t)distinct.size();
+    plan->sub_distinct = plan_create(ctx, schema, &sub);
+    plan->mixed = true;
+    plan->distinct_col = -1;
+  } else if (n_distinct) {
     // the shape DataFusion rewrites with SingleDistinctToGroupBy: two chained GROUP BYs
-    if (n_distinct != d->n_aggs) fail(PRISM_GPU_EUNSUPPORTED, "COUNT(DISTINCT) mixed with other aggregates");
     plan->distinct_plan = true;
   }
   plan->order_by = d->order_by;
