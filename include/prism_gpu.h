@@ -217,7 +217,10 @@ const char* prism_gpu_last_error(void);
 int prism_gpu_table_create(prism_gpu_ctx* ctx, const struct ArrowSchema* schema,
                            prism_gpu_table** out);
 /* Appends one RecordBatch (a struct-typed ArrowArray matching the table schema;
- * Utf8 columns may arrive dictionary encoded) to partition `partition_id`.
+ * Utf8 / Binary columns may arrive dictionary encoded, with Int32 indices -- the only index
+ * width arrow-rs produces for DataFusion's Dictionary(Int32, Utf8) -- and a dictionary
+ * without NULL entries; NULL rows are told by the indices' validity) to partition
+ * `partition_id`.
  * The array is moved: the library releases it once the bytes are staged. */
 int prism_gpu_table_append(prism_gpu_table* table, uint32_t partition_id,
                            struct ArrowArray* batch);

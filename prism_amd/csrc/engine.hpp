@@ -2,6 +2,7 @@
 #pragma once
 
 #include <atomic>
+#include <deque>
 #include <cstdint>
 #include <memory>
 #include <mutex>
@@ -53,9 +54,10 @@ struct prism_gpu_table {
   prism_gpu_ctx* ctx = nullptr;
   bool pooled = false;  // column memory comes from the context's scratch pool (short-lived chunk tables)
   std::vector<prism::FieldType> fields;
-  std::vector<prism::Chunk> chunks;
+  // (a deque: scans keep pointers to chunks, and appending must not move the ones they hold)
+  std::deque<prism::Chunk> chunks;
   std::vector<prism::ColumnDict> dicts;  // one per column (used by string columns)
-  std::mutex mu;
+  std::mutex mu;  // appends hold it throughout; scans while they collect their chunks
   ~prism_gpu_table();
 };
 

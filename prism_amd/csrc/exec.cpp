@@ -1521,18 +1521,21 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
   ss.ctx = ctx;
   ss.stats_override = stats_override;
   uint64_t chunks_pruned = 0;
-  for (const Chunk& ch : table->chunks) {
-    bool take = partition_ids == nullptr || n_partitions == 0;
-    for (size_t i = 0; !take && i < n_partitions; ++i) take = partition_ids[i] == ch.partition_id;
-    if (!take || ch.rows == 0) continue;
-    if (plan->pred_root >= 0 && !merge_input && !chunk_may_match(plan, table, plan->pred_root, ch)) {
-      chunks_pruned += 1;
-      continue;
+  {
+    std::lock_guard<std::mutex> chunks_lock(table->mu);  // appends may be adding chunks
+    for (const Chunk& ch : table->chunks) {
+      bool take = partition_ids == nullptr || n_partitions == 0;
+      for (size_t i = 0; !take && i < n_partitions; ++i) take = partition_ids[i] == ch.partition_id;
+      if (!take || ch.rows == 0) continue;
+      if (plan->pred_root >= 0 && !merge_input && !chunk_may_match(plan, table, plan->pred_root, ch)) {
+        chunks_pruned += 1;
+        continue;
+      }
+      ss.chunks.push_back(&ch);
+      ss.segs.push_back({ch.rows, ss.n_tiles});
+      ss.n_tiles += ceil_div(ch.rows, kTileRows);
+      ss.rows += ch.rows;
     }
-    ss.chunks.push_back(&ch);
-    ss.segs.push_back({ch.rows, ss.n_tiles});
-    ss.n_tiles += ceil_div(ch.rows, kTileRows);
-    ss.rows += ch.rows;
   }
   if (chunks_pruned) {
     std::lock_guard<std::mutex> g(ctx->mu);
@@ -1647,7 +1650,18 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
     return;
   }
   Scratch selvec;
-  unsigned long long fused_selected = 0;  // filled in by the kernel, valid after the next stream synchronisation
+  // Rows that passed a predicate evaluated inside the aggregation kernel: copied back
+  // asynchronously, valid after the next stream synchronisation.  It lands in a leased
+  // page-locked block rather than on this stack frame, so a copy still in flight when an
+  // error unwinds the frame writes into pooled memory, not into a dead stack slot.
+  std::shared_ptr<void> fused_landing;
+  auto fused_slot = [&]() -> unsigned long long* {
+    if (!fused_landing) {
+      fused_landing = lease_pinned(ctx, 64);
+      *(unsigned long long*)fused_landing.get() = 0;
+    }
+    return (unsigned long long*)fused_landing.get();
+  };
   if (fused) {
     ap.row_mode = kRowsAll;
     ap.selected_out = d_scalar.as<unsigned long long>();
@@ -1745,10 +1759,10 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       launch_group_by(ctx, ap, agg_bytes, "agg_global");
       std::vector<int64_t> both((size_t)ap.n_slots * 2);  // entry 0 and the unused extra entry of every slot
       PRISM_HIP(hipMemcpyAsync(both.data(), gt.state.p, both.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-      if (fused) PRISM_HIP(hipMemcpyAsync(&fused_selected, d_scalar.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+      if (fused) PRISM_HIP(hipMemcpyAsync(fused_slot(), d_scalar.p, 8, hipMemcpyDeviceToHost, ctx->stream));
       PRISM_HIP(hipStreamSynchronize(ctx->stream));
       for (int s = 0; s < ap.n_slots; ++s) g.state[s] = both[(size_t)s * 2];
-      if (fused) selected = fused_selected;
+      if (fused) selected = *fused_slot();
     } else {
       // a selection vector of few rows: gather them
       std::vector<int64_t> init(ap.n_slots);
@@ -1873,7 +1887,7 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
     }
     if (!dense && !use_part) plan->learned_capacity.store(capacity, std::memory_order_relaxed);
     // lands with the next synchronisation of the stream (every path below has one before the statistics)
-    if (fused) PRISM_HIP(hipMemcpyAsync(&fused_selected, d_scalar.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (fused) PRISM_HIP(hipMemcpyAsync(fused_slot(), d_scalar.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     if (capture) {
       PRISM_HIP(hipStreamSynchronize(ctx->stream));
       collect_timings(ctx);
@@ -1885,7 +1899,7 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       st->low = low;
       st->gt = std::move(gt);
       st->slot_ops = slot_ops;
-      if (fused) selected = fused_selected;
+      if (fused) selected = *fused_slot();
       st->distinct = plan->distinct_plan ? 1 : 0;
       st->selected = selected;
       {
@@ -1913,7 +1927,7 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
   }
   PRISM_HIP(hipStreamSynchronize(ctx->stream));
   collect_timings(ctx);
-  if (fused && !plan->keys.empty()) selected = fused_selected;
+  if (fused && !plan->keys.empty()) selected = *fused_slot();
   if (!partial) sort_and_limit(plan, cols);
   {
     std::lock_guard<std::mutex> g(ctx->mu);
@@ -2023,15 +2037,18 @@ void execute_noalloc(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_
 
   ScanSet ss;
   ss.ctx = ctx;
-  for (const Chunk& ch : table->chunks) {
-    bool take = partition_ids == nullptr || n_partitions == 0;
-    for (size_t i = 0; !take && i < n_partitions; ++i) take = partition_ids[i] == ch.partition_id;
-    if (!take || ch.rows == 0) continue;
-    if (plan->pred_root >= 0 && !chunk_may_match(plan, table, plan->pred_root, ch)) continue;
-    ss.chunks.push_back(&ch);
-    ss.segs.push_back({ch.rows, ss.n_tiles});
-    ss.n_tiles += ceil_div(ch.rows, kTileRows);
-    ss.rows += ch.rows;
+  {
+    std::lock_guard<std::mutex> chunks_lock(table->mu);  // appends may be adding chunks
+    for (const Chunk& ch : table->chunks) {
+      bool take = partition_ids == nullptr || n_partitions == 0;
+      for (size_t i = 0; !take && i < n_partitions; ++i) take = partition_ids[i] == ch.partition_id;
+      if (!take || ch.rows == 0) continue;
+      if (plan->pred_root >= 0 && !chunk_may_match(plan, table, plan->pred_root, ch)) continue;
+      ss.chunks.push_back(&ch);
+      ss.segs.push_back({ch.rows, ss.n_tiles});
+      ss.n_tiles += ceil_div(ch.rows, kTileRows);
+      ss.rows += ch.rows;
+    }
   }
   *n_groups = 0;
   if (ss.chunks.empty()) return;
@@ -2163,10 +2180,13 @@ void scan_stats(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* pa
   table_sync_stats(table);
   ScanSet ss;
   ss.ctx = plan->ctx;
-  for (const Chunk& ch : table->chunks) {
-    bool take = partition_ids == nullptr || n_partitions == 0;
-    for (size_t i = 0; !take && i < n_partitions; ++i) take = partition_ids[i] == ch.partition_id;
-    if (take && ch.rows) ss.chunks.push_back(&ch);
+  {
+    std::lock_guard<std::mutex> chunks_lock(table->mu);  // appends may be adding chunks
+    for (const Chunk& ch : table->chunks) {
+      bool take = partition_ids == nullptr || n_partitions == 0;
+      for (size_t i = 0; !take && i < n_partitions; ++i) take = partition_ids[i] == ch.partition_id;
+      if (take && ch.rows) ss.chunks.push_back(&ch);
+    }
   }
   for (size_t c = 0; c < table->fields.size(); ++c) {
     ColInfo ci = col_info(ss, (int)c);

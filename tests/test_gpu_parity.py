@@ -270,8 +270,11 @@ def test_unsupported_and_invalid_plans(gpu_ctx):
     with pytest.raises(PrismGpuError) as e:
         Plan(gpu_ctx, t.schema, QueryPlan([count_star()], keys=[date_bin(0, "ts")]))
     assert e.value.code == abi.EINVAL
+    with pytest.raises(PrismGpuError) as e:  # COUNT(DISTINCT) beside other aggregates has no PARTIAL form
+        Plan(gpu_ctx, t.schema, QueryPlan([count_distinct("user"), count_star()]).with_mode(abi.MODE_PARTIAL))
+    assert e.value.code == abi.EUNSUPPORTED
     with pytest.raises(PrismGpuError) as e:
-        Plan(gpu_ctx, t.schema, QueryPlan([count_distinct("user"), count_star()]))
+        Plan(gpu_ctx, t.schema, QueryPlan([count_distinct("user"), count_distinct("i16")]))
     assert e.value.code == abi.EUNSUPPORTED
     with pytest.raises(KeyError):
         Plan(gpu_ctx, t.schema, QueryPlan([count_star()], keys=["something"]))
