@@ -301,6 +301,9 @@ struct TopKState {
   uint32_t exact;         // all 64 rank bits are resolved: of the entries whose rank equals `prefix`
                           // only k_rem are wanted (ties are broken arbitrarily)
   unsigned long long ties_taken;  // ties let through by the emit pass in progress
+  // OR and AND of every occupied entry's rank (gathered by the first pass): where they agree
+  // the bit is the same in all ranks, and a pass whose bits are all of that kind is skipped
+  unsigned long long or_bits, and_bits;
   uint32_t hist[kTopKBins];
 };
 // Leaves the threshold in d_state->prefix.  d_state is overwritten.

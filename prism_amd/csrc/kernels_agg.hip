@@ -506,15 +506,32 @@ __global__ __launch_bounds__(kBlock) void k_topk_hist(TopKOrder o, int dense, ui
                                                      TopKState* st, int shift, int bits) {
   __shared__ uint32_t h[kTopKBins];
   if (st->done) return;
+  const bool first = shift + bits == 64;
+  // (counts and the like use a few low bits: the passes over bits no rank differs in do nothing)
+  if (!first && (((st->or_bits ^ st->and_bits) >> shift) & ((1ull << bits) - 1ull)) == 0) return;
   for (int b = threadIdx.x; b < kTopKBins; b += kBlock) h[b] = 0;
   __syncthreads();
   const uint64_t prefix = st->prefix, mask = st->mask;
   const uint64_t n = dense ? capacity : capacity + 1;
+  unsigned long long all_or = 0ull, all_and = ~0ull;
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
     if (g_state[i] == 0) continue;  // slot 0 counts the rows of the group
     const uint64_t r = topk_rank(o, dense != 0, capacity, g_keys, g_keys_hi, g_state, i);
+    all_or |= r;
+    all_and &= r;
     if ((r & mask) != prefix) continue;
     atomicAdd(&h[(r >> shift) & ((1u << bits) - 1)], 1u);
+  }
+  if (first) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      all_or |= __shfl_xor(all_or, off, 64);
+      all_and &= __shfl_xor(all_and, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      if (all_or) atomicOr(&st->or_bits, all_or);
+      if (all_and != ~0ull) atomicAnd(&st->and_bits, all_and);
+    }
   }
   __syncthreads();
   for (int b = threadIdx.x; b < kTopKBins; b += kBlock)
@@ -531,6 +548,16 @@ __global__ __launch_bounds__(kBlock) void k_topk_pick(TopKState* st, int shift, 
   const bool done = st->done != 0;
   const uint64_t k = st->k_rem;
   const int t = threadIdx.x;
+  // the pass was skipped: its bits are the same in every rank
+  if (shift + bits != 64 && !done && (((st->or_bits ^ st->and_bits) >> shift) & ((1ull << bits) - 1ull)) == 0) {
+    if (t == 0) {
+      const uint64_t field = ((1ull << bits) - 1ull) << shift;
+      st->prefix |= st->and_bits & field;
+      st->mask |= field;
+      if (shift == 0) st->exact = 1u;
+    }
+    return;
+  }
   // thread t owns bins [top - kPer + 1, top], walked from the top down
   const int top = kTopKBins - 1 - t * kPer;
   uint32_t c[kPer];
@@ -843,12 +870,17 @@ void launch_topk_threshold(prism_gpu_ctx* ctx, bool dense, uint64_t capacity, co
   const uint64_t n = dense ? capacity : capacity + 1;
   PRISM_HIP(hipMemsetAsync(d_state, 0, sizeof(TopKState), ctx->stream));
   PRISM_HIP(hipMemcpyAsync(&d_state->k_rem, &k, 8, hipMemcpyHostToDevice, ctx->stream));
+  PRISM_HIP(hipMemsetAsync(&d_state->and_bits, 0xff, 8, ctx->stream));
   KernelTimer timer(ctx, "topk_select", n * 16);
+  // Few workgroups: each ends with updates of the bins its entries fell into, which for
+  // counts and the like are the same few bins for everybody, and updates of one address are
+  // carried out one after the other.
+  const uint32_t grid = (uint32_t)std::min<uint64_t>(stream_grid(ctx, n), std::max<uint64_t>((uint64_t)ctx->n_cus, n / 4096));
   // 64 rank bits, most significant first: five passes of 11 bits and one of 9
   for (int hi = 64; hi > 0;) {
     const int bits = hi >= 11 ? 11 : hi;
     const int shift = hi - bits;
-    k_topk_hist<<<dim3(stream_grid(ctx, n)), dim3(kBlock), 0, ctx->stream>>>(order, dense ? 1 : 0, capacity, g_keys, g_keys_hi,
+    k_topk_hist<<<dim3(grid), dim3(kBlock), 0, ctx->stream>>>(order, dense ? 1 : 0, capacity, g_keys, g_keys_hi,
                                                                            (const long long*)g_state, d_state, shift, bits);
     k_topk_pick<<<dim3(1), dim3(kBlock), 0, ctx->stream>>>(d_state, shift, bits);
     hi = shift;

@@ -538,6 +538,36 @@ __global__ __launch_bounds__(kPartBlock) void k_part_agg(AggParams p, PartParams
         for (int w = 0; w < W; ++w) rec[u][w] = next[u][w];
       }
       if (base + kStep < it.hi) request(base + kStep);
+      // One-word keys: the two home buckets of all the step's rows are read before any of
+      // them is looked at, so the LDS latencies overlap instead of adding up row after row (a
+      // key that another row of the step inserts meanwhile is simply not seen here: the row
+      // then takes the search-and-insert path, which reads again).
+      int found[kPartAggInFlight];
+      if (KW == 1) {
+        ulonglong2 c1[kPartAggInFlight], c2[kPartAggInFlight];
+        uint32_t hb1[kPartAggInFlight], hb2[kPartAggInFlight];
+        const uint32_t nb = S / 2;
+#pragma unroll
+        for (int u = 0; u < kPartAggInFlight; ++u) {
+          const uint64_t lo = rec[u][0];
+          const uint32_t m1 = ((uint32_t)lo ^ (uint32_t)(lo >> 32)) * 0x9E3779B1u;
+          const uint32_t m2 = (m1 ^ (m1 >> 15)) * 0x85EBCA6Bu;
+          hb1[u] = __umulhi(m1, nb);
+          hb2[u] = __umulhi(m2, nb);
+          c1[u] = *(const ulonglong2*)&keys_lo[2 * (size_t)hb1[u]];
+          c2[u] = *(const ulonglong2*)&keys_lo[2 * (size_t)hb2[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < kPartAggInFlight; ++u) {
+          const uint64_t lo = rec[u][0];
+          int f = -1;
+          f = c2[u].y == lo ? (int)(2 * hb2[u] + 1) : f;
+          f = c2[u].x == lo ? (int)(2 * hb2[u]) : f;
+          f = c1[u].y == lo ? (int)(2 * hb1[u] + 1) : f;
+          f = c1[u].x == lo ? (int)(2 * hb1[u]) : f;
+          found[u] = f;
+        }
+      }
 #pragma unroll
       for (int u = 0; u < kPartAggInFlight; ++u) {
         const uint64_t lo = rec[u][0], hi = KW == 2 ? rec[u][KW - 1] : 0ull;
@@ -584,22 +614,10 @@ __global__ __launch_bounds__(kPartBlock) void k_part_agg(AggParams p, PartParams
         int e = -1;
         bool ins = false;
         bool search = act && lo != kPartEmpty;
-        if (KW == 1) {
-          // Most rows find their key in one of its two home buckets: both are read at once and
-          // compared without a branch; only the lanes that found nothing (new keys, as a rule)
-          // enter the search-and-insert loop.
-          const uint32_t nb = S / 2;
-          const uint32_t m1 = ((uint32_t)lo ^ (uint32_t)(lo >> 32)) * 0x9E3779B1u;
-          const uint32_t m2 = (m1 ^ (m1 >> 15)) * 0x85EBCA6Bu;
-          const uint32_t b1 = __umulhi(m1, nb), b2 = __umulhi(m2, nb);
-          const ulonglong2 c1 = *(const ulonglong2*)&keys_lo[2 * (size_t)b1], c2 = *(const ulonglong2*)&keys_lo[2 * (size_t)b2];
-          int f = -1;
-          f = c2.y == lo ? (int)(2 * b2 + 1) : f;
-          f = c2.x == lo ? (int)(2 * b2) : f;
-          f = c1.y == lo ? (int)(2 * b1 + 1) : f;
-          f = c1.x == lo ? (int)(2 * b1) : f;
-          if (search && f >= 0) { e = f; search = false; }
-        }
+        // Most rows find their key in one of its two home buckets (read above, compared without
+        // a branch); only the lanes that found nothing (new keys, as a rule) enter the
+        // search-and-insert loop.
+        if (KW == 1 && search && found[u] >= 0) { e = found[u]; search = false; }
         if (search) e = part_find<KW>(keys_lo, keys_hi, S, (int)q.lds_limit, &n_entries, lo, hi, ins);
         const uint64_t m_ins = __ballot(ins);
         if (m_ins && (int)lane == __ffsll((long long)m_ins) - 1) atomicAdd(&n_entries, __popcll(m_ins));
