@@ -6,6 +6,7 @@
 // predicate that produced it had to read.
 #include <algorithm>
 
+#include "context.hpp"
 #include "device_utils.hpp"
 
 namespace prism {
@@ -20,8 +21,8 @@ __global__ __launch_bounds__(64) void k_tile_counts(const uint64_t* bits, uint64
   }
 }
 
-// Single-block exclusive scan; counts[n] receives the total.  n is at most a few
-// hundred thousand tiles, so one block walking it in 1024-element steps is enough.
+// Single-block exclusive scan; counts[n] receives the total.  Used directly for up to 8192
+// tiles, and for the run totals of larger scans.
 __global__ __launch_bounds__(1024) void k_scan_counts(uint32_t* counts, uint64_t n, unsigned long long* total) {
   __shared__ uint32_t wave_tot[16];
   __shared__ unsigned long long carry;
@@ -49,6 +50,36 @@ __global__ __launch_bounds__(1024) void k_scan_counts(uint32_t* counts, uint64_t
   if (threadIdx.x == 0) {
     counts[n] = (uint32_t)carry;
     *total = carry;
+  }
+}
+
+// Many tiles: every workgroup scans a run of 1024 counts in place and leaves the run's total;
+// the totals are scanned by the single-block kernel above and added back.
+__global__ __launch_bounds__(1024) void k_scan_runs(uint32_t* counts, uint64_t n, uint32_t* run_totals) {
+  __shared__ uint32_t wave_tot[16];
+  const uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
+  const uint32_t v = i < n ? counts[i] : 0;
+  uint32_t incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = __shfl_up(incl, off, 64);
+    if ((int)(threadIdx.x & 63) >= off) incl += o;
+  }
+  if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  uint32_t before = 0;
+  for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) before += wave_tot[w];
+  if (i < n) counts[i] = before + incl - v;
+  if (threadIdx.x == 1023) run_totals[blockIdx.x] = before + incl;
+}
+
+__global__ __launch_bounds__(1024) void k_add_run_offsets(uint32_t* counts, uint64_t n, const uint32_t* run_offsets,
+                                                          uint64_t n_runs, unsigned long long* total) {
+  const uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
+  if (i < n) counts[i] += run_offsets[blockIdx.x];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    counts[n] = run_offsets[n_runs];
+    *total = run_offsets[n_runs];
   }
 }
 
@@ -94,7 +125,16 @@ void launch_compact(prism_gpu_ctx* ctx, const uint64_t* bits, uint64_t n_tiles, 
   if (selvec == nullptr) {
     k_tile_counts<<<dim3(grid), dim3(64), 0, ctx->stream>>>(bits, n_tiles, tile_offsets);
     PRISM_HIP(hipGetLastError());
-    k_scan_counts<<<dim3(1), dim3(1024), 0, ctx->stream>>>(tile_offsets, n_tiles, total);
+    if (n_tiles <= 8192) {
+      k_scan_counts<<<dim3(1), dim3(1024), 0, ctx->stream>>>(tile_offsets, n_tiles, total);
+    } else {
+      // (the block of run totals goes back to the pool right away: the stream orders its reuse)
+      const uint64_t n_runs = ceil_div(n_tiles, 1024);
+      Scratch runs(ctx, (n_runs + 1) * 4);
+      k_scan_runs<<<dim3((uint32_t)n_runs), dim3(1024), 0, ctx->stream>>>(tile_offsets, n_tiles, runs.as<uint32_t>());
+      k_scan_counts<<<dim3(1), dim3(1024), 0, ctx->stream>>>(runs.as<uint32_t>(), n_runs, total);
+      k_add_run_offsets<<<dim3((uint32_t)n_runs), dim3(1024), 0, ctx->stream>>>(tile_offsets, n_tiles, runs.as<uint32_t>(), n_runs, total);
+    }
     PRISM_HIP(hipGetLastError());
     return;
   }

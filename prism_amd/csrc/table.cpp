@@ -200,16 +200,25 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
   } releaser{batches, n_batches, take};
 
   int64_t n = 0;
+  std::vector<std::vector<ArrowArray>> views(n_batches);
   for (size_t b = 0; b < n_batches; ++b) {
     const ArrowArray* batch = batches[b];
     if (!batch) fail(PRISM_GPU_EINVAL, "batch is null");
     if (batch->n_children != (int64_t)t->fields.size())
       fail(PRISM_GPU_EINVAL, "batch has " + std::to_string(batch->n_children) + " columns, table schema has " +
                                  std::to_string(t->fields.size()));
-    if (batch->offset != 0) fail(PRISM_GPU_EUNSUPPORTED, "struct arrays with a non-zero offset are not supported");
+    if (batch->offset < 0 || batch->length < 0) fail(PRISM_GPU_EINVAL, "batch has a negative offset or length");
     for (size_t ci = 0; ci < t->fields.size(); ++ci)
-      if (batch->children[ci]->length != batch->length)
-        fail(PRISM_GPU_EINVAL, "column " + t->fields[ci].name + " has a different length than the batch");
+      if (batch->children[ci]->length < batch->offset + batch->length)
+        fail(PRISM_GPU_EINVAL, "column " + t->fields[ci].name + " is shorter than the batch");
+    // A struct array's offset and length select rows [offset, offset + length) of every child
+    // (on top of the child's own offset): the columns are read through adjusted views.
+    views[b].resize(t->fields.size());
+    for (size_t ci = 0; ci < t->fields.size(); ++ci) {
+      views[b][ci] = *batch->children[ci];
+      views[b][ci].offset += batch->offset;
+      views[b][ci].length = batch->length;
+    }
     n += batch->length;
   }
   if (n == 0) return;
@@ -239,14 +248,14 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
     // ---- validity: one bitmap for the chunk, present only if some row is NULL ----
     bool any_null = false;
     for (size_t b = 0; b < n_batches && !any_null; ++b) {
-      const ArrowArray* a = batches[b]->children[ci];
+      const ArrowArray* a = &views[b][ci];
       any_null = a->null_count != 0 && a->n_buffers > 0 && a->buffers[0] != nullptr && a->length > 0;
     }
     if (any_null) {
       std::vector<uint64_t> words((size_t)ceil_div((uint64_t)n, kTileRows) * kTileWords, 0);  // whole tiles: kernels read a tile's words even past the last row
       uint64_t at = 0;
       for (size_t b = 0; b < n_batches; ++b) {
-        const ArrowArray* a = batches[b]->children[ci];
+        const ArrowArray* a = &views[b][ci];
         const uint8_t* vbits = (a->null_count != 0 && a->n_buffers > 0) ? (const uint8_t*)a->buffers[0] : nullptr;
         append_bits(words, at, vbits, a->offset, a->length);
         at += (uint64_t)a->length;
@@ -266,7 +275,7 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
       dc.values = dev_alloc(t, (size_t)n * f.width);
       w.begin(dc.values);
       for (size_t b = 0; b < n_batches; ++b) {
-        const ArrowArray* a = batches[b]->children[ci];
+        const ArrowArray* a = &views[b][ci];
         if (a->dictionary) fail(PRISM_GPU_EUNSUPPORTED, "dictionary encoding is only supported for string columns");
         if (a->length == 0) continue;
         if (a->n_buffers < 2 || !a->buffers[1]) fail(PRISM_GPU_EINVAL, "column " + f.name + " has no value buffer");
@@ -285,7 +294,7 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
     // batches' dictionaries).
     bool codes_only = t->pooled && dict.alive && t->chunks.empty();
     for (size_t b = 0; b < n_batches && codes_only; ++b) {
-      const ArrowArray* a = batches[b]->children[ci];
+      const ArrowArray* a = &views[b][ci];
       codes_only = a->length == 0 || (a->dictionary != nullptr && a->dictionary->length <= 4096);
     }
     std::vector<int32_t> offs(codes_only ? 1 : (size_t)n + 1);
@@ -297,7 +306,7 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
     std::vector<std::vector<uint8_t>> expanded;  // raw bytes of dictionary-encoded input
     int64_t row0 = 0;
     for (size_t b = 0; b < n_batches; ++b) {
-      const ArrowArray* a = batches[b]->children[ci];
+      const ArrowArray* a = &views[b][ci];
       const int64_t nb = a->length;
       if (nb == 0) continue;
       const uint8_t* vbits = (a->null_count != 0 && a->n_buffers > 0) ? (const uint8_t*)a->buffers[0] : nullptr;

@@ -196,6 +196,25 @@ def test_sliced_batches_with_offsets(gpu_ctx, oracle):
         g.append(1, b.slice(1013, 1987))
         assert_tables_match(plan.execute(g), oracle.execute(t.slice(13, 2987), q), 1)
     finally:
+        g.close()
+    # the same rows as struct arrays whose own offset selects them (the children keep all their
+    # rows; one child is itself sliced, so both offsets add up)
+    import ctypes as C
+
+    from prism_amd.engine import _check
+
+    g = Table(gpu_ctx, t.schema)
+    try:
+        cols = [b.column(i) for i in range(b.num_columns)]
+        cols[2] = pa.concat_arrays([cols[2].slice(0, 5), cols[2]]).slice(5)  # child offset 5
+        st = pa.StructArray.from_arrays(cols, fields=list(t.schema))
+        for part, (lo, n) in enumerate([(13, 1000), (1013, 1987)]):
+            arr = abi.ArrowArray()
+            st.slice(lo, n)._export_to_c(C.addressof(arr))
+            assert arr.offset == lo and arr.length == n
+            _check(g._lib.prism_gpu_table_append(g._h, part, C.byref(arr)))
+        assert_tables_match(plan.execute(g), oracle.execute(t.slice(13, 2987), q), 1)
+    finally:
         plan.close()
         g.close()
 
