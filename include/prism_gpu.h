@@ -142,9 +142,9 @@ typedef enum prism_gpu_agg_func {
   PRISM_AGG_MIN = 4,        /* type preserving, NULLs ignored                  */
   PRISM_AGG_MAX = 5,
   PRISM_AGG_AVG = 6,        /* Float64 = f64 sum of values cast to f64 / count */
-  PRISM_AGG_COUNT_DISTINCT = 7 /* every COUNT(DISTINCT) of a plan over the same column.  Next to
-                                  other aggregates: SINGLE mode over resident partitions only
-                                  (prism_gpu_execute; two passes joined on the group keys) */
+  PRISM_AGG_COUNT_DISTINCT = 7 /* Next to other aggregates, or over more than one column: SINGLE
+                                  mode over resident partitions only (prism_gpu_execute: one
+                                  pass per kind of aggregate, joined on the group keys) */
 } prism_gpu_agg_func;
 
 typedef struct prism_gpu_agg {

@@ -115,11 +115,12 @@ struct prism_gpu_plan {
   uint64_t groups_hint = 0;
   bool distinct_plan = false;
   int distinct_col = -1;
-  // COUNT(DISTINCT) next to other aggregates (SINGLE mode): the plan runs as two plans over the
-  // same rows -- the other aggregates, and the COUNT(DISTINCT)s -- whose results are joined on
-  // the group keys.  mixed_map[i] = (0: sub_plain / 1: sub_distinct, aggregate index there).
+  // COUNT(DISTINCT) next to other aggregates, or over several columns (SINGLE mode): the plan
+  // runs as several plans over the same rows -- the other aggregates, and the COUNT(DISTINCT)s
+  // of each column -- whose results are joined on the group keys.
+  // mixed_map[i] = (sub-plan, aggregate index there) of the plan's i-th aggregate.
   bool mixed = false;
-  std::unique_ptr<prism_gpu_plan> sub_plain, sub_distinct;
+  std::vector<std::unique_ptr<prism_gpu_plan>> subs;
   std::vector<std::pair<int, int>> mixed_map;
   std::vector<prism::FieldType> partial_fields, final_fields;
   // capacity the GROUP BY hash table ended up with the last time this plan ran: the next

@@ -1963,51 +1963,59 @@ void append_row_key(const std::vector<OutColumn>& cols, size_t n_keys, size_t ro
   }
 }
 
-// COUNT(DISTINCT) next to other aggregates: both sub-plans see the same rows and therefore
-// the same groups; the distinct counts are looked up by group key and placed beside the
-// other aggregates, in the order the plan lists them.
+// COUNT(DISTINCT) next to other aggregates or over several columns: the sub-plans see the
+// same rows and therefore the same groups; the first one's rows give the order, the others'
+// aggregates are looked up by group key and placed in the order the plan lists them.
 void execute_mixed(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions, ArrowArray* out) {
-  std::vector<OutColumn> a, b;
-  execute_impl(plan->sub_plain.get(), table, partition_ids, n_partitions, false, nullptr, nullptr, nullptr, false, nullptr, &a);
-  execute_impl(plan->sub_distinct.get(), table, partition_ids, n_partitions, false, nullptr, nullptr, nullptr, false, nullptr, &b);
-  const size_t n_keys = plan->keys.size();
-  const size_t rows = a.empty() ? 0 : a[0].rows();
-  if ((b.empty() ? 0 : b[0].rows()) != rows) fail(PRISM_GPU_EINTERNAL, "the two halves of the plan found different groups");
-  std::vector<size_t> b_row(rows);
-  if (n_keys == 0 || rows <= 1) {
-    for (size_t i = 0; i < rows; ++i) b_row[i] = i;
-  } else {
+  const size_t n_subs = plan->subs.size(), n_keys = plan->keys.size();
+  std::vector<std::vector<OutColumn>> res(n_subs);
+  for (size_t k = 0; k < n_subs; ++k)
+    execute_impl(plan->subs[k].get(), table, partition_ids, n_partitions, false, nullptr, nullptr, nullptr, false, nullptr, &res[k]);
+  const size_t rows = res[0].empty() ? 0 : res[0][0].rows();
+  std::vector<std::vector<size_t>> row_of(n_subs, std::vector<size_t>(rows));
+  std::string key;
+  for (size_t k = 0; k < n_subs; ++k) {
+    if ((res[k].empty() ? 0 : res[k][0].rows()) != rows) fail(PRISM_GPU_EINTERNAL, "the parts of the plan found different groups");
+    if (k == 0 || n_keys == 0 || rows <= 1) {
+      for (size_t i = 0; i < rows; ++i) row_of[k][i] = i;
+      continue;
+    }
     std::unordered_map<std::string, size_t> where;
     where.reserve(rows * 2);
-    std::string key;
     for (size_t i = 0; i < rows; ++i) {
-      append_row_key(b, n_keys, i, key);
+      append_row_key(res[k], n_keys, i, key);
       where.emplace(key, i);
     }
     for (size_t i = 0; i < rows; ++i) {
-      append_row_key(a, n_keys, i, key);
+      append_row_key(res[0], n_keys, i, key);
       auto it = where.find(key);
-      if (it == where.end()) fail(PRISM_GPU_EINTERNAL, "the two halves of the plan found different groups");
-      b_row[i] = it->second;
+      if (it == where.end()) fail(PRISM_GPU_EINTERNAL, "the parts of the plan found different groups");
+      row_of[k][i] = it->second;
     }
   }
   std::vector<OutColumn> cols = make_columns(plan->final_fields);
-  for (size_t c = 0; c < n_keys; ++c) {
-    FieldType t = cols[c].type;
-    cols[c] = std::move(a[c]);
-    cols[c].type = t;
-  }
   for (size_t i = 0; i < plan->aggs.size(); ++i) {
     OutColumn& dst = cols[n_keys + i];
-    const auto [which, idx] = plan->mixed_map[i];
-    if (which == 0) {
+    const auto [k, idx] = plan->mixed_map[i];
+    OutColumn& src = res[(size_t)k][n_keys + (size_t)idx];
+    if (k == 0) {
       FieldType t = dst.type;
-      dst = std::move(a[n_keys + (size_t)idx]);
+      dst = std::move(src);
       dst.type = t;
-    } else {
-      const OutColumn& src = b[n_keys + (size_t)idx];
-      for (size_t r = 0; r < rows; ++r) dst.push_int(src.i64_data()[b_row[r]]);
+      continue;
     }
+    src.materialise();
+    for (size_t r = 0; r < rows; ++r) {
+      const size_t at = row_of[(size_t)k][r];
+      if (!src.valid[at]) dst.push_null();
+      else if (src.type.is_float) dst.push_float(src.f64[at]);
+      else dst.push_int(src.i64[at]);
+    }
+  }
+  for (size_t c = 0; c < n_keys; ++c) {
+    FieldType t = cols[c].type;
+    cols[c] = std::move(res[0][c]);
+    cols[c].type = t;
   }
   sort_and_limit(plan, cols);
   export_record_batch(cols, out);

@@ -195,6 +195,7 @@ std::unique_ptr<prism_gpu_plan> plan_create(prism_gpu_ctx* ctx, const ArrowSchem
     plan->keys.push_back(kp);
   }
   uint32_t n_distinct = 0;
+  bool several_distinct_columns = false;
   for (uint32_t i = 0; i < d->n_aggs; ++i) {
     const prism_gpu_agg& a = d->aggs[i];
     AggPlan ap;
@@ -208,8 +209,7 @@ std::unique_ptr<prism_gpu_plan> plan_create(prism_gpu_ctx* ctx, const ArrowSchem
       const FieldType& f = plan->fields[a.column];
       if (a.func == PRISM_AGG_COUNT_DISTINCT) {
         ++n_distinct;
-        if (plan->distinct_col >= 0 && plan->distinct_col != a.column)
-          fail(PRISM_GPU_EUNSUPPORTED, "COUNT(DISTINCT) over more than one column");
+        if (plan->distinct_col >= 0 && plan->distinct_col != a.column) several_distinct_columns = true;
         plan->distinct_col = a.column;
       } else if (a.func != PRISM_AGG_COUNT) {
         if (f.is_string) fail(PRISM_GPU_EUNSUPPORTED, "SUM/MIN/MAX/AVG over string columns are not supported");
@@ -221,25 +221,29 @@ std::unique_ptr<prism_gpu_plan> plan_create(prism_gpu_ctx* ctx, const ArrowSchem
     ap.name = a.name ? a.name : default_agg_name(*plan, ap);
     plan->aggs.push_back(ap);
   }
-  if (n_distinct && n_distinct != d->n_aggs) {
-    // COUNT(DISTINCT) next to other aggregates: two plans over the same rows, joined on the keys
+  if (n_distinct && (n_distinct != d->n_aggs || several_distinct_columns)) {
+    // COUNT(DISTINCT) next to other aggregates, or over several columns: one plan per kind
+    // over the same rows, joined on the keys
     if (d->mode != PRISM_MODE_SINGLE)
-      fail(PRISM_GPU_EUNSUPPORTED, "COUNT(DISTINCT) next to other aggregates is supported in SINGLE mode only");
-    std::vector<prism_gpu_agg> plain, distinct;
+      fail(PRISM_GPU_EUNSUPPORTED, "COUNT(DISTINCT) next to other aggregates or over several columns is supported in SINGLE mode only");
+    std::vector<std::vector<prism_gpu_agg>> kinds;  // [0]: the other aggregates (if any), then one per distinct column
+    std::vector<int> kind_column;                   // -1: the other aggregates
     for (uint32_t i = 0; i < d->n_aggs; ++i) {
-      const bool is_d = d->aggs[i].func == PRISM_AGG_COUNT_DISTINCT;
-      plan->mixed_map.emplace_back(is_d ? 1 : 0, (int)(is_d ? distinct.size() : plain.size()));
-      (is_d ? distinct : plain).push_back(d->aggs[i]);
+      const int col = d->aggs[i].func == PRISM_AGG_COUNT_DISTINCT ? d->aggs[i].column : -1;
+      size_t k = 0;
+      while (k < kinds.size() && kind_column[k] != col) ++k;
+      if (k == kinds.size()) { kinds.emplace_back(); kind_column.push_back(col); }
+      plan->mixed_map.emplace_back((int)k, (int)kinds[k].size());
+      kinds[k].push_back(d->aggs[i]);
     }
-    prism_gpu_plan_desc sub = *d;
-    sub.order_by = -1;
-    sub.limit = -1;
-    sub.aggs = plain.data();
-    sub.n_aggs = (uint32_t)plain.size();
-    plan->sub_plain = plan_create(ctx, schema, &sub);
-    sub.aggs = distinct.data();
-    sub.n_aggs = (uint32_t)distinct.size();
-    plan->sub_distinct = plan_create(ctx, schema, &sub);
+    for (auto& aggs : kinds) {
+      prism_gpu_plan_desc sub = *d;
+      sub.order_by = -1;
+      sub.limit = -1;
+      sub.aggs = aggs.data();
+      sub.n_aggs = (uint32_t)aggs.size();
+      plan->subs.push_back(plan_create(ctx, schema, &sub));
+    }
     plan->mixed = true;
     plan->distinct_col = -1;
   } else if (n_distinct) {

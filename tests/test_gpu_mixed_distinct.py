@@ -15,40 +15,36 @@ from prism_amd.plan import QueryPlan, avg, col, count_distinct, count_star, date
 
 
 def _expected(oracle, t, keys, aggs, predicate):
-    plain = [a for a in aggs if a.func != abi.AGG_COUNT_DISTINCT]
-    distinct = [a for a in aggs if a.func == abi.AGG_COUNT_DISTINCT]
-    a = oracle.execute(t, QueryPlan(plain, keys=keys, predicate=predicate))
-    b = oracle.execute(t, QueryPlan(distinct, keys=keys, predicate=predicate))
+    """One oracle run per kind of aggregate (the plain ones; the COUNT(DISTINCT)s of each
+    column), aligned on the group keys."""
+    kinds = {}
+    for i, a in enumerate(aggs):
+        kinds.setdefault(a.column if a.func == abi.AGG_COUNT_DISTINCT else None, []).append(i)
     n_keys = len(keys)
-    if n_keys:
-        knames = a.schema.names[:n_keys]
-        b = b.rename_columns(knames + [f"__d{i}" for i in range(len(distinct))])
-        j = a.join(b, keys=knames, join_type="inner") if all(a.column(k).null_count == 0 for k in knames) else None
-        if j is None:  # join keys with NULLs: align by hand
-            rows_b = {tuple(r[k] for k in knames): r for r in b.to_pylist()}
-            extra = {f"__d{i}": [] for i in range(len(distinct))}
-            for r in a.to_pylist():
-                m = rows_b[tuple(r[k] for k in knames)]
-                for i in range(len(distinct)):
-                    extra[f"__d{i}"].append(m[f"__d{i}"])
-            j = a
-            for name, vals in extra.items():
-                j = j.append_column(name, pa.array(vals, pa.int64()))
-    else:
-        knames = []
-        j = a
-        for i in range(len(distinct)):
-            j = j.append_column(f"__d{i}", b.column(i))
-    cols, names, ia, ib = [j.column(k) for k in knames], list(knames), 0, 0
-    for ag in aggs:
-        if ag.func == abi.AGG_COUNT_DISTINCT:
-            cols.append(j.column(f"__d{ib}"))
-            ib += 1
-        else:
-            cols.append(j.column(a.schema.names[n_keys + ia]))
-            ia += 1
-        names.append(f"c{len(names)}")
-    return pa.table(cols, names=names)
+    per_kind = {}
+    for kind, idxs in kinds.items():
+        res = oracle.execute(t, QueryPlan([aggs[i] for i in idxs], keys=keys, predicate=predicate))
+        rows = {}
+        for r in range(res.num_rows):
+            key = tuple(res.column(c)[r].as_py() for c in range(n_keys))
+            rows[key] = [res.column(n_keys + j)[r].as_py() for j in range(len(idxs))]
+        per_kind[kind] = (res, rows)
+    base, _ = next(iter(per_kind.values()))
+    out_rows = []
+    for r in range(base.num_rows):
+        key = tuple(base.column(c)[r].as_py() for c in range(n_keys))
+        vals = [None] * len(aggs)
+        for kind, idxs in kinds.items():
+            for j, i in enumerate(idxs):
+                vals[i] = per_kind[kind][1][key][j]
+        out_rows.append(list(key) + vals)
+    cols = list(zip(*out_rows)) if out_rows else [[] for _ in range(n_keys + len(aggs))]
+    arrays = [pa.array(list(cols[c]), type=base.column(c).type) for c in range(n_keys)]
+    for i, a in enumerate(aggs):
+        kind = a.column if a.func == abi.AGG_COUNT_DISTINCT else None
+        src = per_kind[kind][0]
+        arrays.append(pa.array(list(cols[n_keys + i]), type=src.column(n_keys + kinds[kind].index(i)).type))
+    return pa.table(arrays, names=[f"c{c}" for c in range(len(arrays))])
 
 
 @pytest.mark.parametrize("keys,aggs,pred", [
@@ -56,6 +52,9 @@ def _expected(oracle, t, keys, aggs, predicate):
     (["service", "i16"], [count_distinct("user"), max_("u16"), avg("value")], "filter"),
     ([], [count_distinct("i16"), count_star(), max_("value")], "filter"),
     ([date_bin(3_600_000, "ts")], [sum_("i32"), count_distinct("service")], None),
+    (["service"], [count_distinct("user"), count_distinct("i16")], None),                       # two distinct columns
+    (["i16"], [count_distinct("service"), count_star(), count_distinct("user"), count_distinct("service")], "filter"),
+    ([], [count_distinct("user"), count_distinct("value")], None),
 ])
 def test_count_distinct_beside_other_aggregates(gpu_ctx, keys, aggs, pred):
     from oracle import pyoracle
@@ -96,6 +95,7 @@ def test_order_by_the_distinct_count_and_what_is_refused(gpu_ctx):
         top = sorted(want.column(2).to_pylist(), reverse=True)[:3]
         assert got.num_rows == 3 and got.column(2).to_pylist() == top
         by_service = {r["service"]: r for r in want.rename_columns(["service", "n", "d"]).to_pylist()}
+        assert want.num_rows > 3
         for r in got.rename_columns(["service", "n", "d"]).to_pylist():
             assert by_service[r["service"]] == r
         # no PARTIAL form, no streaming form
