@@ -139,7 +139,9 @@ typedef enum prism_gpu_agg_func {
   PRISM_AGG_COUNT_STAR = 1, /* COUNT(*) == COUNT(UInt8(1)): counts rows       */
   PRISM_AGG_COUNT = 2,      /* counts non-NULL values                          */
   PRISM_AGG_SUM = 3,        /* Int* -> Int64, UInt16 -> UInt64, wrapping       */
-  PRISM_AGG_MIN = 4,        /* type preserving, NULLs ignored                  */
+  PRISM_AGG_MIN = 4,        /* type preserving, NULLs ignored; Utf8 / Binary:
+                               byte-lexicographic, SINGLE mode over resident
+                               partitions (columns GROUP BY accepts)            */
   PRISM_AGG_MAX = 5,
   PRISM_AGG_AVG = 6,        /* Float64 = f64 sum of values cast to f64 / count */
   PRISM_AGG_COUNT_DISTINCT = 7 /* Next to other aggregates, or over more than one column: SINGLE

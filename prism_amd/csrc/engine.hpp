@@ -119,9 +119,14 @@ struct prism_gpu_plan {
   // runs as several plans over the same rows -- the other aggregates, and the COUNT(DISTINCT)s
   // of each column -- whose results are joined on the group keys.
   // mixed_map[i] = (sub-plan, aggregate index there) of the plan's i-th aggregate.
+  // MIN / MAX over a string column run the same way: a sub-plan that groups by the keys *and*
+  // the column (sub_string_col[k] >= 0; its result holds every (group, value) pair once), from
+  // which the byte-lexicographic extremes per group are picked on the host.  Sub-plan 0
+  // always has one row per group (COUNT(*) alone when the plan has no plain aggregate).
   bool mixed = false;
   std::vector<std::unique_ptr<prism_gpu_plan>> subs;
-  std::vector<std::pair<int, int>> mixed_map;
+  std::vector<int> sub_string_col;
+  std::vector<std::pair<int, int>> mixed_map;  // (-1, _) never occurs: every aggregate maps to a sub-plan
   std::vector<prism::FieldType> partial_fields, final_fields;
   // capacity the GROUP BY hash table ended up with the last time this plan ran: the next
   // run starts there instead of growing into it again (0: no run yet)

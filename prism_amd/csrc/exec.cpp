@@ -1963,50 +1963,79 @@ void append_row_key(const std::vector<OutColumn>& cols, size_t n_keys, size_t ro
   }
 }
 
-// COUNT(DISTINCT) next to other aggregates or over several columns: the sub-plans see the
-// same rows and therefore the same groups; the first one's rows give the order, the others'
-// aggregates are looked up by group key and placed in the order the plan lists them.
+// COUNT(DISTINCT) next to other aggregates or over several columns, MIN / MAX over strings:
+// the sub-plans see the same rows and therefore the same groups; sub-plan 0's rows (one per
+// group) give the order, the others' results are looked up by group key and placed in the
+// order the plan lists its aggregates.  A string sub-plan lists (group, value) pairs: the
+// byte-lexicographic extremes per group are picked from them here.
 void execute_mixed(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions, ArrowArray* out) {
   const size_t n_subs = plan->subs.size(), n_keys = plan->keys.size();
   std::vector<std::vector<OutColumn>> res(n_subs);
   for (size_t k = 0; k < n_subs; ++k)
     execute_impl(plan->subs[k].get(), table, partition_ids, n_partitions, false, nullptr, nullptr, nullptr, false, nullptr, &res[k]);
   const size_t rows = res[0].empty() ? 0 : res[0][0].rows();
-  std::vector<std::vector<size_t>> row_of(n_subs, std::vector<size_t>(rows));
   std::string key;
-  for (size_t k = 0; k < n_subs; ++k) {
-    if ((res[k].empty() ? 0 : res[k][0].rows()) != rows) fail(PRISM_GPU_EINTERNAL, "the parts of the plan found different groups");
-    if (k == 0 || n_keys == 0 || rows <= 1) {
-      for (size_t i = 0; i < rows; ++i) row_of[k][i] = i;
-      continue;
-    }
-    std::unordered_map<std::string, size_t> where;
-    where.reserve(rows * 2);
-    for (size_t i = 0; i < rows; ++i) {
-      append_row_key(res[k], n_keys, i, key);
-      where.emplace(key, i);
-    }
+  std::unordered_map<std::string, size_t> group_row;  // group key -> row of sub-plan 0
+  if (n_keys) {
+    group_row.reserve(rows * 2);
     for (size_t i = 0; i < rows; ++i) {
       append_row_key(res[0], n_keys, i, key);
-      auto it = where.find(key);
-      if (it == where.end()) fail(PRISM_GPU_EINTERNAL, "the parts of the plan found different groups");
-      row_of[k][i] = it->second;
+      group_row.emplace(key, i);
+    }
+  }
+  auto group_of = [&](const std::vector<OutColumn>& cols, size_t row) -> size_t {
+    if (!n_keys) return 0;
+    append_row_key(cols, n_keys, row, key);
+    auto it = group_row.find(key);
+    if (it == group_row.end()) fail(PRISM_GPU_EINTERNAL, "the parts of the plan found different groups");
+    return it->second;
+  };
+  // per sub-plan: for every group (row of sub-plan 0) the row of the sub-plan's result, or for
+  // a string sub-plan the rows holding the group's smallest and largest value
+  constexpr size_t kNone = ~(size_t)0;
+  std::vector<std::vector<size_t>> row_of(n_subs), max_row_of(n_subs);
+  for (size_t k = 1; k < n_subs; ++k) {
+    const size_t n_k = res[k].empty() ? 0 : res[k][0].rows();
+    row_of[k].assign(rows, kNone);
+    if (plan->sub_string_col[k] < 0) {
+      if (n_k != rows) fail(PRISM_GPU_EINTERNAL, "the parts of the plan found different groups");
+      for (size_t i = 0; i < n_k; ++i) row_of[k][group_of(res[k], i)] = i;
+      continue;
+    }
+    max_row_of[k].assign(rows, kNone);
+    const OutColumn& v = res[k][n_keys];
+    for (size_t i = 0; i < n_k; ++i) {
+      if (!v.valid_data()[i]) continue;  // NULLs are ignored
+      const size_t g = group_of(res[k], i);
+      const std::string& s = v.str_at(i);  // std::string compares bytes as unsigned: byte-lexicographic
+      if (row_of[k][g] == kNone || s < v.str_at(row_of[k][g])) row_of[k][g] = i;
+      if (max_row_of[k][g] == kNone || s > v.str_at(max_row_of[k][g])) max_row_of[k][g] = i;
     }
   }
   std::vector<OutColumn> cols = make_columns(plan->final_fields);
   for (size_t i = 0; i < plan->aggs.size(); ++i) {
     OutColumn& dst = cols[n_keys + i];
     const auto [k, idx] = plan->mixed_map[i];
-    OutColumn& src = res[(size_t)k][n_keys + (size_t)idx];
     if (k == 0) {
       FieldType t = dst.type;
-      dst = std::move(src);
+      dst = std::move(res[0][n_keys + (size_t)idx]);
       dst.type = t;
       continue;
     }
+    if (plan->sub_string_col[(size_t)k] >= 0) {
+      const OutColumn& v = res[(size_t)k][n_keys];
+      const std::vector<size_t>& pick = plan->aggs[i].func == PRISM_AGG_MIN ? row_of[(size_t)k] : max_row_of[(size_t)k];
+      for (size_t r = 0; r < rows; ++r) {
+        if (pick[r] == kNone) dst.push_null();
+        else dst.push_str(v.str_at(pick[r]));
+      }
+      continue;
+    }
+    OutColumn& src = res[(size_t)k][n_keys + (size_t)idx];
     src.materialise();
     for (size_t r = 0; r < rows; ++r) {
       const size_t at = row_of[(size_t)k][r];
+      if (at == kNone) fail(PRISM_GPU_EINTERNAL, "the parts of the plan found different groups");
       if (!src.valid[at]) dst.push_null();
       else if (src.type.is_float) dst.push_float(src.f64[at]);
       else dst.push_int(src.i64[at]);

@@ -195,7 +195,7 @@ std::unique_ptr<prism_gpu_plan> plan_create(prism_gpu_ctx* ctx, const ArrowSchem
     plan->keys.push_back(kp);
   }
   uint32_t n_distinct = 0;
-  bool several_distinct_columns = false;
+  bool several_distinct_columns = false, string_min_max = false;
   for (uint32_t i = 0; i < d->n_aggs; ++i) {
     const prism_gpu_agg& a = d->aggs[i];
     AggPlan ap;
@@ -212,7 +212,8 @@ std::unique_ptr<prism_gpu_plan> plan_create(prism_gpu_ctx* ctx, const ArrowSchem
         if (plan->distinct_col >= 0 && plan->distinct_col != a.column) several_distinct_columns = true;
         plan->distinct_col = a.column;
       } else if (a.func != PRISM_AGG_COUNT) {
-        if (f.is_string) fail(PRISM_GPU_EUNSUPPORTED, "SUM/MIN/MAX/AVG over string columns are not supported");
+        if (f.is_string && (a.func == PRISM_AGG_MIN || a.func == PRISM_AGG_MAX)) string_min_max = true;
+        else if (f.is_string) fail(PRISM_GPU_EUNSUPPORTED, "SUM / AVG over string columns");
         if (f.is_float) fail(PRISM_GPU_EUNSUPPORTED, "aggregates over Float64 columns are not supported");
         if ((a.func == PRISM_AGG_SUM || a.func == PRISM_AGG_AVG) && f.logical == PRISM_COL_TIMESTAMP)
           fail(PRISM_GPU_EUNSUPPORTED, "SUM/AVG over a timestamp");
@@ -221,28 +222,48 @@ std::unique_ptr<prism_gpu_plan> plan_create(prism_gpu_ctx* ctx, const ArrowSchem
     ap.name = a.name ? a.name : default_agg_name(*plan, ap);
     plan->aggs.push_back(ap);
   }
-  if (n_distinct && (n_distinct != d->n_aggs || several_distinct_columns)) {
-    // COUNT(DISTINCT) next to other aggregates, or over several columns: one plan per kind
-    // over the same rows, joined on the keys
+  if ((n_distinct && (n_distinct != d->n_aggs || several_distinct_columns)) || string_min_max) {
+    // COUNT(DISTINCT) next to other aggregates or over several columns, MIN / MAX over strings:
+    // one plan per kind over the same rows, joined on the keys
     if (d->mode != PRISM_MODE_SINGLE)
-      fail(PRISM_GPU_EUNSUPPORTED, "COUNT(DISTINCT) next to other aggregates or over several columns is supported in SINGLE mode only");
-    std::vector<std::vector<prism_gpu_agg>> kinds;  // [0]: the other aggregates (if any), then one per distinct column
-    std::vector<int> kind_column;                   // -1: the other aggregates
+      fail(PRISM_GPU_EUNSUPPORTED, "COUNT(DISTINCT) next to other aggregates or over several columns, and MIN / MAX over "
+                                   "strings, are supported in SINGLE mode only");
+    // kind 0: the plain aggregates; then one kind per distinct column (kind id = column) and
+    // one per string column under MIN / MAX (kind id = -2 - column)
+    std::vector<std::vector<prism_gpu_agg>> kinds(1);
+    std::vector<int> kind_id(1, -1);
     for (uint32_t i = 0; i < d->n_aggs; ++i) {
-      const int col = d->aggs[i].func == PRISM_AGG_COUNT_DISTINCT ? d->aggs[i].column : -1;
+      const prism_gpu_agg& a = d->aggs[i];
+      const bool str_mm = (a.func == PRISM_AGG_MIN || a.func == PRISM_AGG_MAX) && plan->fields[a.column].is_string;
+      const int id = a.func == PRISM_AGG_COUNT_DISTINCT ? a.column : str_mm ? -2 - a.column : -1;
       size_t k = 0;
-      while (k < kinds.size() && kind_column[k] != col) ++k;
-      if (k == kinds.size()) { kinds.emplace_back(); kind_column.push_back(col); }
+      while (k < kinds.size() && kind_id[k] != id) ++k;
+      if (k == kinds.size()) { kinds.emplace_back(); kind_id.push_back(id); }
       plan->mixed_map.emplace_back((int)k, (int)kinds[k].size());
-      kinds[k].push_back(d->aggs[i]);
+      kinds[k].push_back(a);
     }
-    for (auto& aggs : kinds) {
+    const prism_gpu_agg count_rows{PRISM_AGG_COUNT_STAR, -1, nullptr};
+    for (size_t k = 0; k < kinds.size(); ++k) {
       prism_gpu_plan_desc sub = *d;
       sub.order_by = -1;
       sub.limit = -1;
+      std::vector<prism_gpu_key> keys(d->keys, d->keys + d->n_keys);
+      std::vector<prism_gpu_agg> aggs = kinds[k];
+      int string_col = -1;
+      if (kind_id[k] <= -2) {  // GROUP BY keys, column: every (group, value) pair once
+        string_col = -2 - kind_id[k];
+        keys.push_back(prism_gpu_key{PRISM_KEY_COLUMN, string_col, 0, 0, "__value"});
+        if (keys.size() > (size_t)kMaxKeys) fail(PRISM_GPU_EUNSUPPORTED, "too many GROUP BY keys for MIN / MAX over a string column");
+        aggs.assign(1, count_rows);
+      } else if (aggs.empty()) {
+        aggs.assign(1, count_rows);  // no plain aggregate: sub-plan 0 only lists the groups
+      }
+      sub.keys = keys.data();
+      sub.n_keys = (uint32_t)keys.size();
       sub.aggs = aggs.data();
       sub.n_aggs = (uint32_t)aggs.size();
       plan->subs.push_back(plan_create(ctx, schema, &sub));
+      plan->sub_string_col.push_back(string_col);
     }
     plan->mixed = true;
     plan->distinct_col = -1;

@@ -111,3 +111,83 @@ def test_order_by_the_distinct_count_and_what_is_refused(gpu_ctx):
             plan.close()
     finally:
         g.close()
+
+
+def _string_extremes(t, key_names, column, mask=None):
+    """Byte-lexicographic MIN and MAX of `column` per group, NULLs ignored (the group exists even
+    when all its values are NULL)."""
+    out = {}
+    keys = [t.column(k).to_pylist() for k in key_names]
+    vals = t.column(column).to_pylist()
+    keep = mask.to_pylist() if mask is not None else [True] * t.num_rows
+    for r in range(t.num_rows):
+        if not keep[r]:
+            continue
+        g = tuple(k[r] for k in keys)
+        lo, hi = out.setdefault(g, (None, None))
+        v = vals[r]
+        if v is not None:
+            b = v.encode() if isinstance(v, str) else v
+            lo = v if lo is None or b < (lo.encode() if isinstance(lo, str) else lo) else lo
+            hi = v if hi is None or b > (hi.encode() if isinstance(hi, str) else hi) else hi
+        out[g] = (lo, hi)
+    return out
+
+
+def test_min_max_over_strings(gpu_ctx):
+    """MIN / MAX over Utf8 are byte-lexicographic (DataFusion's min_max.rs compares the bytes):
+    grouped, ungrouped, next to other aggregates, with NULLs and a filter, non-ASCII values."""
+    import numpy as np
+    import pyarrow.compute as pc
+
+    from prism_amd.engine import Plan, PrismGpuError, Table
+    from prism_amd.plan import min_
+
+    rng = np.random.default_rng(5)
+    n = 20_000
+    words = ["zeta", "Zeta", "alpha", "alph", "", "ünï", "u", "~", "alpha0", " alpha"]
+    t = pa.table({
+        "k": pa.array(rng.integers(0, 40, n).astype(np.int64), mask=rng.random(n) < 0.05),
+        "w": pa.array([words[int(i)] for i in rng.integers(0, len(words), n)], type=pa.string(), mask=rng.random(n) < 0.3),
+        "path": pa.array([f"/p/{int(i):05d}" for i in rng.integers(0, 3000, n)], type=pa.string()),
+        "v": pa.array(rng.integers(-100, 100, n).astype(np.int64)),
+    })
+    # one group whose strings are all NULL
+    t = pa.concat_tables([t, pa.table({"k": pa.array([777] * 3, pa.int64()), "w": pa.array([None] * 3, pa.string()),
+                                       "path": pa.array(["/x"] * 3), "v": pa.array([1, 2, 3], pa.int64())})])
+    g = Table(gpu_ctx, t.schema)
+    g.append_table(t, 3)
+    try:
+        q = QueryPlan([min_("w"), count_star(), max_("w"), max_("path"), sum_("v")], keys=["k"], predicate=col("v") > -50)
+        plan = Plan(gpu_ctx, t.schema, q)
+        try:
+            got = plan.execute(g)
+        finally:
+            plan.close()
+        assert got.schema.field(1).type == pa.string() and got.schema.field(4).type == pa.string()
+        mask = pc.greater(t.column("v"), -50)
+        ew, ep = _string_extremes(t, ["k"], "w", mask), _string_extremes(t, ["k"], "path", mask)
+        rows = got.to_pylist()
+        names = got.schema.names
+        assert len(rows) == len(ew)
+        for r in rows:
+            key = (r[names[0]],)
+            assert (r[names[1]], r[names[3]]) == ew[key], key
+            assert r[names[4]] == ep[key][1]
+        assert ew[(777,)] == (None, None)
+        # ungrouped
+        plan = Plan(gpu_ctx, t.schema, QueryPlan([max_("w"), min_("path")]))
+        try:
+            one = plan.execute(g).to_pylist()[0]
+        finally:
+            plan.close()
+        assert list(one.values()) == [_string_extremes(t, [], "w")[()][1], _string_extremes(t, [], "path")[()][0]]
+        # no PARTIAL form; SUM over strings stays refused
+        with pytest.raises(PrismGpuError) as e:
+            Plan(gpu_ctx, t.schema, QueryPlan([min_("w")], keys=["k"]).with_mode(abi.MODE_PARTIAL))
+        assert e.value.code == abi.EUNSUPPORTED
+        with pytest.raises(PrismGpuError) as e:
+            Plan(gpu_ctx, t.schema, QueryPlan([sum_("w")]))
+        assert e.value.code == abi.EUNSUPPORTED
+    finally:
+        g.close()
