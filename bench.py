@@ -157,17 +157,26 @@ def main() -> int:
     comm = None
     if grouped:
         exchange = args.exchange
+        fallback_reason = None
         if exchange in ("auto", "state"):
             # the library's own RCCL communicator; torch.distributed only hands the id around
-            comm = Comm.from_process_group(ctx)
             try:
+                comm = Comm.from_process_group(ctx)
                 single.execute_sharded(comm, table, None, 0)
                 exchange = "state"
             except PrismGpuError as e:
-                if e.code != abi.EUNSUPPORTED or args.exchange == "state":
+                if args.exchange == "state":
                     raise
+                fallback_reason = str(e)
                 exchange = "arrow"
-        log(f"[rank {rank}] exchange between GPUs: {exchange}")
+            # every rank takes the same path: one that could not run the exchange in the library
+            # (an unsupported plan fails on all of them alike; a transport error may not) moves
+            # all of them to the PARTIAL Arrow exchange
+            ok = torch.tensor([1 if exchange == "state" else 0], dtype=torch.int32, device=device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                exchange = "arrow"
+        log(f"[rank {rank}] exchange between GPUs: {exchange}" + (f" (library exchange not used: {fallback_reason})" if fallback_reason else ""))
 
     def step():
         if not grouped:
