@@ -49,6 +49,9 @@ __device__ __forceinline__ uint64_t hash64(uint64_t z) {
 }
 
 // One fixed-width value widened to int64.
+// Hash of the high word of a two-word key (the group of a COUNT(DISTINCT) pair).
+__device__ __forceinline__ uint64_t part_hash_hi(uint64_t hi) { return hash64(hi ^ 0xA0761D6478BD642Full); }
+
 __device__ __forceinline__ long long load_value(const void* base, int width, int is_unsigned, uint64_t row) {
   if (width == 8) return ((const long long*)base)[row];
   if (width == 4) return is_unsigned ? (long long)((const unsigned int*)base)[row] : (long long)((const int*)base)[row];

@@ -1317,6 +1317,98 @@ uint64_t distinct_emit_outer(prism_gpu_ctx* ctx, const prism_gpu_plan* plan, con
   return g.n;
 }
 
+// COUNT(DISTINCT x) GROUP BY keys over two-word pairs, partitioned twice (kernels_part2.hip):
+// the rows' pairs are sorted into coarse buckets by a hash of the group key, every coarse
+// bucket into fine buckets by a hash of the pair, and the fine buckets are deduplicated in
+// LDS and counted per group into `outer`.  False: a fine bucket did not fit (very uneven
+// data) or the outer table overflowed; nothing usable was produced.
+bool partitioned_distinct(prism_gpu_ctx* ctx, const AggParams& ap, uint64_t selected, uint64_t key_bytes, const KeyLayout& layout,
+                          GroupTable& outer) {
+  const int words = part_record_words(ap, false);
+  if (words != 2 || selected == 0 || selected >= (1ull << 32)) return false;
+  // coarse buckets of about half a million rows, fine buckets of about a quarter of the LDS set
+  int p1 = 6;
+  while (p1 < 11 && (selected >> p1) > (1ull << 19)) ++p1;
+  const uint32_t P1 = 1u << p1;
+  if (P1 > part_max_buckets(words)) return false;
+  const uint32_t set_entries = part2_lds_entries();
+  // (a fine bucket of up to half the set's entries is taken in one go; larger ones, in the
+  // coarse buckets of very frequent groups, in several passes)
+  const uint64_t fine_rows = set_entries * 3 / 8;
+  int p2 = 0;
+  while (p2 < 10 && (selected >> (p1 + p2)) > fine_rows) ++p2;
+  if ((selected >> (p1 + p2)) > fine_rows) return false;  // more rows than 2^21 fine buckets take
+
+  PartParams q1;
+  std::memset(&q1, 0, sizeof(q1));
+  q1.p_bits = p1;
+  q1.n_buckets = P1;
+  q1.n_wg = part_scan_workgroups(ctx, ap, &q1.tiles_per_wg);
+  q1.chunk_rows = 1u << 30;
+  q1.max_items = P1 + 4;
+  q1.lds_entries = part_lds_entries(ap);
+  q1.lds_limit = q1.lds_entries / 4 * 3;
+  q1.rec_capacity = selected;
+  q1.by_hi = 1;
+  Scratch rec[2], rec2[2], d_hist(ctx, (size_t)q1.n_wg * P1 * 4), d_totals(ctx, (size_t)P1 * 4), d_base(ctx, (size_t)(P1 + 1) * 8),
+      d_items(ctx, (size_t)q1.max_items * sizeof(PartItem)), d_small(ctx, 256);
+  for (int w = 0; w < 2; ++w) {
+    rec[w] = Scratch(ctx, selected * 8 + 256);
+    rec2[w] = Scratch(ctx, selected * 8 + 256);
+    q1.rec[w] = rec[w].as<uint64_t>();
+  }
+  q1.hist = d_hist.as<uint32_t>();
+  q1.totals = d_totals.as<uint32_t>();
+  q1.bucket_base = d_base.as<uint64_t>();
+  q1.items = d_items.as<PartItem>();
+  // one small block: [0] the list cursor, [8] the item count, [16] two flags, [24] the queue
+  // of the first level (unused here); [32] the queue and [40] the flags of the second level
+  q1.list_cursor = d_small.as<unsigned long long>();
+  q1.n_items = (uint32_t*)(d_small.as<uint8_t>() + 8);
+  q1.flags = (uint32_t*)(d_small.as<uint8_t>() + 16);
+  q1.queue = (uint32_t*)(d_small.as<uint8_t>() + 24);
+  PRISM_HIP(hipMemsetAsync(d_small.p, 0, 256, ctx->stream));
+  launch_partitioned_group_by(ctx, ap, q1, false, selected * key_bytes, selected * (key_bytes + 16), 0, true);
+
+  const uint32_t n_fine = 1u << (p1 + p2);
+  Scratch d_fine(ctx, (size_t)n_fine * 12 + 64);
+  PRISM_HIP(hipMemsetAsync(d_fine.p, 0, (size_t)n_fine * 4, ctx->stream));
+  distinct_outer_alloc(ctx, layout, selected, outer);
+  Part2Params q2;
+  std::memset(&q2, 0, sizeof(q2));
+  q2.in_lo = rec[0].as<uint64_t>();
+  q2.in_hi = rec[1].as<uint64_t>();
+  q2.out_lo = rec2[0].as<uint64_t>();
+  q2.out_hi = rec2[1].as<uint64_t>();
+  q2.coarse_base = q1.bucket_base;
+  q2.p1_bits = (uint32_t)p1;
+  q2.p2_bits = (uint32_t)p2;
+  q2.n_rows = selected;
+  q2.slice_rows = 1u << 16;
+  q2.fine_count = d_fine.as<uint32_t>();
+  q2.fine_cursor = d_fine.as<uint32_t>() + n_fine;
+  q2.fine_base = d_fine.as<uint32_t>() + 2 * (size_t)n_fine;
+  q2.lds_entries = set_entries;
+  q2.x_null_bit = layout.fields[0].null_bit;
+  q2.dense = outer.dense ? 1 : 0;
+  q2.capacity = outer.capacity;
+  q2.g_keys = outer.keys.as<uint64_t>();
+  q2.g_state = outer.state.as<int64_t>();
+  q2.overflow = outer.overflow.as<uint32_t>();
+  q2.queue = (uint32_t*)(d_small.as<uint8_t>() + 32);
+  q2.flags = (uint32_t*)(d_small.as<uint8_t>() + 40);
+  launch_distinct_second_level(ctx, q2);
+  uint32_t flag = 0;
+  PRISM_HIP(hipMemcpyAsync(&flag, q2.flags, 4, hipMemcpyDeviceToHost, ctx->stream));
+  PRISM_HIP(hipStreamSynchronize(ctx->stream));
+  collect_timings(ctx);
+  if (flag != 0 || table_overflowed(ctx, outer)) {
+    outer = GroupTable();
+    return false;
+  }
+  return true;
+}
+
 }  // namespace
 
 }  // namespace prism
@@ -1848,11 +1940,22 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       const uint64_t learned = plan->learned_capacity.load(std::memory_order_relaxed);
       if (learned > capacity) capacity = std::min(learned, max_capacity);
     }
-    if (use_part) {
+    // COUNT(DISTINCT) over two-word pairs at scale: the set of pairs is too large for the
+    // buckets of one partition level and, as one table in HBM, costs two random cache lines per
+    // row; partitioned twice, the pairs are counted per group without the set ever being stored.
+    GroupTable outer_q;
+    bool outer_ready = false;
+    if (plan->distinct_plan && layout.words == 2 && !partial && !capture && part_ok && ap.n_pred == 0 &&
+        selected >= (part_forced(ctx) ? 1ull : (1ull << 24)) && plan->part_mode.load(std::memory_order_relaxed) >= 0) {
+      KernelTimer timer(ctx, "group_by", ss.rows * value_bytes);
+      outer_ready = partitioned_distinct(ctx, ap, selected, key_bytes, layout, outer_q);
+      if (!outer_ready) plan->part_mode.store(-1, std::memory_order_relaxed);  // uneven data: the one-table way from now on
+    }
+    if (use_part && !outer_ready) {
       partitioned_group_by(ctx, plan, ap, selected, ss.rows, key_bytes, value_bytes, vals_nullable, slot_ops, gt);
       dense = false;
     }
-    while (!use_part) {
+    while (!use_part && !outer_ready) {
       {
         HostTimer ht(ctx, "host:table_alloc");
         table_alloc(ctx, gt, dense, capacity, slot_ops, layout.words);
@@ -1885,7 +1988,7 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       if (capacity >= max_capacity) fail(PRISM_GPU_EINTERNAL, "group table overflow at maximum capacity");
       capacity = std::min(max_capacity, capacity * 4);  // more groups than expected: grow and redo the pass
     }
-    if (!dense && !use_part) plan->learned_capacity.store(capacity, std::memory_order_relaxed);
+    if (!dense && !use_part && !outer_ready) plan->learned_capacity.store(capacity, std::memory_order_relaxed);
     // lands with the next synchronisation of the stream (every path below has one before the statistics)
     if (fused) PRISM_HIP(hipMemcpyAsync(fused_slot(), d_scalar.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     if (capture) {
@@ -1920,9 +2023,13 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       groups_out = g.n;
     } else {
       // outer GROUP BY keys: COUNT(x) over the distinct pairs
-      GroupTable q;
-      distinct_fold_outer(ctx, layout, selected, gt, q);
-      groups_out = distinct_emit_outer(ctx, plan, table, keys, layout, q, cols);
+      if (outer_ready) {
+        groups_out = distinct_emit_outer(ctx, plan, table, keys, layout, outer_q, cols);
+      } else {
+        GroupTable q;
+        distinct_fold_outer(ctx, layout, selected, gt, q);
+        groups_out = distinct_emit_outer(ctx, plan, table, keys, layout, q, cols);
+      }
     }
   }
   PRISM_HIP(hipStreamSynchronize(ctx->stream));

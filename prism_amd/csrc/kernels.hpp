@@ -249,6 +249,7 @@ struct PartParams {
   unsigned long long* list_cursor;
   uint32_t* flags;         // [0]: the list overflowed, [1]: rows / groups sent to the HBM table
   uint32_t* queue;         // next item of the aggregation pass (starts at 0)
+  int32_t by_hi;           // two-word keys: the bucket follows from the high word alone
 };
 // 8-byte words of a row's record for this plan shape (key words + value columns + one word
 // of validity bits when a value column has NULLs); 0: the shape has no partitioned kernels.
@@ -257,8 +258,39 @@ uint32_t part_max_buckets(int words);
 uint32_t part_lds_entries(const AggParams& p);
 uint32_t part_scan_workgroups(prism_gpu_ctx* ctx, const AggParams& p, uint32_t* tiles_per_wg);
 // (hist_bytes, scatter_bytes, agg_bytes: algorithmic bytes of the three passes, for the statistics)
+// scatter_only: stop once the records lie sorted by bucket (q.rec, q.bucket_base); nothing is aggregated.
 void launch_partitioned_group_by(prism_gpu_ctx* ctx, const AggParams& p, const PartParams& q, bool vals_nullable,
-                                 uint64_t hist_bytes, uint64_t scatter_bytes, uint64_t agg_bytes);
+                                 uint64_t hist_bytes, uint64_t scatter_bytes, uint64_t agg_bytes, bool scatter_only = false);
+
+// COUNT(DISTINCT x) GROUP BY k over two-word (x, k) pairs whose set is far too large for one
+// level of buckets: the records, already sorted into coarse buckets by a hash of k, are
+// sorted once more, inside every coarse bucket, by a hash of the whole pair; each fine bucket
+// is then deduplicated in LDS and its pairs are counted per group straight into the outer
+// table (slot 0: pairs, slot 1: pairs whose x is not NULL) -- the set itself is never stored.
+struct Part2Params {
+  const uint64_t* in_lo;        // records sorted by coarse bucket
+  const uint64_t* in_hi;
+  uint64_t* out_lo;             // the same records sorted by fine bucket
+  uint64_t* out_hi;
+  const uint64_t* coarse_base;  // [2^p1_bits + 1]
+  uint32_t p1_bits, p2_bits;    // fine bucket = coarse << p2_bits | sub
+  uint64_t n_rows;
+  uint32_t slice_rows;          // rows per workgroup of the histogram and scatter passes
+  uint32_t* fine_count;         // [n_fine], zero on entry
+  uint32_t* fine_base;          // [n_fine + 1]
+  uint32_t* fine_cursor;        // [n_fine]
+  uint32_t lds_entries;         // entries of the pair table in LDS (a fine bucket may hold half as many rows)
+  int32_t x_null_bit;           // bit of the low word that marks a NULL x, -1: none
+  int32_t dense;                // the outer table
+  uint64_t capacity;
+  uint64_t* g_keys;
+  int64_t* g_state;
+  uint32_t* overflow;
+  uint32_t* queue;              // next fine bucket of the last pass (zero on entry)
+  uint32_t* flags;              // [0]: a fine bucket did not fit LDS (the result is void)
+};
+uint32_t part2_lds_entries();
+void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q);
 
 // Second level of COUNT(DISTINCT x) GROUP BY k: every occupied entry of the
 // (k, x) set adds 1 (when its x field is not NULL) to group k of table `q`.

@@ -59,6 +59,14 @@ __device__ __forceinline__ uint64_t part_hash(uint64_t lo, uint64_t hi) {
   return KW == 2 ? hash64(lo ^ hash64(hi)) : hash64(lo);
 }
 
+// The hash a row's bucket is taken from: the whole key, or (two-word pairs of a COUNT(DISTINCT)
+// that is partitioned twice) the high word alone, so that a group's pairs share a bucket.
+template <int KW>
+__device__ __forceinline__ uint64_t part_bucket_hash(const PartParams& q, uint64_t lo, uint64_t hi) {
+  if (KW == 2 && q.by_hi) return part_hash_hi(hi);
+  return part_hash<KW>(lo, hi);
+}
+
 // One scan tile (kTileRows rows of one segment) as a workgroup sees it; wave uniform.
 struct PartTile {
   uint32_t seg;   // segment the tile lies in
@@ -216,7 +224,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_hist(AggParams p, PartParam
     part_load_keys<KW, R>(p, tl, tid, lo, hi, rowc, live);
 #pragma unroll
     for (int r = 0; r < R; ++r)
-      if ((live >> r) & 1u) atomicAdd(&h[(uint32_t)(part_hash<KW>(lo[r], hi[r]) >> shift)], 1u);
+      if ((live >> r) & 1u) atomicAdd(&h[(uint32_t)(part_bucket_hash<KW>(q, lo[r], hi[r]) >> shift)], 1u);
   }
   __syncthreads();
   for (uint32_t b = tid; b < P; b += kPartBlock) q.hist[(uint64_t)blockIdx.x * P + b] = h[b];
@@ -341,7 +349,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(AggParams p, PartPa
     uint32_t slot[R];  // bucket (low 12 bits) and rank inside it (a tile holds at most 2^14 rows)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const uint32_t b = (uint32_t)(part_hash<KW>(rec[0][r], KW == 2 ? rec[KW - 1][r] : 0ull) >> shift);
+      const uint32_t b = (uint32_t)(part_bucket_hash<KW>(q, rec[0][r], KW == 2 ? rec[KW - 1][r] : 0ull) >> shift);
       slot[r] = b;
       if ((live >> r) & 1u) slot[r] |= atomicAdd(&start[b], 1u) << 12;
     }
@@ -361,7 +369,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(AggParams p, PartPa
     const uint32_t n_live = start[P];
     for (uint32_t i = tid; i < n_live; i += kPartBlock) {
       uint64_t w0 = sorted[i], w1 = KW == 2 ? sorted[(size_t)T + i] : 0ull;
-      const uint32_t b = (uint32_t)(part_hash<KW>(w0, w1) >> shift);
+      const uint32_t b = (uint32_t)(part_bucket_hash<KW>(q, w0, w1) >> shift);
       const uint64_t g = (uint64_t)cursor[b] + (i - start[b]);
       if (g < q.rec_capacity) {
         q.rec[0][g] = w0;
@@ -749,7 +757,7 @@ uint32_t part_scan_workgroups(prism_gpu_ctx* ctx, const AggParams& p, uint32_t* 
 }
 
 void launch_partitioned_group_by(prism_gpu_ctx* ctx, const AggParams& p_scan, const PartParams& q, bool vals_nullable,
-                                 uint64_t hist_bytes, uint64_t scatter_bytes, uint64_t agg_bytes) {
+                                 uint64_t hist_bytes, uint64_t scatter_bytes, uint64_t agg_bytes, bool scatter_only) {
   const AggParams& p_table = p_scan;  // the same descriptor carries the scan and the HBM table the stragglers go to
   PartKernels k;
   if (!pick_part_kernels(p_scan.key_words, p_scan.keys_only ? 0 : p_scan.n_vals, vals_nullable, &k))
@@ -774,7 +782,7 @@ void launch_partitioned_group_by(prism_gpu_ctx* ctx, const AggParams& p_scan, co
     KernelTimer timer(ctx, "part_plan", 0);
     k_part_offsets<<<dim3((uint32_t)ceil_div(P, kBlock)), dim3(kBlock), 0, ctx->stream>>>(q);
     PRISM_HIP(hipGetLastError());
-    k_part_plan<<<dim3(1), dim3(kPartBlock), 0, ctx->stream>>>(q);
+    k_part_plan<<<dim3(1), dim3(kPartBlock), 0, ctx->stream>>>(q);  // (the bucket starts; the work items go unused when scatter_only)
     PRISM_HIP(hipGetLastError());
   }
   {
@@ -782,6 +790,7 @@ void launch_partitioned_group_by(prism_gpu_ctx* ctx, const AggParams& p_scan, co
     k.scatter<<<dim3(q.n_wg), dim3(kPartBlock), scatter_lds, ctx->stream>>>(p_scan, q);
     PRISM_HIP(hipGetLastError());
   }
+  if (scatter_only) return;
   {
     KernelTimer timer(ctx, "part_agg", agg_bytes);
     const uint32_t grid = (uint32_t)std::min<uint64_t>(q.max_items, (uint64_t)ctx->n_cus);

@@ -1,0 +1,348 @@
+// Second level of the partitioned COUNT(DISTINCT x) GROUP BY k (two-word (x, k) pairs).
+//
+// The first level (kernels_part.hip, bucket = hash of k) leaves the pairs sorted into coarse
+// buckets: all pairs of a group share one.  Here every coarse bucket is sorted once more by
+// a hash of the whole pair, into fine buckets small enough for LDS; a fine bucket is
+// deduplicated in an LDS table and its distinct pairs are counted per group -- a fine
+// bucket sees only the few groups of its coarse bucket -- into the outer table.  The set of
+// pairs (hundreds of millions of 16-byte keys for the benchmark query) is never built in
+// HBM: that set was what made the one-level version bound by random cache-line fetches.
+//
+//   k_part2_hist     rows per fine bucket (slices of the record array; LDS counters for the
+//                    coarse buckets a slice touches, flushed with one atomic per counter)
+//   k_part2_scan     exclusive scan of the counts (one workgroup)
+//   k_part2_scatter  the same slices again, tile by tile: ranks inside the tile from LDS
+//                    counters, one reservation per (tile, fine bucket) in the bucket's
+//                    cursor, records written to their places
+//   k_part2_agg      fine buckets handed out through a counter: LDS set, then per-group counts
+//
+// Algorithmic bytes per row: 16 read (hist) + 16 read + 16 written (scatter) + 16 read (agg).
+#include <algorithm>
+
+#include "agg_device.hpp"
+#include "context.hpp"
+#include "device_utils.hpp"
+#include "kernels.hpp"
+
+namespace prism {
+
+namespace {
+
+constexpr uint32_t kP2Block = 1024;
+constexpr uint32_t kP2Counters = 2048;   // LDS counters of a slice: (coarse buckets covered) x 2^p2_bits
+constexpr uint32_t kP2MaxSpan = 8;       // coarse buckets covered at most
+constexpr uint32_t kP2TileRows = 8;      // rows per thread and tile of the scatter pass
+constexpr unsigned long long kP2Empty = ~0ull;
+constexpr uint32_t kP2Groups = 512;      // entries of the per-bucket group counters in LDS
+constexpr uint32_t kP2AggBlock = 512;    // threads of the last pass; two of its workgroups share a CU, so that
+constexpr uint32_t kP2AggPerCu = 2;      // one's waits for HBM overlap with the other's work in LDS
+constexpr size_t kP2LdsBytes = 160 * 1024 - 1024;
+
+typedef const __attribute__((address_space(1))) unsigned long long* P2WordPtr;
+
+__device__ __forceinline__ uint32_t coarse_of(const Part2Params& q, uint64_t hi) {
+  return q.p1_bits ? (uint32_t)(part_hash_hi(hi) >> (64 - q.p1_bits)) : 0u;
+}
+__device__ __forceinline__ uint32_t span_of(const Part2Params& q) {
+  const uint32_t s = kP2Counters >> q.p2_bits;
+  return s < kP2MaxSpan ? s : kP2MaxSpan;
+}
+__device__ __forceinline__ uint32_t sub_of(const Part2Params& q, uint64_t lo, uint64_t hi) {
+  return q.p2_bits ? (uint32_t)(hash64(lo ^ hash64(hi)) >> (64 - q.p2_bits)) : 0u;
+}
+
+__global__ __launch_bounds__(kP2Block) void k_part2_hist(Part2Params q) {
+  __shared__ uint32_t cnt[kP2Counters];
+  const uint32_t n_sub = 1u << q.p2_bits, span = span_of(q);
+  for (uint32_t i = threadIdx.x; i < span * n_sub; i += kP2Block) cnt[i] = 0;
+  const uint64_t r0 = (uint64_t)blockIdx.x * q.slice_rows;
+  const uint64_t r1 = r0 + q.slice_rows < q.n_rows ? r0 + q.slice_rows : q.n_rows;
+  // the slice's first coarse bucket (the records are sorted by it)
+  const uint32_t c0 = __builtin_amdgcn_readfirstlane(coarse_of(q, q.in_hi[r0]));
+  __syncthreads();
+  for (uint64_t i = r0 + threadIdx.x; i < r1; i += kP2Block) {
+    const uint64_t lo = __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.in_lo + i));
+    const uint64_t hi = __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.in_hi + i));
+    const uint32_t c = coarse_of(q, hi), s = sub_of(q, lo, hi);
+    if (c - c0 < span) atomicAdd(&cnt[(c - c0) * n_sub + s], 1u);
+    else atomicAdd(&q.fine_count[((uint64_t)c << q.p2_bits) | s], 1u);  // a slice over many small coarse buckets
+  }
+  __syncthreads();
+  const uint32_t n_coarse = 1u << q.p1_bits;
+  for (uint32_t i = threadIdx.x; i < span * n_sub; i += kP2Block) {
+    const uint32_t c = c0 + i / n_sub;
+    if (cnt[i] && c < n_coarse) atomicAdd(&q.fine_count[((uint64_t)c << q.p2_bits) | (i % n_sub)], cnt[i]);
+  }
+}
+
+// counts -> exclusive offsets (and the cursors the scatter pass advances); one workgroup
+__global__ __launch_bounds__(1024) void k_part2_scan(Part2Params q, uint32_t n_fine) {
+  __shared__ uint32_t wave_tot[16];
+  __shared__ uint32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < n_fine; base += 1024) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < n_fine ? q.fine_count[i] : 0;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t o = __shfl_up(incl, off, 64);
+      if ((int)(threadIdx.x & 63) >= off) incl += o;
+    }
+    if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) before += wave_tot[w];
+    const uint32_t c = carry;
+    if (i < n_fine) {
+      q.fine_base[i] = c + before + incl - v;
+      q.fine_cursor[i] = c + before + incl - v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = c + before + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) q.fine_base[n_fine] = carry;
+}
+
+// Exclusive scan of n (<= 2 * kP2Block, even) LDS counters in place; a[n] receives the total.
+__device__ __forceinline__ void p2_block_scan(uint32_t* a, uint32_t n, uint32_t* wave_tot) {
+  const uint32_t t = threadIdx.x, i0 = 2 * t;
+  const uint32_t v0 = i0 < n ? a[i0] : 0u, v1 = i0 + 1 < n ? a[i0 + 1] : 0u;
+  uint32_t incl = v0 + v1;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = __shfl_up(incl, off, 64);
+    if ((int)(t & 63) >= off) incl += o;
+  }
+  if ((t & 63) == 63) wave_tot[t >> 6] = incl;
+  __syncthreads();
+  uint32_t before = 0;
+  for (uint32_t w = 0; w < (t >> 6); ++w) before += wave_tot[w];
+  const uint32_t excl = before + incl - (v0 + v1);
+  if (i0 < n) a[i0] = excl;
+  if (i0 + 1 < n) a[i0 + 1] = excl + v0;
+  if (t == kP2Block - 1) a[n] = before + incl;
+  __syncthreads();
+}
+
+// The tile's records are put in fine-bucket order in LDS first and leave as runs: written
+// straight from the registers, 8 bytes at a time to places 32 rows apart, the pass wrote 3.6
+// times its payload (partial cache lines).
+__global__ __launch_bounds__(kP2Block) void k_part2_scatter(Part2Params q) {
+  extern __shared__ __align__(16) unsigned long long p2s_lds[];
+  constexpr uint32_t kTile = kP2Block * kP2TileRows;
+  unsigned long long* s_lo = p2s_lds;
+  unsigned long long* s_hi = p2s_lds + kTile;
+  uint32_t* cnt = (uint32_t*)(p2s_lds + 2 * kTile);  // [kP2Counters]: rows of the tile per counter
+  uint32_t* lstart = cnt + kP2Counters;                // [kP2Counters + 1]: where a counter's run starts in the tile
+  uint32_t* base = lstart + kP2Counters + 1;           // [kP2Counters]: and in the output
+  __shared__ uint32_t wave_tot[kP2Block / 64];
+  const uint32_t n_sub = 1u << q.p2_bits, span = span_of(q), n_cnt = span * n_sub;
+  const uint32_t n_coarse = 1u << q.p1_bits;
+  const uint64_t r0 = (uint64_t)blockIdx.x * q.slice_rows;
+  const uint64_t r1 = r0 + q.slice_rows < q.n_rows ? r0 + q.slice_rows : q.n_rows;
+  // every thread makes the same number of trips (the barriers are inside)
+  for (uint64_t t0 = r0; t0 < r1; t0 += kTile) {
+    for (uint32_t i = threadIdx.x; i < kP2Counters; i += kP2Block) cnt[i] = 0;
+    const uint32_t c0 = __builtin_amdgcn_readfirstlane(coarse_of(q, q.in_hi[t0]));
+    __syncthreads();
+    uint64_t lo[kP2TileRows], hi[kP2TileRows];
+    uint32_t where[kP2TileRows];  // LDS counter (low 12 bits) and rank in it; ~0: handled directly
+#pragma unroll
+    for (uint32_t r = 0; r < kP2TileRows; ++r) {
+      const uint64_t i = t0 + (uint64_t)r * kP2Block + threadIdx.x;
+      const bool in = i < r1;
+      const uint64_t ic = in ? i : t0;
+      lo[r] = __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.in_lo + ic));
+      hi[r] = __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.in_hi + ic));
+      where[r] = ~0u;
+      if (!in) continue;
+      const uint32_t c = coarse_of(q, hi[r]), s = sub_of(q, lo[r], hi[r]);
+      if (c - c0 < span) {
+        const uint32_t li = (c - c0) * n_sub + s;
+        where[r] = li | (atomicAdd(&cnt[li], 1u) << 12);
+      } else {
+        // beyond the coarse buckets the counters cover: a place of its own
+        const uint32_t g = atomicAdd(&q.fine_cursor[((uint64_t)c << q.p2_bits) | s], 1u);
+        if (g < q.n_rows) {
+          q.out_lo[g] = lo[r];
+          q.out_hi[g] = hi[r];
+        }
+      }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kP2Counters; i += kP2Block) {
+      const uint32_t c = c0 + i / n_sub;
+      lstart[i] = i < n_cnt ? cnt[i] : 0u;
+      base[i] = (i < n_cnt && cnt[i] && c < n_coarse) ? atomicAdd(&q.fine_cursor[((uint64_t)c << q.p2_bits) | (i % n_sub)], cnt[i]) : 0u;
+    }
+    __syncthreads();
+    p2_block_scan(lstart, kP2Counters, wave_tot);
+#pragma unroll
+    for (uint32_t r = 0; r < kP2TileRows; ++r) {
+      if (where[r] == ~0u) continue;
+      const uint32_t pos = lstart[where[r] & 0xfffu] + (where[r] >> 12);
+      s_lo[pos] = lo[r];
+      s_hi[pos] = hi[r];
+    }
+    __syncthreads();
+    // out: neighbouring lanes hold neighbouring records of one fine bucket
+    const uint32_t n_live = lstart[kP2Counters];
+    for (uint32_t i = threadIdx.x; i < n_live; i += kP2Block) {
+      const unsigned long long w0 = s_lo[i], w1 = s_hi[i];
+      const uint32_t li = (coarse_of(q, w1) - c0) * n_sub + sub_of(q, w0, w1);
+      const uint32_t g = base[li] + (i - lstart[li]);
+      if (g < q.n_rows) {
+        q.out_lo[g] = w0;
+        q.out_hi[g] = w1;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Puts the pair into the LDS set unless it is there: 1 = it was new, 0 = it was there, -1 = the
+// set is full (which the passes of k_part2_agg are sized to avoid).  The low word claims the entry;
+// the claimant publishes the high word right after, until then it reads all ones.
+__device__ __forceinline__ int set_insert(unsigned long long* keys_lo, unsigned long long* keys_hi, uint32_t S, uint64_t lo,
+                                          uint64_t hi) {
+  // (32-bit mixing: the look-up runs once per row, and 64-bit multiplies are several instructions each)
+  uint32_t h = (uint32_t)lo ^ (uint32_t)(lo >> 32) * 0x85EBCA6Bu ^ (uint32_t)hi * 0xC2B2AE35u ^ (uint32_t)(hi >> 32);
+  h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+  uint32_t idx = __umulhi(h, S);
+  for (uint32_t probes = 0; probes < S; ++probes) {
+    unsigned long long k = __hip_atomic_load(&keys_lo[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (k == kP2Empty) {
+      const unsigned long long old = atomicCAS(&keys_lo[idx], kP2Empty, (unsigned long long)lo);
+      if (old == kP2Empty) {
+        __hip_atomic_store(&keys_hi[idx], (unsigned long long)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return 1;
+      }
+      k = old;
+    }
+    if (k == lo) {
+      const unsigned long long kh = __hip_atomic_load(&keys_hi[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (kh == hi) return 0;
+      if (kh == kP2Empty) { --probes; continue; }  // not published yet: look again
+    }
+    idx = idx + 1 == S ? 0u : idx + 1;
+  }
+  return -1;  // every entry holds another pair
+}
+
+__global__ __launch_bounds__(kP2AggBlock) void k_part2_agg(Part2Params q, uint32_t n_fine) {
+  extern __shared__ __align__(16) unsigned long long p2_lds[];
+  __shared__ unsigned long long gkey[kP2Groups];
+  __shared__ uint32_t gcnt[2][kP2Groups];
+  const uint32_t S = q.lds_entries, tid = threadIdx.x;
+  unsigned long long* keys_lo = p2_lds;
+  unsigned long long* keys_hi = p2_lds + S;
+  for (uint32_t i = tid; i < S; i += kP2AggBlock) { keys_lo[i] = kP2Empty; keys_hi[i] = kP2Empty; }
+  for (uint32_t i = tid; i < kP2Groups; i += kP2AggBlock) { gkey[i] = kP2Empty; gcnt[0][i] = 0; gcnt[1][i] = 0; }
+  // fine buckets are dealt round robin: they are many and alike, and a counter to hand them
+  // out would put a device-scope atomic and a barrier in front of every one of them
+  for (uint32_t f = blockIdx.x; f < n_fine; f += gridDim.x) {
+    __syncthreads();
+    const uint32_t b0 = q.fine_base[f], b1 = q.fine_base[f + 1];
+    if (b1 == b0) continue;
+    // A fine bucket of more rows than the set is sure to take (the coarse bucket of a very
+    // frequent group) is worked off in several passes over its rows, each taking the pairs of
+    // one residue class of another hash: the classes are disjoint, so their counts add up.
+    const uint32_t n = b1 - b0;
+    const uint32_t passes = n > S / 2 ? (n + S / 4 - 1) / (S / 4) : 1u;
+    for (uint32_t pass = 0; pass < passes; ++pass) {
+    if (pass) __syncthreads();  // the group counters of the pass before have been flushed
+    for (uint32_t i = b0 + tid; i < b1; i += kP2AggBlock) {
+      const uint64_t lo = __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.out_lo + i));
+      const uint64_t hi = __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.out_hi + i));
+      if (passes > 1 && (uint32_t)(hash64(lo * 0xD6E8FEB86659FD93ull + hi) >> 33) % passes != pass) continue;
+      const int r = set_insert(keys_lo, keys_hi, S, lo, hi);
+      if (r < 0) q.flags[0] = 1u;  // (a class far larger than its share: the result is void)
+      if (r != 1) continue;
+      // a pair seen for the first time counts for its group (walking the set afterwards to
+      // count its entries cost three times the instructions of the insertions themselves)
+      const uint32_t not_null = (q.x_null_bit >= 0 && ((lo >> q.x_null_bit) & 1ull)) ? 0u : 1u;
+      uint32_t g = (((uint32_t)hi ^ (uint32_t)(hi >> 32)) * 0x9E3779B1u) >> 23;  // kP2Groups = 2^9
+      bool placed = false;
+      for (uint32_t probes = 0; probes < kP2Groups && !placed; ++probes) {
+        unsigned long long k = __hip_atomic_load(&gkey[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (k == kP2Empty) {
+          const unsigned long long old = atomicCAS(&gkey[g], kP2Empty, (unsigned long long)hi);
+          k = old == kP2Empty ? hi : old;
+        }
+        if (k == hi) {
+          atomicAdd(&gcnt[0][g], 1u);
+          if (not_null) atomicAdd(&gcnt[1][g], 1u);
+          placed = true;
+        } else {
+          g = g + 1 == kP2Groups ? 0u : g + 1;
+        }
+      }
+      if (!placed) {  // more groups in one fine bucket than the counters hold: straight to the outer table
+        const uint64_t e = global_entry_raw(q.dense, q.capacity, q.g_keys, q.overflow, hi);
+        if (e != ~0ull) {
+          atomicAdd((unsigned long long*)&q.g_state[e], 1ull);
+          if (not_null) atomicAdd((unsigned long long*)&q.g_state[(q.capacity + 1) + e], 1ull);
+        }
+      }
+    }
+    __syncthreads();
+    // the set is emptied for the next bucket, the groups' counts go to the outer table
+    for (uint32_t i = tid; i < S; i += kP2AggBlock) { keys_lo[i] = kP2Empty; keys_hi[i] = kP2Empty; }
+    for (uint32_t i = tid; i < kP2Groups; i += kP2AggBlock) {
+      const unsigned long long hi = gkey[i];
+      if (hi == kP2Empty) continue;
+      const uint64_t e = global_entry_raw(q.dense, q.capacity, q.g_keys, q.overflow, hi);
+      if (e != ~0ull) {
+        atomicAdd((unsigned long long*)&q.g_state[e], (unsigned long long)gcnt[0][i]);
+        if (gcnt[1][i]) atomicAdd((unsigned long long*)&q.g_state[(q.capacity + 1) + e], (unsigned long long)gcnt[1][i]);
+      }
+      gkey[i] = kP2Empty;
+      gcnt[0][i] = 0;
+      gcnt[1][i] = 0;
+    }
+    }  // passes
+  }
+}
+
+}  // namespace
+
+uint32_t part2_lds_entries() {
+  // a workgroup's share of the LDS next to its static arrays (group counters), in 16-byte pairs
+  return (uint32_t)((kP2LdsBytes / kP2AggPerCu - kP2Groups * 16 - 256) / 16) & ~63u;
+}
+
+void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q) {
+  if (q.n_rows == 0) return;
+  const uint32_t n_fine = 1u << (q.p1_bits + q.p2_bits);
+  if (q.p2_bits > 10 || q.p1_bits + q.p2_bits > 21 || q.n_rows >= (1ull << 32) || q.slice_rows == 0)
+    fail(PRISM_GPU_EINTERNAL, "bad shape for the second partition level");
+  if (q.lds_entries > part2_lds_entries()) fail(PRISM_GPU_EINTERNAL, "the pair table exceeds LDS");
+  const uint32_t slices = (uint32_t)ceil_div(q.n_rows, q.slice_rows);
+  {
+    KernelTimer timer(ctx, "part2_hist", q.n_rows * 16);
+    k_part2_hist<<<dim3(slices), dim3(kP2Block), 0, ctx->stream>>>(q);
+    PRISM_HIP(hipGetLastError());
+    k_part2_scan<<<dim3(1), dim3(1024), 0, ctx->stream>>>(q, n_fine);
+    PRISM_HIP(hipGetLastError());
+  }
+  {
+    KernelTimer timer(ctx, "part2_scatter", q.n_rows * 32);
+    const size_t lds = (size_t)kP2Block * kP2TileRows * 16 + (size_t)(3 * kP2Counters + 1) * 4;
+    PRISM_HIP(hipFuncSetAttribute((const void*)k_part2_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_part2_scatter<<<dim3(slices), dim3(kP2Block), lds, ctx->stream>>>(q);
+    PRISM_HIP(hipGetLastError());
+  }
+  {
+    KernelTimer timer(ctx, "part2_agg", q.n_rows * 16);
+    const size_t lds = (size_t)q.lds_entries * 16;
+    PRISM_HIP(hipFuncSetAttribute((const void*)k_part2_agg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(n_fine, (uint64_t)ctx->n_cus * kP2AggPerCu);
+    k_part2_agg<<<dim3(grid), dim3(kP2AggBlock), lds, ctx->stream>>>(q, n_fine);
+    PRISM_HIP(hipGetLastError());
+  }
+}
+
+}  // namespace prism

@@ -185,6 +185,48 @@ def test_two_word_keys_and_count_distinct(part_ctx, oracle):
     _synth_both(part_ctx, oracle, wl, 1_500_000, 4, [(wl.query, 2)])
 
 
+def test_count_distinct_partitioned_twice(part_ctx, oracle):
+    """COUNT(DISTINCT) over two-word pairs: coarse buckets by group, fine buckets by pair, LDS
+    sets, per-group counts straight into the outer table (no set in HBM).  C5's shape, and a
+    table whose 62-bit values have NULLs (a NULL is a pair of its own but is not counted)."""
+    import numpy as np
+    import pyarrow as pa
+    from prism_amd.engine import Plan, Table
+
+    wl = workloads.c5(n_services=16, user_bits=14)
+    part_ctx.reset_stats()
+    _synth_both(part_ctx, oracle, wl, 1_500_000, 4, [(wl.query, 2)])
+    assert {"part2_hist", "part2_scatter", "part2_agg"} <= _kernels(part_ctx)
+
+    rng = np.random.default_rng(21)
+    n = 300_000
+    a = rng.integers(0, 5000, n).astype(np.int64) * (2**62 // 5000) - 2**61
+    t = pa.table({"a": pa.array(a, mask=rng.random(n) < 0.05),
+                  "b": pa.array(rng.integers(0, 200, n).astype(np.int64) * (2**40 // 200), mask=rng.random(n) < 0.01),
+                  "c": pa.array(rng.integers(0, 9, n).astype(np.int32))})
+    g = Table(part_ctx, t.schema)
+    g.append_table(t, 3)
+    try:
+        for q in [QueryPlan([count_distinct("a")], keys=["c", "b"]),
+                  QueryPlan([count_distinct("a")], keys=["c"], predicate=col("c") > 2),
+                  QueryPlan([count_distinct("a")], keys=["b"], order_by=1, descending=True, limit=5)]:
+            plan = Plan(part_ctx, t.schema, q)
+            try:
+                got = plan.execute(g)
+                again = plan.execute(g)
+            finally:
+                plan.close()
+            want = oracle.execute(t, q)
+            if q.limit is not None:
+                assert_topk_match(got, want, q.order_by)
+                assert_topk_match(again, want, q.order_by)
+            else:
+                assert_tables_match(got, want, len(q.keys))
+                assert_tables_match(again, want, len(q.keys))
+    finally:
+        g.close()
+
+
 def test_streaming_kernel_hands_over_when_rows_scatter(oracle):
     """No forcing: the streaming kernel runs first, finds that its rows miss the LDS tables,
     stops, and the plan is partitioned from then on (its predicate, evaluated inside the
