@@ -48,10 +48,19 @@ __device__ __forceinline__ uint64_t hash64(uint64_t z) {
   return z ^ (z >> 31);
 }
 
-// One fixed-width value widened to int64.
+// 32 mixed bits of a 64-bit key from three 32-bit multiplies; the top bits pick a bucket of
+// the partition passes (uniform enough for that; hash64 is the hash of the tables).
+__device__ __forceinline__ uint32_t bucket_hash32(uint64_t k) {
+  uint32_t x = (uint32_t)k ^ ((uint32_t)(k >> 32) * 0x85EBCA6Bu);
+  x = (x ^ (x >> 16)) * 0x7FEB352Du;
+  x = (x ^ (x >> 15)) * 0x846CA68Bu;
+  return x;
+}
+
 // Hash of the high word of a two-word key (the group of a COUNT(DISTINCT) pair).
 __device__ __forceinline__ uint64_t part_hash_hi(uint64_t hi) { return hash64(hi ^ 0xA0761D6478BD642Full); }
 
+// One fixed-width value widened to int64.
 __device__ __forceinline__ long long load_value(const void* base, int width, int is_unsigned, uint64_t row) {
   if (width == 8) return ((const long long*)base)[row];
   if (width == 4) return is_unsigned ? (long long)((const unsigned int*)base)[row] : (long long)((const int*)base)[row];

@@ -59,11 +59,14 @@ __device__ __forceinline__ uint64_t part_hash(uint64_t lo, uint64_t hi) {
   return KW == 2 ? hash64(lo ^ hash64(hi)) : hash64(lo);
 }
 
-// The hash a row's bucket is taken from: the whole key, or (two-word pairs of a COUNT(DISTINCT)
-// that is partitioned twice) the high word alone, so that a group's pairs share a bucket.
+// The hash a row's bucket is taken from (its top bits): for one-word keys 32 bits mixed with
+// three 32-bit multiplies (the two 64-bit multiplies of hash64 are eight), for two-word keys
+// the whole pair, or (pairs of a COUNT(DISTINCT) that is partitioned twice) the high word
+// alone, so that a group's pairs share a bucket.
 template <int KW>
 __device__ __forceinline__ uint64_t part_bucket_hash(const PartParams& q, uint64_t lo, uint64_t hi) {
-  if (KW == 2 && q.by_hi) return part_hash_hi(hi);
+  if (KW == 1) return (uint64_t)bucket_hash32(lo) << 32;
+  if (q.by_hi) return part_hash_hi(hi);
   return part_hash<KW>(lo, hi);
 }
 
@@ -150,6 +153,129 @@ __device__ __forceinline__ void part_load_keys(const AggParams& p, const PartTil
   }
 }
 
+// Plans whose key columns (at most one per key word) carry no validity bitmap load their keys
+// one super-tile ahead: the raw column words are requested here and turned into packed keys
+// (part_finish_keys) an iteration later, so the loads are in flight while the tile before is
+// ranked, sorted and copied out.
+// Where a workgroup stands in the scan when it takes its tiles in order: the segment of the
+// last tile and the column bases there, all in scalar registers.  (Looking a tile's segment up
+// and fetching the column pointers for it is a chain of eight dependent scalar loads from
+// device memory; per tile, that chain was a quarter of the scatter pass.)
+template <int NC>
+struct PartCursor {
+  uint32_t seg;
+  uint64_t base, rows, next_base;  // first tile and rows of the segment; first tile of the next one
+  PartBytePtr col[NC];             // values of the key columns, then of the value columns
+};
+
+template <int KW, int NV>
+__device__ __forceinline__ void part_cursor_load(const AggParams& p, PartCursor<KW + NV>& c, uint32_t seg) {
+  c.seg = seg;
+  c.base = part_uniform(p.sd.segs[seg].tile_base);
+  c.rows = part_uniform(p.sd.segs[seg].rows);
+  c.next_base = seg + 1 < p.sd.n_segs ? part_uniform(p.sd.segs[seg + 1].tile_base) : ~0ull;
+#pragma unroll
+  for (int k = 0; k < KW; ++k)
+    c.col[k] = k < p.n_keys ? (PartBytePtr)part_uniform((uint64_t)p.cols[(uint64_t)p.keys[k].col * p.sd.n_segs + seg].values) : nullptr;
+#pragma unroll
+  for (int v = 0; v < NV; ++v)
+    c.col[KW + v] = (PartBytePtr)part_uniform((uint64_t)p.cols[(uint64_t)p.vals[v].col * p.sd.n_segs + seg].values);
+}
+
+template <int KW, int NV>
+__device__ __forceinline__ void part_cursor_init(const AggParams& p, PartCursor<KW + NV>& c, uint64_t tile) {
+  const uint64_t last = p.sd.n_tiles ? p.sd.n_tiles - 1 : 0;
+  part_cursor_load<KW, NV>(p, c, __builtin_amdgcn_readfirstlane(find_seg(p.sd, tile < last ? tile : last)));
+}
+
+// The loads of one scan tile (group G of the super-tile: its rows 4 G .. 4 G + 3).  Tiles are
+// asked for in rising order; a tile at or beyond t1 has no rows (its lanes load row 0 of the
+// cursor's segment and are dropped by `live`).
+template <int KW, int NV, int R, int G>
+__device__ __forceinline__ void part_issue_group(const AggParams& p, PartCursor<KW + NV>& c, uint64_t tile, uint64_t t1, uint32_t tid,
+                                                 unsigned long long (&raw)[KW + NV][R], uint32_t& live) {
+  uint32_t n = 0, row0 = 0;
+  if (tile < t1) {
+    while (tile >= c.next_base) part_cursor_load<KW, NV>(p, c, c.seg + 1);
+    const uint64_t first = (tile - c.base) * kTileRows, left = c.rows - first;
+    row0 = (uint32_t)first;
+    n = left > kTileRows ? kTileRows : (uint32_t)left;
+  }
+  uint32_t rowc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t in_tile = (uint32_t)i * kPartBlock + tid;
+    bool in = in_tile < n;
+    rowc[i] = row0 + (in ? in_tile : 0u);
+    if (p.row_mode == kRowsBitmap) {
+      const uint64_t pid = tile * kTileRows + in_tile;
+      const uint64_t word = in ? p.sel_bits[pid >> 6] : 0ull;
+      in = in && ((word >> (pid & 63)) & 1ull);
+    }
+    live |= (in ? 1u : 0u) << (4 * G + i);
+  }
+#pragma unroll
+  for (int k = 0; k < KW; ++k) {
+    if (k >= p.n_keys) break;
+    const uint32_t width = (uint32_t)p.keys[k].width;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      raw[k][4 * G + i] = __builtin_nontemporal_load((const __attribute__((address_space(1))) part_unaligned_u64*)(c.col[k] + rowc[i] * width));
+  }
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const uint32_t width = (uint32_t)p.vals[v].width;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      raw[KW + v][4 * G + i] = __builtin_nontemporal_load((const __attribute__((address_space(1))) part_unaligned_u64*)(c.col[KW + v] + rowc[i] * width));
+  }
+}
+
+// All the loads of the super-tile that starts at `tile`.
+template <int KW, int NV, int R>
+__device__ __forceinline__ void part_issue(const AggParams& p, PartCursor<KW + NV>& c, uint64_t tile, uint64_t t1, uint32_t tid,
+                                           unsigned long long (&raw)[KW + NV][R], uint32_t& live) {
+  live = 0;
+  part_issue_group<KW, NV, R, 0>(p, c, tile, t1, tid, raw, live);
+  if constexpr (R >= 8) part_issue_group<KW, NV, R, 1>(p, c, tile + 1, t1, tid, raw, live);
+  if constexpr (R >= 16) {
+    part_issue_group<KW, NV, R, 2>(p, c, tile + 2, t1, tid, raw, live);
+    part_issue_group<KW, NV, R, 3>(p, c, tile + 3, t1, tid, raw, live);
+  }
+}
+
+// The words requested by part_issue as a record: packed key word(s), then the widened values.
+template <int KW, int NV, int R>
+__device__ __forceinline__ void part_finish(const AggParams& p, const unsigned long long (&raw)[KW + NV][R],
+                                            uint64_t (&rec)[KW + NV][R]) {
+  uint64_t lo[R], hi[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) { lo[r] = 0; hi[r] = 0; }
+#pragma unroll
+  for (int k = 0; k < KW; ++k) {
+    if (k >= p.n_keys) break;
+    const KeySpec& ks = p.keys[k];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      long long v = part_widen(raw[k][r], ks.width, ks.is_unsigned);
+      if (ks.date_bin) v = bucket_number(v, ks);
+      const uint64_t field = ((uint64_t)v - (uint64_t)ks.bias) << ks.bit_pos;
+      if (KW == 2 && ks.word) hi[r] |= field; else lo[r] |= field;
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const ValSpec& vs = p.vals[v];
+#pragma unroll
+    for (int r = 0; r < R; ++r) rec[KW + v][r] = (uint64_t)part_widen(raw[KW + v][r], vs.width, vs.is_unsigned);
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    rec[0][r] = lo[r];
+    if (KW == 2) rec[1][r] = hi[r];
+  }
+}
+
 // The aggregate inputs of the same rows, widened to 64 bits; validw[r] bit v = value v is not NULL.
 template <int NV, bool VALID, int R>
 __device__ __forceinline__ void part_load_vals(const AggParams& p, const PartTile (&tl)[R / 4], const uint32_t (&rowc)[R],
@@ -204,7 +330,7 @@ __device__ __forceinline__ void part_block_scan(uint32_t* a, uint32_t n, uint32_
 
 // ---- pass 1a: histogram ------------------------------------------------------------
 
-template <int KW>
+template <int KW, bool AHEAD>
 __global__ __launch_bounds__(kPartBlock) void k_part_hist(AggParams p, PartParams q) {
   constexpr int R = 8;
   extern __shared__ __align__(16) unsigned long long part_lds[];
@@ -215,13 +341,31 @@ __global__ __launch_bounds__(kPartBlock) void k_part_hist(AggParams p, PartParam
   const uint64_t t0 = (uint64_t)blockIdx.x * q.tiles_per_wg;
   const uint64_t t1 = t0 + q.tiles_per_wg < p.sd.n_tiles ? t0 + q.tiles_per_wg : p.sd.n_tiles;
   const int shift = 64 - q.p_bits;
+  constexpr bool ahead = AHEAD;
+  PartTile tl[R / 4];
+  unsigned long long raw[KW][R];
+  uint32_t live_next = 0;
+  PartCursor<KW> cur;
+  if (ahead && t0 < t1) {
+    part_cursor_init<KW, 0>(p, cur, t0);
+    part_issue<KW, 0, R>(p, cur, t0, t1, tid, raw, live_next);
+  }
   for (uint64_t t = t0; t < t1; t += R / 4) {
-    PartTile tl[R / 4];
-#pragma unroll
-    for (int j = 0; j < R / 4; ++j) tl[j] = part_tile(p, t + j, t1);
     uint64_t lo[R], hi[R];
-    uint32_t rowc[R], live;
-    part_load_keys<KW, R>(p, tl, tid, lo, hi, rowc, live);
+    uint32_t live;
+    if constexpr (ahead) {
+      uint64_t rec[KW][R];
+      part_finish<KW, 0, R>(p, raw, rec);
+#pragma unroll
+      for (int r = 0; r < R; ++r) { lo[r] = rec[0][r]; hi[r] = KW == 2 ? rec[KW - 1][r] : 0ull; }
+      live = live_next;
+      if (t + R / 4 < t1) part_issue<KW, 0, R>(p, cur, t + R / 4, t1, tid, raw, live_next);
+    } else {
+      uint32_t rowc[R];
+#pragma unroll
+      for (int j = 0; j < R / 4; ++j) tl[j] = part_tile(p, t + j, t1);
+      part_load_keys<KW, R>(p, tl, tid, lo, hi, rowc, live);
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r)
       if ((live >> r) & 1u) atomicAdd(&h[(uint32_t)(part_bucket_hash<KW>(q, lo[r], hi[r]) >> shift)], 1u);
@@ -303,47 +447,92 @@ __global__ __launch_bounds__(kPartBlock) void k_part_plan(PartParams q) {
 template <int W>
 constexpr int part_rows_per_thread() { return W == 1 ? 16 : (W == 2 ? 8 : 4); }
 
-template <int KW, int NV, bool VALID>
+// Per super-tile (R rows a thread): the rows are ranked inside their buckets with LDS counters,
+// the counters are scanned, the records are put in bucket order in LDS and leave as runs.  The
+// counters are double buffered (the next tile's are cleared while this tile's are still read)
+// and every thread keeps the output cursors of its own buckets in registers, which leaves
+// four barriers per tile.
+//
+// AHEAD (no validity bitmaps to read, at most one key column per key word): the column words
+// of a tile are requested two tiles before they are used and turned into records one tile
+// before, right ahead of the copy-out of the tile in between.  The wait for them is then also
+// the wait for the stores of the copy-out a whole tile earlier (one counter covers loads and
+// stores, in order), which have long completed; waiting right after a copy-out instead was
+// half of this kernel's time.
+template <int KW, int NV, bool VALID, bool AHEAD>
 __global__ __launch_bounds__(kPartBlock) void k_part_scatter(AggParams p, PartParams q) {
+  static_assert(!(AHEAD && VALID), "validity bitmaps are read with the values, not ahead of them");
   constexpr int W = KW + NV + (VALID ? 1 : 0);
+  constexpr int WA = AHEAD ? KW + NV : 1;
   constexpr int R = part_rows_per_thread<W>();
   constexpr uint32_t T = (uint32_t)R * kPartBlock;
   extern __shared__ __align__(16) unsigned long long part_lds[];
   __shared__ uint32_t wave_tot[kPartBlock / 64];
-  unsigned long long* sorted = part_lds;                  // [W][T]
-  uint32_t* start = (uint32_t*)(part_lds + (size_t)W * T);  // [P + 1]: rows of the tile per bucket, then their first slot
+  unsigned long long* sorted = part_lds;                        // [W][T]
+  uint32_t* counters = (uint32_t*)(part_lds + (size_t)W * T);   // [2][P + 2]: rows of the tile per bucket, then their first slot
   const uint32_t tid = threadIdx.x, P = q.n_buckets;
-  uint32_t* cursor = start + P + 2;                       // [P]: next record of this workgroup in each bucket
-  for (uint32_t b = tid; b < P; b += kPartBlock) {
-    cursor[b] = (uint32_t)q.bucket_base[b] + q.hist[(uint64_t)blockIdx.x * P + b];
-    start[b] = 0;
+  uint32_t* delta = counters + 2 * (P + 2);                     // [P]: a bucket's place in the output minus its place in the tile
+  uint32_t cursor[4];  // next record of this workgroup in the buckets tid, tid + 1024, ...
+#pragma unroll
+  for (uint32_t i = 0; i < 4; ++i) {
+    const uint32_t b = tid + i * kPartBlock;
+    cursor[i] = 0;
+    if (b < P) {
+      cursor[i] = (uint32_t)q.bucket_base[b] + q.hist[(uint64_t)blockIdx.x * P + b];
+      counters[b] = 0;
+      counters[P + 2 + b] = 0;
+    }
   }
-  if (tid == 0) start[P] = 0;
   __syncthreads();
   const uint64_t t0 = (uint64_t)blockIdx.x * q.tiles_per_wg;
   const uint64_t t1 = t0 + q.tiles_per_wg < p.sd.n_tiles ? t0 + q.tiles_per_wg : p.sd.n_tiles;
   const int shift = 64 - q.p_bits;
-  for (uint64_t t = t0; t < t1; t += R / 4) {
-    PartTile tl[R / 4];
-#pragma unroll
-    for (int j = 0; j < R / 4; ++j) tl[j] = part_tile(p, t + j, t1);
-    uint64_t rec[W][R];
-    uint32_t rowc[R], live;
-    {
-      uint64_t hi_unused[R];
-      part_load_keys<KW, R>(p, tl, tid, rec[0], KW == 2 ? rec[KW - 1] : hi_unused, rowc, live);
+  constexpr uint64_t kStep = R / 4;
+  uint64_t rec[W][R];
+  uint32_t live = 0, live_next = 0;
+  unsigned long long raw[WA][R];
+  PartCursor<WA> cur;
+  if constexpr (AHEAD) {
+    if (t0 < t1) {
+      part_cursor_init<KW, NV>(p, cur, t0);
+      part_issue<KW, NV, R>(p, cur, t0, t1, tid, raw, live);
+      part_finish<KW, NV, R>(p, raw, rec);
     }
-    if constexpr (NV > 0) {
-      uint64_t val[NV][R], validw[R];
-      part_load_vals<NV, VALID, R>(p, tl, rowc, val, validw);
+  }
+  // `pending`: the next super-tile exists and the loads of its first scan tile are on their way;
+  // the loads of its other tiles are issued between the phases of the loop body, a few at a
+  // time (a burst of all of them only stalls in the issue: a CU holds so many misses)
+  bool pending = false;
+  if constexpr (AHEAD) {
+    pending = t0 + kStep < t1;
+    if (pending) part_issue_group<KW, NV, R, 0>(p, cur, t0 + kStep, t1, tid, raw, live_next);
+  }
+  uint32_t flip = 0;
+  for (uint64_t t = t0; t < t1; t += kStep, flip ^= 1u) {
+    uint32_t* start = counters + flip * (P + 2);
+    uint32_t* start_next = counters + (flip ^ 1u) * (P + 2);
+    if constexpr (!AHEAD) {
+      PartTile tl[R / 4];
+      uint32_t rowc[R];
+      uint64_t hi_unused[R];
 #pragma unroll
-      for (int v = 0; v < NV; ++v)
+      for (int j = 0; j < R / 4; ++j) tl[j] = part_tile(p, t + j, t1);
+      part_load_keys<KW, R>(p, tl, tid, rec[0], KW == 2 ? rec[KW - 1] : hi_unused, rowc, live);
+      if constexpr (NV > 0) {
+        uint64_t val[NV][R], validw[R];
+        part_load_vals<NV, VALID, R>(p, tl, rowc, val, validw);
 #pragma unroll
-        for (int r = 0; r < R; ++r) rec[KW + v][r] = val[v][r];
-      if constexpr (VALID) {
+        for (int v = 0; v < NV; ++v)
 #pragma unroll
-        for (int r = 0; r < R; ++r) rec[W - 1][r] = validw[r];
+          for (int r = 0; r < R; ++r) rec[KW + v][r] = val[v][r];
+        if constexpr (VALID) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) rec[W - 1][r] = validw[r];
+        }
       }
+    }
+    if constexpr (AHEAD && R >= 8) {
+      if (pending) part_issue_group<KW, NV, R, 1>(p, cur, t + kStep + 1, t1, tid, raw, live_next);
     }
     // rank of every row among the tile's rows of its bucket
     uint32_t slot[R];  // bucket (low 12 bits) and rank inside it (a tile holds at most 2^14 rows)
@@ -354,8 +543,14 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(AggParams p, PartPa
       if ((live >> r) & 1u) slot[r] |= atomicAdd(&start[b], 1u) << 12;
     }
     __syncthreads();
+    if constexpr (AHEAD && R >= 16) {
+      if (pending) part_issue_group<KW, NV, R, 2>(p, cur, t + kStep + 2, t1, tid, raw, live_next);
+    }
     part_block_scan(start, P, wave_tot);
     __syncthreads();
+    if constexpr (AHEAD && R >= 16) {
+      if (pending) part_issue_group<KW, NV, R, 3>(p, cur, t + kStep + 3, t1, tid, raw, live_next);
+    }
     // the tile's records, sorted by bucket, in LDS
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -364,13 +559,37 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(AggParams p, PartPa
 #pragma unroll
       for (int w = 0; w < W; ++w) sorted[(size_t)w * T + pos] = rec[w][r];
     }
+    // the thread's own buckets: where their runs go, the cursors behind them, and the other
+    // set of counters cleared for the next tile
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) {
+      const uint32_t b = tid + i * kPartBlock;
+      if (b < P) {
+        const uint32_t s0 = start[b], s1 = start[b + 1];
+        delta[b] = cursor[i] - s0;
+        cursor[i] += s1 - s0;
+        start_next[b] = 0;
+      }
+    }
+    if constexpr (AHEAD) {
+      // the next tile's records, and the first requests for the tile after it
+      if (pending) {
+        part_finish<KW, NV, R>(p, raw, rec);
+        live = live_next;
+        pending = t + 2 * kStep < t1;
+        if (pending) {
+          live_next = 0;
+          part_issue_group<KW, NV, R, 0>(p, cur, t + 2 * kStep, t1, tid, raw, live_next);
+        }
+      }
+    }
     __syncthreads();
     // out: neighbouring lanes hold neighbouring records of one bucket
     const uint32_t n_live = start[P];
     for (uint32_t i = tid; i < n_live; i += kPartBlock) {
       uint64_t w0 = sorted[i], w1 = KW == 2 ? sorted[(size_t)T + i] : 0ull;
       const uint32_t b = (uint32_t)(part_bucket_hash<KW>(q, w0, w1) >> shift);
-      const uint64_t g = (uint64_t)cursor[b] + (i - start[b]);
+      const uint64_t g = (uint64_t)(delta[b] + i);
       if (g < q.rec_capacity) {
         q.rec[0][g] = w0;
         if (KW == 2) q.rec[1][g] = w1;
@@ -378,21 +597,8 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(AggParams p, PartPa
         for (int w = KW; w < W; ++w) q.rec[w][g] = sorted[(size_t)w * T + i];
       }
     }
-    __syncthreads();
-    uint32_t cnt[4];
-#pragma unroll
-    for (uint32_t i = 0; i < 4; ++i) {
-      const uint32_t b = tid + i * kPartBlock;
-      cnt[i] = b < P ? start[b + 1] - start[b] : 0u;
-    }
-    __syncthreads();
-#pragma unroll
-    for (uint32_t i = 0; i < 4; ++i) {
-      const uint32_t b = tid + i * kPartBlock;
-      if (b < P) { cursor[b] += cnt[i]; start[b] = 0; }
-    }
-    if (tid == 0) start[P] = 0;
-    __syncthreads();
+    // (no barrier here: the next tile's ranks go to the other set of counters, and nothing
+    // of this tile is overwritten before the next tile's first barrier)
   }
 }
 
@@ -498,6 +704,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_agg(AggParams p, PartParams
   __shared__ unsigned long long out_base;
   const uint32_t S = q.lds_entries & ~1u, tid = threadIdx.x, lane = tid & 63u;
   const int n_lds_slots = p.keys_only ? 0 : p.n_slots;
+  const bool count_only = n_lds_slots == 1 && p.slots[0].op == kSlotAddOne;  // COUNT(*) and nothing else
   unsigned long long* keys_lo = part_lds;
   unsigned long long* keys_hi = part_lds + (KW == 2 ? S : 0);
   long long* state = (long long*)(part_lds + (size_t)KW * S);  // [n_lds_slots][S]
@@ -550,7 +757,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_agg(AggParams p, PartParams
       // them is looked at, so the LDS latencies overlap instead of adding up row after row (a
       // key that another row of the step inserts meanwhile is simply not seen here: the row
       // then takes the search-and-insert path, which reads again).
-      int found[kPartAggInFlight];
+      int found[kPartAggInFlight], vacant[kPartAggInFlight];
       if (KW == 1) {
         ulonglong2 c1[kPartAggInFlight], c2[kPartAggInFlight];
         uint32_t hb1[kPartAggInFlight], hb2[kPartAggInFlight];
@@ -574,6 +781,13 @@ __global__ __launch_bounds__(kPartBlock) void k_part_agg(AggParams p, PartParams
           f = c1[u].y == lo ? (int)(2 * hb1[u] + 1) : f;
           f = c1[u].x == lo ? (int)(2 * hb1[u]) : f;
           found[u] = f;
+          // the first free entry on the key's path, as far as the two home buckets go
+          int v = -1;
+          v = c2[u].y == kPartEmpty ? (int)(2 * hb2[u] + 1) : v;
+          v = c2[u].x == kPartEmpty ? (int)(2 * hb2[u]) : v;
+          v = c1[u].y == kPartEmpty ? (int)(2 * hb1[u] + 1) : v;
+          v = c1[u].x == kPartEmpty ? (int)(2 * hb1[u]) : v;
+          vacant[u] = v;
         }
       }
 #pragma unroll
@@ -626,6 +840,16 @@ __global__ __launch_bounds__(kPartBlock) void k_part_agg(AggParams p, PartParams
         // a branch); only the lanes that found nothing (new keys, as a rule) enter the
         // search-and-insert loop.
         if (KW == 1 && search && found[u] >= 0) { e = found[u]; search = false; }
+        // A new key, as a rule, finds a free entry in its home buckets: one attempt to claim it,
+        // without the loop (which a whole wave walks through for its few new keys).  The entry
+        // was free when the buckets were read and the ones before it on the path were taken, and
+        // entries only ever fill up: if the claim succeeds, or meets the same key, the entry is
+        // the key's.  Anything else (another key got there first, no free entry) is for the loop.
+        if (KW == 1 && search && vacant[u] >= 0) {
+          const unsigned long long old = atomicCAS(&keys_lo[vacant[u]], kPartEmpty, (unsigned long long)lo);
+          if (old == kPartEmpty) { ins = true; e = vacant[u]; search = false; }
+          else if (old == lo) { e = vacant[u]; search = false; }
+        }
         if (search) e = part_find<KW>(keys_lo, keys_hi, S, (int)q.lds_limit, &n_entries, lo, hi, ins);
         const uint64_t m_ins = __ballot(ins);
         if (m_ins && (int)lane == __ffsll((long long)m_ins) - 1) atomicAdd(&n_entries, __popcll(m_ins));
@@ -636,9 +860,13 @@ __global__ __launch_bounds__(kPartBlock) void k_part_agg(AggParams p, PartParams
           if (rejected) part_hbm_update<KW, NV>(p, lo, hi, rv);
         }
         if (act && e >= 0) {
-          for (int s = 0; s < n_lds_slots; ++s) {
-            long long x;
-            if (slot_input(p, s, rv, x)) atomic_apply(&state[(size_t)s * S + (uint32_t)e], p.slots[s].op, x);
+          if (count_only) {
+            atomicAdd((unsigned long long*)&state[(uint32_t)e], 1ull);
+          } else {
+            for (int s = 0; s < n_lds_slots; ++s) {
+              long long x;
+              if (slot_input(p, s, rv, x)) atomic_apply(&state[(size_t)s * S + (uint32_t)e], p.slots[s].op, x);
+            }
           }
         }
       }
@@ -699,24 +927,37 @@ struct PartKernels {
 };
 
 template <int KW, int NV, bool VALID>
-PartKernels part_kernels() {
-  return {k_part_hist<KW>, k_part_scatter<KW, NV, VALID>, k_part_agg<KW, NV, VALID>, KW + NV + (VALID ? 1 : 0)};
+PartKernels part_kernels(bool ahead) {
+  if constexpr (!VALID) {
+    if (ahead) return {k_part_hist<KW, true>, k_part_scatter<KW, NV, false, true>, k_part_agg<KW, NV, false>, KW + NV};
+  }
+  if (ahead) return {k_part_hist<KW, true>, k_part_scatter<KW, NV, VALID, false>, k_part_agg<KW, NV, VALID>, KW + NV + (VALID ? 1 : 0)};
+  return {k_part_hist<KW, false>, k_part_scatter<KW, NV, VALID, false>, k_part_agg<KW, NV, VALID>, KW + NV + (VALID ? 1 : 0)};
 }
 
-bool pick_part_kernels(int kw, int nv, bool valid, PartKernels* out) {
+// Whether the scan kernels may load the keys a super-tile ahead: at most one key column per
+// key word, none of them nullable.
+bool part_keys_ahead(const AggParams& p) {
+  if (p.n_keys > p.key_words) return false;
+  for (int k = 0; k < p.n_keys; ++k)
+    if (p.keys[k].null_bit >= 0) return false;
+  return true;
+}
+
+bool pick_part_kernels(int kw, int nv, bool valid, bool ahead, PartKernels* out) {
   if (valid && nv == 0) valid = false;
   const int code = kw * 100 + nv * 10 + (valid ? 1 : 0);
   switch (code) {
-    case 100: *out = part_kernels<1, 0, false>(); return true;
-    case 110: *out = part_kernels<1, 1, false>(); return true;
-    case 111: *out = part_kernels<1, 1, true>(); return true;
-    case 120: *out = part_kernels<1, 2, false>(); return true;
-    case 121: *out = part_kernels<1, 2, true>(); return true;
-    case 130: *out = part_kernels<1, 3, false>(); return true;
-    case 200: *out = part_kernels<2, 0, false>(); return true;
-    case 210: *out = part_kernels<2, 1, false>(); return true;
-    case 211: *out = part_kernels<2, 1, true>(); return true;
-    case 220: *out = part_kernels<2, 2, false>(); return true;
+    case 100: *out = part_kernels<1, 0, false>(ahead); return true;
+    case 110: *out = part_kernels<1, 1, false>(ahead); return true;
+    case 111: *out = part_kernels<1, 1, true>(ahead); return true;
+    case 120: *out = part_kernels<1, 2, false>(ahead); return true;
+    case 121: *out = part_kernels<1, 2, true>(ahead); return true;
+    case 130: *out = part_kernels<1, 3, false>(ahead); return true;
+    case 200: *out = part_kernels<2, 0, false>(ahead); return true;
+    case 210: *out = part_kernels<2, 1, false>(ahead); return true;
+    case 211: *out = part_kernels<2, 1, true>(ahead); return true;
+    case 220: *out = part_kernels<2, 2, false>(ahead); return true;
     default: return false;
   }
 }
@@ -731,15 +972,15 @@ void allow_lds(PartKernel k, size_t bytes) {
 
 int part_record_words(const AggParams& p, bool vals_nullable) {
   PartKernels k;
-  if (!pick_part_kernels(p.key_words, p.keys_only ? 0 : p.n_vals, vals_nullable, &k)) return 0;
+  if (!pick_part_kernels(p.key_words, p.keys_only ? 0 : p.n_vals, vals_nullable, false, &k)) return 0;
   return k.words;
 }
 
 uint32_t part_max_buckets(int words) {
-  // scatter workgroup: W * R * 1024 records of 8 bytes, (P + 2) + P counters of 4 bytes
+  // scatter workgroup: W * R * 1024 records of 8 bytes, 2 * (P + 2) + P counters of 4 bytes
   const size_t tile = (size_t)words * (words == 1 ? 16 : (words == 2 ? 8 : 4)) * kPartBlock * 8;
   size_t p = 64;
-  while (p * 2 <= 4 * kPartBlock && tile + (2 * (p * 2) + 2) * 4 <= kPartLdsBytes) p *= 2;
+  while (p * 2 <= 4 * kPartBlock && tile + (3 * (p * 2) + 4) * 4 <= kPartLdsBytes) p *= 2;
   return (uint32_t)p;
 }
 
@@ -760,7 +1001,7 @@ void launch_partitioned_group_by(prism_gpu_ctx* ctx, const AggParams& p_scan, co
                                  uint64_t hist_bytes, uint64_t scatter_bytes, uint64_t agg_bytes, bool scatter_only) {
   const AggParams& p_table = p_scan;  // the same descriptor carries the scan and the HBM table the stragglers go to
   PartKernels k;
-  if (!pick_part_kernels(p_scan.key_words, p_scan.keys_only ? 0 : p_scan.n_vals, vals_nullable, &k))
+  if (!pick_part_kernels(p_scan.key_words, p_scan.keys_only ? 0 : p_scan.n_vals, vals_nullable, part_keys_ahead(p_scan), &k))
     fail(PRISM_GPU_EINTERNAL, "no partitioned GROUP BY kernel for this plan shape");
   const uint32_t P = q.n_buckets;
   if (P < 64 || P > part_max_buckets(k.words) || (P & (P - 1)) != 0 || (1u << q.p_bits) != P)
@@ -768,7 +1009,7 @@ void launch_partitioned_group_by(prism_gpu_ctx* ctx, const AggParams& p_scan, co
   if (q.n_wg == 0 || (uint64_t)q.n_wg * q.tiles_per_wg < p_scan.sd.n_tiles || q.tiles_per_wg % 4 != 0)
     fail(PRISM_GPU_EINTERNAL, "bad work split for the partitioned GROUP BY");
   const int R = k.words == 1 ? 16 : (k.words == 2 ? 8 : 4);
-  const size_t scatter_lds = (size_t)k.words * R * kPartBlock * 8 + (size_t)(2 * P + 2) * 4;
+  const size_t scatter_lds = (size_t)k.words * R * kPartBlock * 8 + (size_t)(3 * P + 4) * 4;
   const size_t agg_lds = (size_t)q.lds_entries * 8 * ((size_t)p_scan.key_words + (p_scan.keys_only ? 0 : (size_t)p_scan.n_slots));
   if (scatter_lds > kPartLdsBytes || agg_lds > kPartLdsBytes) fail(PRISM_GPU_EINTERNAL, "partitioned GROUP BY exceeds LDS");
   allow_lds(k.scatter, scatter_lds);
