@@ -1122,8 +1122,7 @@ uint64_t partitioned_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, AggParam
   q.n_wg = part_scan_workgroups(ctx, ap, &q.tiles_per_wg);
   // A bucket of more than 4 times the average holds a heavy hitter and is aggregated in
   // slices, by several workgroups, that meet in the HBM table.  (Slices are kept large: every
-  // slice sends each of the bucket's ordinary keys it has seen to the HBM table, and rows of
-  // the heavy hitter itself are cheap, being reduced wave by wave.)
+  // slice sends each of the bucket's ordinary keys it has seen to the HBM table.)
   q.chunk_rows = (uint32_t)std::min<uint64_t>(1u << 30, std::max<uint64_t>(65536, 4 * ceil_div(selected, P)));
   q.max_items = (uint32_t)(P + selected / q.chunk_rows + 2);
   q.lds_entries = lds_entries;

@@ -790,86 +790,75 @@ __global__ __launch_bounds__(kPartBlock) void k_part_agg(AggParams p, PartParams
           vacant[u] = v;
         }
       }
-#pragma unroll
-      for (int u = 0; u < kPartAggInFlight; ++u) {
-        const uint64_t lo = rec[u][0], hi = KW == 2 ? rec[u][KW - 1] : 0ull;
+      auto row_values = [&](int u) {
         RowValsT<NV> rv;
         rv.valid = VALID ? (uint32_t)rec[u][W - 1] : 0xffffffffu;
 #pragma unroll
         for (int v = 0; v < NV; ++v) rv.v[v] = (long long)rec[u][KW + v];
-        bool act = in[u];
-        {
-          // Heavy hitters: when many lanes of the wave carry the key of its first row, those
-          // rows are reduced in the wave and applied once (64 LDS atomics on one address are
-          // carried out one after the other); the other lanes go on as usual.
-          const uint64_t m_act = __ballot(act);
-          if (m_act == 0) continue;
-          const int leader = __ffsll((long long)m_act) - 1;
-          const uint64_t flo = __shfl(lo, leader), fhi = KW == 2 ? __shfl(hi, leader) : 0ull;
-          const bool grp = act && lo == flo && hi == fhi;
-          const uint64_t m_grp = __ballot(grp);
-          if (__popcll(m_grp) >= 16 && flo != kPartEmpty) {
-            int e = -1;
-            bool ins = false;
-            if ((int)lane == leader) e = part_find<KW>(keys_lo, keys_hi, S, (int)q.lds_limit, &n_entries, lo, hi, ins);
-            if (ins) atomicAdd(&n_entries, 1);
-            e = __shfl(e, leader);
-            if (e >= 0) {
-              for (int s = 0; s < n_lds_slots; ++s) {
-                const int op = p.slots[s].op;
-                long long x;
-                const bool has = grp && slot_input(p, s, rv, x);
-                if (!has) x = op == kSlotAddF64 ? __double_as_longlong(-0.0) : slot_identity(op);
-                // counters are a population count; the other rules a shuffle reduction
-                if (op == kSlotAddOne || op == kSlotAddValid) x = (long long)__popcll(__ballot(has));
-                else if (op == kSlotMin) x = wave_min_i64(x);
-                else if (op == kSlotMax) x = wave_max_i64(x);
-                else if (op == kSlotAddF64) x = __double_as_longlong(wave_sum_f64(__longlong_as_double(x)));
-                else x = (long long)wave_sum_u64((unsigned long long)x);
-                if (lane == 0) atomic_apply(&state[(size_t)s * S + (uint32_t)e], op, x);
-              }
-              act = act && !grp;
-            }
+        return rv;
+      };
+      auto apply_row = [&](int u, int e) {
+        if (count_only) {
+          atomicAdd((unsigned long long*)&state[(uint32_t)e], 1ull);
+        } else {
+          const RowValsT<NV> rv = row_values(u);
+          for (int s = 0; s < n_lds_slots; ++s) {
+            long long x;
+            if (slot_input(p, s, rv, x)) atomic_apply(&state[(size_t)s * S + (uint32_t)e], p.slots[s].op, x);
           }
         }
+      };
+      int e[kPartAggInFlight];
+      bool pend[kPartAggInFlight];
+      uint32_t n_new = 0;
+#pragma unroll
+      for (int u = 0; u < kPartAggInFlight; ++u) {
+        const uint64_t lo = rec[u][0];
         // (a one-word key of all ones is the table's empty marker: it lives in the HBM table)
-        int e = -1;
+        bool search = in[u] && lo != kPartEmpty;
         bool ins = false;
-        bool search = act && lo != kPartEmpty;
-        // Most rows find their key in one of its two home buckets (read above, compared without
-        // a branch); only the lanes that found nothing (new keys, as a rule) enter the
-        // search-and-insert loop.
-        if (KW == 1 && search && found[u] >= 0) { e = found[u]; search = false; }
-        // A new key, as a rule, finds a free entry in its home buckets: one attempt to claim it,
-        // without the loop (which a whole wave walks through for its few new keys).  The entry
-        // was free when the buckets were read and the ones before it on the path were taken, and
-        // entries only ever fill up: if the claim succeeds, or meets the same key, the entry is
-        // the key's.  Anything else (another key got there first, no free entry) is for the loop.
-        if (KW == 1 && search && vacant[u] >= 0) {
-          const unsigned long long old = atomicCAS(&keys_lo[vacant[u]], kPartEmpty, (unsigned long long)lo);
-          if (old == kPartEmpty) { ins = true; e = vacant[u]; search = false; }
-          else if (old == lo) { e = vacant[u]; search = false; }
-        }
-        if (search) e = part_find<KW>(keys_lo, keys_hi, S, (int)q.lds_limit, &n_entries, lo, hi, ins);
-        const uint64_t m_ins = __ballot(ins);
-        if (m_ins && (int)lane == __ffsll((long long)m_ins) - 1) atomicAdd(&n_entries, __popcll(m_ins));
-        const bool rejected = act && e < 0;
-        const uint64_t m_rej = __ballot(rejected);
-        if (m_rej) {
-          if ((int)lane == __ffsll((long long)m_rej) - 1) atomicAdd(&n_rejects, (uint32_t)__popcll(m_rej));
-          if (rejected) part_hbm_update<KW, NV>(p, lo, hi, rv);
-        }
-        if (act && e >= 0) {
-          if (count_only) {
-            atomicAdd((unsigned long long*)&state[(uint32_t)e], 1ull);
-          } else {
-            for (int s = 0; s < n_lds_slots; ++s) {
-              long long x;
-              if (slot_input(p, s, rv, x)) atomic_apply(&state[(size_t)s * S + (uint32_t)e], p.slots[s].op, x);
-            }
+        e[u] = -1;
+        if (KW == 1) {
+          // Most rows find their key in one of its two home buckets (read above, compared
+          // without a branch).  A new key, as a rule, finds a free entry there: one attempt to
+          // claim it.  The entry was free when the buckets were read and the ones before it
+          // on the path were taken, and entries only ever fill up: if the claim succeeds, or
+          // meets the same key, the entry is the key's.  Anything else (another key got there
+          // first, no free entry) is for the probe loop.
+          if (search && found[u] >= 0) { e[u] = found[u]; search = false; }
+          if (search && vacant[u] >= 0) {
+            const unsigned long long old = atomicCAS(&keys_lo[vacant[u]], kPartEmpty, (unsigned long long)lo);
+            if (old == kPartEmpty) { ins = true; e[u] = vacant[u]; search = false; }
+            else if (old == lo) { e[u] = vacant[u]; search = false; }
           }
+        }
+        pend[u] = search;
+        n_new += (uint32_t)__popcll(__ballot(ins));
+      }
+#pragma unroll
+      for (int u = 0; u < kPartAggInFlight; ++u) {
+        if (!__ballot(pend[u])) continue;
+        bool ins = false;
+        if (pend[u]) e[u] = part_find<KW>(keys_lo, keys_hi, S, (int)q.lds_limit, &n_entries, rec[u][0], KW == 2 ? rec[u][KW - 1] : 0ull, ins);
+        n_new += (uint32_t)__popcll(__ballot(ins));
+      }
+      if (n_new && lane == 0) atomicAdd(&n_entries, (int)n_new);
+      bool any_rejected = false;
+#pragma unroll
+      for (int u = 0; u < kPartAggInFlight; ++u) any_rejected = any_rejected || (in[u] && e[u] < 0);
+      if (__ballot(any_rejected)) {
+#pragma unroll
+        for (int u = 0; u < kPartAggInFlight; ++u) {
+          const bool rejected = in[u] && e[u] < 0;
+          const uint64_t m_rej = __ballot(rejected);
+          if (!m_rej) continue;
+          if ((int)lane == __ffsll((long long)m_rej) - 1) atomicAdd(&n_rejects, (uint32_t)__popcll(m_rej));
+          if (rejected) part_hbm_update<KW, NV>(p, rec[u][0], KW == 2 ? rec[u][KW - 1] : 0ull, row_values(u));
         }
       }
+#pragma unroll
+      for (int u = 0; u < kPartAggInFlight; ++u)
+        if (in[u] && e[u] >= 0) apply_row(u, e[u]);
     }
     __syncthreads();
     const uint32_t n = (uint32_t)n_entries;
