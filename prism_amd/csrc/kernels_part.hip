@@ -857,8 +857,24 @@ __global__ __launch_bounds__(kPartBlock) void k_part_agg(AggParams p, PartParams
         }
       }
 #pragma unroll
-      for (int u = 0; u < kPartAggInFlight; ++u)
-        if (in[u] && e[u] >= 0) apply_row(u, e[u]);
+      for (int u = 0; u < kPartAggInFlight; ++u) {
+        bool todo = in[u] && e[u] >= 0;
+        if (count_only) {
+          // a frequent key: the lanes that hold the entry of the first one are counted and
+          // added once (LDS atomics of a wave on one address are carried out one by one)
+          const uint64_t m_todo = __ballot(todo);
+          if (m_todo) {
+            const int leader = __ffsll((long long)m_todo) - 1;
+            const int e0 = __shfl(e[u], leader);
+            const uint64_t m_same = __ballot(todo && e[u] == e0);
+            if (__popcll(m_same) >= 8) {
+              if ((int)lane == leader) atomicAdd((unsigned long long*)&state[(uint32_t)e0], (unsigned long long)__popcll(m_same));
+              todo = todo && e[u] != e0;
+            }
+          }
+        }
+        if (todo) apply_row(u, e[u]);
+      }
     }
     __syncthreads();
     const uint32_t n = (uint32_t)n_entries;
