@@ -254,37 +254,50 @@ __global__ __launch_bounds__(kP2AggBlock) void k_part2_agg(Part2Params q, uint32
     const uint32_t passes = n > S / 2 ? (n + S / 4 - 1) / (S / 4) : 1u;
     for (uint32_t pass = 0; pass < passes; ++pass) {
     if (pass) __syncthreads();  // the group counters of the pass before have been flushed
-    for (uint32_t i = b0 + tid; i < b1; i += kP2AggBlock) {
-      const uint64_t lo = __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.out_lo + i));
-      const uint64_t hi = __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.out_hi + i));
-      if (passes > 1 && (uint32_t)(hash64(lo * 0xD6E8FEB86659FD93ull + hi) >> 33) % passes != pass) continue;
-      const int r = set_insert(keys_lo, keys_hi, S, lo, hi);
-      if (r < 0) q.flags[0] = 1u;  // (a class far larger than its share: the result is void)
-      if (r != 1) continue;
-      // a pair seen for the first time counts for its group (walking the set afterwards to
-      // count its entries cost three times the instructions of the insertions themselves)
-      const uint32_t not_null = (q.x_null_bit >= 0 && ((lo >> q.x_null_bit) & 1ull)) ? 0u : 1u;
-      uint32_t g = (((uint32_t)hi ^ (uint32_t)(hi >> 32)) * 0x9E3779B1u) >> 23;  // kP2Groups = 2^9
-      bool placed = false;
-      for (uint32_t probes = 0; probes < kP2Groups && !placed; ++probes) {
-        unsigned long long k = __hip_atomic_load(&gkey[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (k == kP2Empty) {
-          const unsigned long long old = atomicCAS(&gkey[g], kP2Empty, (unsigned long long)hi);
-          k = old == kP2Empty ? hi : old;
-        }
-        if (k == hi) {
-          atomicAdd(&gcnt[0][g], 1u);
-          if (not_null) atomicAdd(&gcnt[1][g], 1u);
-          placed = true;
-        } else {
-          g = g + 1 == kP2Groups ? 0u : g + 1;
-        }
+    // the rows of a bucket are few per thread: they are requested four at a time, so that the
+    // thread waits for memory once, not once per row (9.0 -> 7.5 ms at 4e8 rows)
+    constexpr uint32_t kBatch = 4;
+    for (uint32_t i0 = b0 + tid; i0 < b1; i0 += kBatch * kP2AggBlock) {
+      uint64_t blo[kBatch], bhi[kBatch];
+#pragma unroll
+      for (uint32_t j = 0; j < kBatch; ++j) {
+        const uint32_t i = i0 + j * kP2AggBlock, ic = i < b1 ? i : b0;
+        blo[j] = __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.out_lo + ic));
+        bhi[j] = __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.out_hi + ic));
       }
-      if (!placed) {  // more groups in one fine bucket than the counters hold: straight to the outer table
-        const uint64_t e = global_entry_raw(q.dense, q.capacity, q.g_keys, q.overflow, hi);
-        if (e != ~0ull) {
-          atomicAdd((unsigned long long*)&q.g_state[e], 1ull);
-          if (not_null) atomicAdd((unsigned long long*)&q.g_state[(q.capacity + 1) + e], 1ull);
+#pragma unroll
+      for (uint32_t j = 0; j < kBatch; ++j) {
+        if (i0 + j * kP2AggBlock >= b1) continue;
+        const uint64_t lo = blo[j], hi = bhi[j];
+        if (passes > 1 && (uint32_t)(hash64(lo * 0xD6E8FEB86659FD93ull + hi) >> 33) % passes != pass) continue;
+        const int r = set_insert(keys_lo, keys_hi, S, lo, hi);
+        if (r < 0) q.flags[0] = 1u;  // (a class far larger than its share: the result is void)
+        if (r != 1) continue;
+        // a pair seen for the first time counts for its group (walking the set afterwards to
+        // count its entries cost three times the instructions of the insertions themselves)
+        const uint32_t not_null = (q.x_null_bit >= 0 && ((lo >> q.x_null_bit) & 1ull)) ? 0u : 1u;
+        uint32_t g = (((uint32_t)hi ^ (uint32_t)(hi >> 32)) * 0x9E3779B1u) >> 23;  // kP2Groups = 2^9
+        bool placed = false;
+        for (uint32_t probes = 0; probes < kP2Groups && !placed; ++probes) {
+          unsigned long long k = __hip_atomic_load(&gkey[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (k == kP2Empty) {
+            const unsigned long long old = atomicCAS(&gkey[g], kP2Empty, (unsigned long long)hi);
+            k = old == kP2Empty ? hi : old;
+          }
+          if (k == hi) {
+            atomicAdd(&gcnt[0][g], 1u);
+            if (not_null) atomicAdd(&gcnt[1][g], 1u);
+            placed = true;
+          } else {
+            g = g + 1 == kP2Groups ? 0u : g + 1;
+          }
+        }
+        if (!placed) {  // more groups in one fine bucket than the counters hold: straight to the outer table
+          const uint64_t e = global_entry_raw(q.dense, q.capacity, q.g_keys, q.overflow, hi);
+          if (e != ~0ull) {
+            atomicAdd((unsigned long long*)&q.g_state[e], 1ull);
+            if (not_null) atomicAdd((unsigned long long*)&q.g_state[(q.capacity + 1) + e], 1ull);
+          }
         }
       }
     }
