@@ -34,7 +34,6 @@ namespace prism {
 namespace {
 
 constexpr uint32_t kPartBlock = 1024;
-constexpr uint32_t kPartRowsPerTileThread = kTileRows / kPartBlock;  // 4
 constexpr int kPartAggInFlight = 4;
 
 typedef unsigned long long __attribute__((aligned(1))) part_unaligned_u64;
@@ -78,15 +77,35 @@ struct PartTile {
   uint64_t tile;  // the tile's number (selection bitmaps are indexed by it)
 };
 
-__device__ __forceinline__ PartTile part_tile(const AggParams& p, uint64_t tile, uint64_t t1) {
+// A workgroup takes its tiles in rising order: the segment of the last tile is remembered
+// (wave uniform), and the table of segments is only read again when a tile lies beyond it.
+// (Searching the table for every tile is a chain of dependent scalar loads from device
+// memory, microseconds per tile when the memory system is busy.)
+struct PartSegPos {
+  uint32_t seg;
+  uint64_t base, rows, next_base;  // first tile and rows of the segment; first tile of the next one
+};
+
+__device__ __forceinline__ void part_seg_load(const AggParams& p, PartSegPos& c, uint32_t seg) {
+  c.seg = seg;
+  c.base = part_uniform(p.sd.segs[seg].tile_base);
+  c.rows = part_uniform(p.sd.segs[seg].rows);
+  c.next_base = seg + 1 < p.sd.n_segs ? part_uniform(p.sd.segs[seg + 1].tile_base) : ~0ull;
+}
+
+__device__ __forceinline__ void part_seg_init(const AggParams& p, PartSegPos& c, uint64_t tile) {
+  const uint64_t last = p.sd.n_tiles ? p.sd.n_tiles - 1 : 0;
+  part_seg_load(p, c, __builtin_amdgcn_readfirstlane(find_seg(p.sd, tile < last ? tile : last)));
+}
+
+__device__ __forceinline__ PartTile part_tile_next(const AggParams& p, PartSegPos& c, uint64_t tile, uint64_t t1) {
   PartTile r;
-  r.seg = 0; r.n = 0; r.row0 = 0; r.tile = 0;
+  r.seg = c.seg; r.n = 0; r.row0 = 0; r.tile = 0;
   if (tile >= t1) return r;
-  const uint32_t seg = __builtin_amdgcn_readfirstlane(find_seg(p.sd, tile));
-  const uint64_t rows = part_uniform(p.sd.segs[seg].rows), base = part_uniform(p.sd.segs[seg].tile_base);
-  r.seg = seg;
-  r.row0 = (tile - base) * kTileRows;
-  const uint64_t left = rows - r.row0;
+  while (tile >= c.next_base) part_seg_load(p, c, c.seg + 1);
+  r.seg = c.seg;
+  r.row0 = (tile - c.base) * kTileRows;
+  const uint64_t left = c.rows - r.row0;
   r.n = left > kTileRows ? kTileRows : (uint32_t)left;
   r.tile = tile;
   return r;
@@ -168,35 +187,35 @@ struct PartCursor {
   PartBytePtr col[NC];             // values of the key columns, then of the value columns
 };
 
-template <int KW, int NV>
-__device__ __forceinline__ void part_cursor_load(const AggParams& p, PartCursor<KW + NV>& c, uint32_t seg) {
+template <int NK, int NV>
+__device__ __forceinline__ void part_cursor_load(const AggParams& p, PartCursor<NK + NV>& c, uint32_t seg) {
   c.seg = seg;
   c.base = part_uniform(p.sd.segs[seg].tile_base);
   c.rows = part_uniform(p.sd.segs[seg].rows);
   c.next_base = seg + 1 < p.sd.n_segs ? part_uniform(p.sd.segs[seg + 1].tile_base) : ~0ull;
 #pragma unroll
-  for (int k = 0; k < KW; ++k)
-    c.col[k] = k < p.n_keys ? (PartBytePtr)part_uniform((uint64_t)p.cols[(uint64_t)p.keys[k].col * p.sd.n_segs + seg].values) : nullptr;
+  for (int k = 0; k < NK; ++k)
+    c.col[k] = (PartBytePtr)part_uniform((uint64_t)p.cols[(uint64_t)p.keys[k].col * p.sd.n_segs + seg].values);
 #pragma unroll
   for (int v = 0; v < NV; ++v)
-    c.col[KW + v] = (PartBytePtr)part_uniform((uint64_t)p.cols[(uint64_t)p.vals[v].col * p.sd.n_segs + seg].values);
+    c.col[NK + v] = (PartBytePtr)part_uniform((uint64_t)p.cols[(uint64_t)p.vals[v].col * p.sd.n_segs + seg].values);
 }
 
-template <int KW, int NV>
-__device__ __forceinline__ void part_cursor_init(const AggParams& p, PartCursor<KW + NV>& c, uint64_t tile) {
+template <int NK, int NV>
+__device__ __forceinline__ void part_cursor_init(const AggParams& p, PartCursor<NK + NV>& c, uint64_t tile) {
   const uint64_t last = p.sd.n_tiles ? p.sd.n_tiles - 1 : 0;
-  part_cursor_load<KW, NV>(p, c, __builtin_amdgcn_readfirstlane(find_seg(p.sd, tile < last ? tile : last)));
+  part_cursor_load<NK, NV>(p, c, __builtin_amdgcn_readfirstlane(find_seg(p.sd, tile < last ? tile : last)));
 }
 
 // The loads of one scan tile (group G of the super-tile: its rows 4 G .. 4 G + 3).  Tiles are
 // asked for in rising order; a tile at or beyond t1 has no rows (its lanes load row 0 of the
 // cursor's segment and are dropped by `live`).
-template <int KW, int NV, int R, int G>
-__device__ __forceinline__ void part_issue_group(const AggParams& p, PartCursor<KW + NV>& c, uint64_t tile, uint64_t t1, uint32_t tid,
-                                                 unsigned long long (&raw)[KW + NV][R], uint32_t& live) {
+template <int NK, int NV, int R, int G>
+__device__ __forceinline__ void part_issue_group(const AggParams& p, PartCursor<NK + NV>& c, uint64_t tile, uint64_t t1, uint32_t tid,
+                                                 unsigned long long (&raw)[NK + NV][R], uint32_t& live) {
   uint32_t n = 0, row0 = 0;
   if (tile < t1) {
-    while (tile >= c.next_base) part_cursor_load<KW, NV>(p, c, c.seg + 1);
+    while (tile >= c.next_base) part_cursor_load<NK, NV>(p, c, c.seg + 1);
     const uint64_t first = (tile - c.base) * kTileRows, left = c.rows - first;
     row0 = (uint32_t)first;
     n = left > kTileRows ? kTileRows : (uint32_t)left;
@@ -215,8 +234,7 @@ __device__ __forceinline__ void part_issue_group(const AggParams& p, PartCursor<
     live |= (in ? 1u : 0u) << (4 * G + i);
   }
 #pragma unroll
-  for (int k = 0; k < KW; ++k) {
-    if (k >= p.n_keys) break;
+  for (int k = 0; k < NK; ++k) {
     const uint32_t width = (uint32_t)p.keys[k].width;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -227,33 +245,32 @@ __device__ __forceinline__ void part_issue_group(const AggParams& p, PartCursor<
     const uint32_t width = (uint32_t)p.vals[v].width;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      raw[KW + v][4 * G + i] = __builtin_nontemporal_load((const __attribute__((address_space(1))) part_unaligned_u64*)(c.col[KW + v] + rowc[i] * width));
+      raw[NK + v][4 * G + i] = __builtin_nontemporal_load((const __attribute__((address_space(1))) part_unaligned_u64*)(c.col[NK + v] + rowc[i] * width));
   }
 }
 
 // All the loads of the super-tile that starts at `tile`.
-template <int KW, int NV, int R>
-__device__ __forceinline__ void part_issue(const AggParams& p, PartCursor<KW + NV>& c, uint64_t tile, uint64_t t1, uint32_t tid,
-                                           unsigned long long (&raw)[KW + NV][R], uint32_t& live) {
+template <int NK, int NV, int R>
+__device__ __forceinline__ void part_issue(const AggParams& p, PartCursor<NK + NV>& c, uint64_t tile, uint64_t t1, uint32_t tid,
+                                           unsigned long long (&raw)[NK + NV][R], uint32_t& live) {
   live = 0;
-  part_issue_group<KW, NV, R, 0>(p, c, tile, t1, tid, raw, live);
-  if constexpr (R >= 8) part_issue_group<KW, NV, R, 1>(p, c, tile + 1, t1, tid, raw, live);
+  part_issue_group<NK, NV, R, 0>(p, c, tile, t1, tid, raw, live);
+  if constexpr (R >= 8) part_issue_group<NK, NV, R, 1>(p, c, tile + 1, t1, tid, raw, live);
   if constexpr (R >= 16) {
-    part_issue_group<KW, NV, R, 2>(p, c, tile + 2, t1, tid, raw, live);
-    part_issue_group<KW, NV, R, 3>(p, c, tile + 3, t1, tid, raw, live);
+    part_issue_group<NK, NV, R, 2>(p, c, tile + 2, t1, tid, raw, live);
+    part_issue_group<NK, NV, R, 3>(p, c, tile + 3, t1, tid, raw, live);
   }
 }
 
 // The words requested by part_issue as a record: packed key word(s), then the widened values.
-template <int KW, int NV, int R>
-__device__ __forceinline__ void part_finish(const AggParams& p, const unsigned long long (&raw)[KW + NV][R],
+template <int KW, int NK, int NV, int R>
+__device__ __forceinline__ void part_finish(const AggParams& p, const unsigned long long (&raw)[NK + NV][R],
                                             uint64_t (&rec)[KW + NV][R]) {
   uint64_t lo[R], hi[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) { lo[r] = 0; hi[r] = 0; }
 #pragma unroll
-  for (int k = 0; k < KW; ++k) {
-    if (k >= p.n_keys) break;
+  for (int k = 0; k < NK; ++k) {
     const KeySpec& ks = p.keys[k];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -267,7 +284,7 @@ __device__ __forceinline__ void part_finish(const AggParams& p, const unsigned l
   for (int v = 0; v < NV; ++v) {
     const ValSpec& vs = p.vals[v];
 #pragma unroll
-    for (int r = 0; r < R; ++r) rec[KW + v][r] = (uint64_t)part_widen(raw[KW + v][r], vs.width, vs.is_unsigned);
+    for (int r = 0; r < R; ++r) rec[KW + v][r] = (uint64_t)part_widen(raw[NK + v][r], vs.width, vs.is_unsigned);
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -330,7 +347,7 @@ __device__ __forceinline__ void part_block_scan(uint32_t* a, uint32_t n, uint32_
 
 // ---- pass 1a: histogram ------------------------------------------------------------
 
-template <int KW, bool AHEAD>
+template <int KW, int NK>
 __global__ __launch_bounds__(kPartBlock) void k_part_hist(AggParams p, PartParams q) {
   constexpr int R = 8;
   extern __shared__ __align__(16) unsigned long long part_lds[];
@@ -341,29 +358,32 @@ __global__ __launch_bounds__(kPartBlock) void k_part_hist(AggParams p, PartParam
   const uint64_t t0 = (uint64_t)blockIdx.x * q.tiles_per_wg;
   const uint64_t t1 = t0 + q.tiles_per_wg < p.sd.n_tiles ? t0 + q.tiles_per_wg : p.sd.n_tiles;
   const int shift = 64 - q.p_bits;
-  constexpr bool ahead = AHEAD;
+  constexpr bool ahead = NK > 0;
+  constexpr int NA = NK > 0 ? NK : 1;
   PartTile tl[R / 4];
-  unsigned long long raw[KW][R];
+  unsigned long long raw[NA][R];
   uint32_t live_next = 0;
-  PartCursor<KW> cur;
+  PartCursor<NA> cur;
+  PartSegPos pos;
+  if (!ahead && t0 < t1) part_seg_init(p, pos, t0);
   if (ahead && t0 < t1) {
-    part_cursor_init<KW, 0>(p, cur, t0);
-    part_issue<KW, 0, R>(p, cur, t0, t1, tid, raw, live_next);
+    part_cursor_init<NA, 0>(p, cur, t0);
+    part_issue<NA, 0, R>(p, cur, t0, t1, tid, raw, live_next);
   }
   for (uint64_t t = t0; t < t1; t += R / 4) {
     uint64_t lo[R], hi[R];
     uint32_t live;
     if constexpr (ahead) {
       uint64_t rec[KW][R];
-      part_finish<KW, 0, R>(p, raw, rec);
+      part_finish<KW, NA, 0, R>(p, raw, rec);
 #pragma unroll
       for (int r = 0; r < R; ++r) { lo[r] = rec[0][r]; hi[r] = KW == 2 ? rec[KW - 1][r] : 0ull; }
       live = live_next;
-      if (t + R / 4 < t1) part_issue<KW, 0, R>(p, cur, t + R / 4, t1, tid, raw, live_next);
+      if (t + R / 4 < t1) part_issue<NA, 0, R>(p, cur, t + R / 4, t1, tid, raw, live_next);
     } else {
       uint32_t rowc[R];
 #pragma unroll
-      for (int j = 0; j < R / 4; ++j) tl[j] = part_tile(p, t + j, t1);
+      for (int j = 0; j < R / 4; ++j) tl[j] = part_tile_next(p, pos, t + j, t1);
       part_load_keys<KW, R>(p, tl, tid, lo, hi, rowc, live);
     }
 #pragma unroll
@@ -453,17 +473,19 @@ constexpr int part_rows_per_thread() { return W == 1 ? 16 : (W == 2 ? 8 : 4); }
 // and every thread keeps the output cursors of its own buckets in registers, which leaves
 // four barriers per tile.
 //
-// AHEAD (no validity bitmaps to read, at most one key column per key word): the column words
+// NK > 0 (NK key columns, no validity bitmaps to read): the column words
 // of a tile are requested two tiles before they are used and turned into records one tile
 // before, right ahead of the copy-out of the tile in between.  The wait for them is then also
 // the wait for the stores of the copy-out a whole tile earlier (one counter covers loads and
 // stores, in order), which have long completed; waiting right after a copy-out instead was
 // half of this kernel's time.
-template <int KW, int NV, bool VALID, bool AHEAD>
+template <int KW, int NV, bool VALID, int NK>
 __global__ __launch_bounds__(kPartBlock) void k_part_scatter(AggParams p, PartParams q) {
+  constexpr bool AHEAD = NK > 0;
   static_assert(!(AHEAD && VALID), "validity bitmaps are read with the values, not ahead of them");
   constexpr int W = KW + NV + (VALID ? 1 : 0);
-  constexpr int WA = AHEAD ? KW + NV : 1;
+  constexpr int NA = AHEAD ? NK : 1;       // key columns requested ahead
+  constexpr int WA = AHEAD ? NK + NV : 1;  // and all the columns
   constexpr int R = part_rows_per_thread<W>();
   constexpr uint32_t T = (uint32_t)R * kPartBlock;
   extern __shared__ __align__(16) unsigned long long part_lds[];
@@ -490,13 +512,17 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(AggParams p, PartPa
   constexpr uint64_t kStep = R / 4;
   uint64_t rec[W][R];
   uint32_t live = 0, live_next = 0;
-  unsigned long long raw[WA][R];
+  unsigned long long raw[AHEAD ? WA : 1][R];
   PartCursor<WA> cur;
+  PartSegPos pos;
+  if constexpr (!AHEAD) {
+    if (t0 < t1) part_seg_init(p, pos, t0);
+  }
   if constexpr (AHEAD) {
     if (t0 < t1) {
-      part_cursor_init<KW, NV>(p, cur, t0);
-      part_issue<KW, NV, R>(p, cur, t0, t1, tid, raw, live);
-      part_finish<KW, NV, R>(p, raw, rec);
+      part_cursor_init<NA, NV>(p, cur, t0);
+      part_issue<NA, NV, R>(p, cur, t0, t1, tid, raw, live);
+      part_finish<KW, NA, NV, R>(p, raw, rec);
     }
   }
   // `pending`: the next super-tile exists and the loads of its first scan tile are on their way;
@@ -505,7 +531,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(AggParams p, PartPa
   bool pending = false;
   if constexpr (AHEAD) {
     pending = t0 + kStep < t1;
-    if (pending) part_issue_group<KW, NV, R, 0>(p, cur, t0 + kStep, t1, tid, raw, live_next);
+    if (pending) part_issue_group<NA, NV, R, 0>(p, cur, t0 + kStep, t1, tid, raw, live_next);
   }
   uint32_t flip = 0;
   for (uint64_t t = t0; t < t1; t += kStep, flip ^= 1u) {
@@ -516,7 +542,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(AggParams p, PartPa
       uint32_t rowc[R];
       uint64_t hi_unused[R];
 #pragma unroll
-      for (int j = 0; j < R / 4; ++j) tl[j] = part_tile(p, t + j, t1);
+      for (int j = 0; j < R / 4; ++j) tl[j] = part_tile_next(p, pos, t + j, t1);
       part_load_keys<KW, R>(p, tl, tid, rec[0], KW == 2 ? rec[KW - 1] : hi_unused, rowc, live);
       if constexpr (NV > 0) {
         uint64_t val[NV][R], validw[R];
@@ -532,7 +558,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(AggParams p, PartPa
       }
     }
     if constexpr (AHEAD && R >= 8) {
-      if (pending) part_issue_group<KW, NV, R, 1>(p, cur, t + kStep + 1, t1, tid, raw, live_next);
+      if (pending) part_issue_group<NA, NV, R, 1>(p, cur, t + kStep + 1, t1, tid, raw, live_next);
     }
     // rank of every row among the tile's rows of its bucket
     uint32_t slot[R];  // bucket (low 12 bits) and rank inside it (a tile holds at most 2^14 rows)
@@ -544,12 +570,12 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(AggParams p, PartPa
     }
     __syncthreads();
     if constexpr (AHEAD && R >= 16) {
-      if (pending) part_issue_group<KW, NV, R, 2>(p, cur, t + kStep + 2, t1, tid, raw, live_next);
+      if (pending) part_issue_group<NA, NV, R, 2>(p, cur, t + kStep + 2, t1, tid, raw, live_next);
     }
     part_block_scan(start, P, wave_tot);
     __syncthreads();
     if constexpr (AHEAD && R >= 16) {
-      if (pending) part_issue_group<KW, NV, R, 3>(p, cur, t + kStep + 3, t1, tid, raw, live_next);
+      if (pending) part_issue_group<NA, NV, R, 3>(p, cur, t + kStep + 3, t1, tid, raw, live_next);
     }
     // the tile's records, sorted by bucket, in LDS
 #pragma unroll
@@ -574,12 +600,12 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(AggParams p, PartPa
     if constexpr (AHEAD) {
       // the next tile's records, and the first requests for the tile after it
       if (pending) {
-        part_finish<KW, NV, R>(p, raw, rec);
+        part_finish<KW, NA, NV, R>(p, raw, rec);
         live = live_next;
         pending = t + 2 * kStep < t1;
         if (pending) {
           live_next = 0;
-          part_issue_group<KW, NV, R, 0>(p, cur, t + 2 * kStep, t1, tid, raw, live_next);
+          part_issue_group<NA, NV, R, 0>(p, cur, t + 2 * kStep, t1, tid, raw, live_next);
         }
       }
     }
@@ -931,25 +957,36 @@ struct PartKernels {
   int words;
 };
 
+template <int KW, int NV, bool VALID, int NK>
+PartKernels part_kernels_ahead() {
+  constexpr int W = KW + NV + (VALID ? 1 : 0);
+  if constexpr (VALID) return {k_part_hist<KW, NK>, k_part_scatter<KW, NV, true, 0>, k_part_agg<KW, NV, true>, W};
+  else return {k_part_hist<KW, NK>, k_part_scatter<KW, NV, false, NK>, k_part_agg<KW, NV, false>, W};
+}
+
+// nk: key columns the scan kernels request a super-tile ahead (0: none; the kernels exist
+// for one column per key word, and for two columns in one key word).
 template <int KW, int NV, bool VALID>
-PartKernels part_kernels(bool ahead) {
-  if constexpr (!VALID) {
-    if (ahead) return {k_part_hist<KW, true>, k_part_scatter<KW, NV, false, true>, k_part_agg<KW, NV, false>, KW + NV};
+PartKernels part_kernels(int nk) {
+  constexpr int W = KW + NV + (VALID ? 1 : 0);
+  if (nk == KW) return part_kernels_ahead<KW, NV, VALID, KW>();
+  // (two key words and three columns: the histogram kernel runs out of registers)
+  if constexpr (W >= 2 && KW == 1) {
+    if (nk == KW + 1) return part_kernels_ahead<KW, NV, VALID, KW + 1>();
   }
-  if (ahead) return {k_part_hist<KW, true>, k_part_scatter<KW, NV, VALID, false>, k_part_agg<KW, NV, VALID>, KW + NV + (VALID ? 1 : 0)};
-  return {k_part_hist<KW, false>, k_part_scatter<KW, NV, VALID, false>, k_part_agg<KW, NV, VALID>, KW + NV + (VALID ? 1 : 0)};
+  return {k_part_hist<KW, 0>, k_part_scatter<KW, NV, VALID, 0>, k_part_agg<KW, NV, VALID>, W};
 }
 
-// Whether the scan kernels may load the keys a super-tile ahead: at most one key column per
-// key word, none of them nullable.
-bool part_keys_ahead(const AggParams& p) {
-  if (p.n_keys > p.key_words) return false;
+// Key columns the scan kernels may request ahead: all of them, when none is nullable and
+// they are no more than the key words plus one (0 otherwise).
+int part_keys_ahead(const AggParams& p) {
+  if (p.n_keys < p.key_words || p.n_keys > p.key_words + 1) return 0;
   for (int k = 0; k < p.n_keys; ++k)
-    if (p.keys[k].null_bit >= 0) return false;
-  return true;
+    if (p.keys[k].null_bit >= 0) return 0;
+  return p.n_keys;
 }
 
-bool pick_part_kernels(int kw, int nv, bool valid, bool ahead, PartKernels* out) {
+bool pick_part_kernels(int kw, int nv, bool valid, int ahead, PartKernels* out) {
   if (valid && nv == 0) valid = false;
   const int code = kw * 100 + nv * 10 + (valid ? 1 : 0);
   switch (code) {
@@ -977,7 +1014,7 @@ void allow_lds(PartKernel k, size_t bytes) {
 
 int part_record_words(const AggParams& p, bool vals_nullable) {
   PartKernels k;
-  if (!pick_part_kernels(p.key_words, p.keys_only ? 0 : p.n_vals, vals_nullable, false, &k)) return 0;
+  if (!pick_part_kernels(p.key_words, p.keys_only ? 0 : p.n_vals, vals_nullable, 0, &k)) return 0;
   return k.words;
 }
 
