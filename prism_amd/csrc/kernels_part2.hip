@@ -249,57 +249,66 @@ __global__ __launch_bounds__(kP2AggBlock) void k_part2_agg(Part2Params q, uint32
     if (b1 == b0) continue;
     // A fine bucket of more rows than the set is sure to take (the coarse bucket of a very
     // frequent group) is worked off in several passes over its rows, each taking the pairs of
-    // one residue class of another hash: the classes are disjoint, so their counts add up.
+    // one residue class of another hash: the classes are disjoint, so their counts add up (the
+    // group counters go on counting from pass to pass; only the set is emptied in between).
     const uint32_t n = b1 - b0;
-    const uint32_t passes = n > S / 2 ? (n + S / 4 - 1) / (S / 4) : 1u;
-    for (uint32_t pass = 0; pass < passes; ++pass) {
-    if (pass) __syncthreads();  // the group counters of the pass before have been flushed
-    // the rows of a bucket are few per thread: they are requested four at a time, so that the
-    // thread waits for memory once, not once per row (9.0 -> 7.5 ms at 4e8 rows)
+    const uint32_t per_pass = S / 5 * 2;
+    const uint32_t passes = n > S / 2 ? (n + per_pass - 1) / per_pass : 1u;
+    auto take = [&](uint64_t lo, uint64_t hi, uint32_t pass) {
+      if (passes > 1 && (uint32_t)(hash64(lo * 0xD6E8FEB86659FD93ull + hi) >> 33) % passes != pass) return;
+      const int r = set_insert(keys_lo, keys_hi, S, lo, hi);
+      if (r < 0) q.flags[0] = 1u;  // (a class far larger than its share: the result is void)
+      if (r != 1) return;
+      // a pair seen for the first time counts for its group (walking the set afterwards to
+      // count its entries cost three times the instructions of the insertions themselves)
+      const uint32_t not_null = (q.x_null_bit >= 0 && ((lo >> q.x_null_bit) & 1ull)) ? 0u : 1u;
+      uint32_t g = (((uint32_t)hi ^ (uint32_t)(hi >> 32)) * 0x9E3779B1u) >> 23;  // kP2Groups = 2^9
+      bool placed = false;
+      for (uint32_t probes = 0; probes < kP2Groups && !placed; ++probes) {
+        unsigned long long k = __hip_atomic_load(&gkey[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (k == kP2Empty) {
+          const unsigned long long old = atomicCAS(&gkey[g], kP2Empty, (unsigned long long)hi);
+          k = old == kP2Empty ? hi : old;
+        }
+        if (k == hi) {
+          atomicAdd(&gcnt[0][g], 1u);
+          if (not_null) atomicAdd(&gcnt[1][g], 1u);
+          placed = true;
+        } else {
+          g = g + 1 == kP2Groups ? 0u : g + 1;
+        }
+      }
+      if (!placed) {  // more groups in one fine bucket than the counters hold: straight to the outer table
+        const uint64_t e = global_entry_raw(q.dense, q.capacity, q.g_keys, q.overflow, hi);
+        if (e != ~0ull) {
+          atomicAdd((unsigned long long*)&q.g_state[e], 1ull);
+          if (not_null) atomicAdd((unsigned long long*)&q.g_state[(q.capacity + 1) + e], 1ull);
+        }
+      }
+    };
+    // The rows of a bucket are few per thread.  The first four are requested together, so that
+    // the thread waits for memory once, not once per row (9.0 -> 7.5 ms at 4e8 rows), and stay
+    // in registers for all the passes.
     constexpr uint32_t kBatch = 4;
-    for (uint32_t i0 = b0 + tid; i0 < b1; i0 += kBatch * kP2AggBlock) {
-      uint64_t blo[kBatch], bhi[kBatch];
+    uint64_t blo[kBatch], bhi[kBatch];
 #pragma unroll
-      for (uint32_t j = 0; j < kBatch; ++j) {
-        const uint32_t i = i0 + j * kP2AggBlock, ic = i < b1 ? i : b0;
-        blo[j] = __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.out_lo + ic));
-        bhi[j] = __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.out_hi + ic));
+    for (uint32_t j = 0; j < kBatch; ++j) {
+      const uint32_t i = b0 + tid + j * kP2AggBlock, ic = i < b1 ? i : b0;
+      blo[j] = __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.out_lo + ic));
+      bhi[j] = __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.out_hi + ic));
+    }
+    for (uint32_t pass = 0; pass < passes; ++pass) {
+      if (pass) {
+        __syncthreads();
+        for (uint32_t i = tid; i < S; i += kP2AggBlock) { keys_lo[i] = kP2Empty; keys_hi[i] = kP2Empty; }
+        __syncthreads();
       }
 #pragma unroll
-      for (uint32_t j = 0; j < kBatch; ++j) {
-        if (i0 + j * kP2AggBlock >= b1) continue;
-        const uint64_t lo = blo[j], hi = bhi[j];
-        if (passes > 1 && (uint32_t)(hash64(lo * 0xD6E8FEB86659FD93ull + hi) >> 33) % passes != pass) continue;
-        const int r = set_insert(keys_lo, keys_hi, S, lo, hi);
-        if (r < 0) q.flags[0] = 1u;  // (a class far larger than its share: the result is void)
-        if (r != 1) continue;
-        // a pair seen for the first time counts for its group (walking the set afterwards to
-        // count its entries cost three times the instructions of the insertions themselves)
-        const uint32_t not_null = (q.x_null_bit >= 0 && ((lo >> q.x_null_bit) & 1ull)) ? 0u : 1u;
-        uint32_t g = (((uint32_t)hi ^ (uint32_t)(hi >> 32)) * 0x9E3779B1u) >> 23;  // kP2Groups = 2^9
-        bool placed = false;
-        for (uint32_t probes = 0; probes < kP2Groups && !placed; ++probes) {
-          unsigned long long k = __hip_atomic_load(&gkey[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if (k == kP2Empty) {
-            const unsigned long long old = atomicCAS(&gkey[g], kP2Empty, (unsigned long long)hi);
-            k = old == kP2Empty ? hi : old;
-          }
-          if (k == hi) {
-            atomicAdd(&gcnt[0][g], 1u);
-            if (not_null) atomicAdd(&gcnt[1][g], 1u);
-            placed = true;
-          } else {
-            g = g + 1 == kP2Groups ? 0u : g + 1;
-          }
-        }
-        if (!placed) {  // more groups in one fine bucket than the counters hold: straight to the outer table
-          const uint64_t e = global_entry_raw(q.dense, q.capacity, q.g_keys, q.overflow, hi);
-          if (e != ~0ull) {
-            atomicAdd((unsigned long long*)&q.g_state[e], 1ull);
-            if (not_null) atomicAdd((unsigned long long*)&q.g_state[(q.capacity + 1) + e], 1ull);
-          }
-        }
-      }
+      for (uint32_t j = 0; j < kBatch; ++j)
+        if (b0 + tid + j * kP2AggBlock < b1) take(blo[j], bhi[j], pass);
+      // (what lies beyond four rows a thread is fetched as it is needed, once per pass)
+      for (uint32_t i = b0 + tid + kBatch * kP2AggBlock; i < b1; i += kP2AggBlock)
+        take(__builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.out_lo + i)), __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.out_hi + i)), pass);
     }
     __syncthreads();
     // the set is emptied for the next bucket, the groups' counts go to the outer table
@@ -316,7 +325,6 @@ __global__ __launch_bounds__(kP2AggBlock) void k_part2_agg(Part2Params q, uint32
       gcnt[0][i] = 0;
       gcnt[1][i] = 0;
     }
-    }  // passes
   }
 }
 
