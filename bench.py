@@ -100,6 +100,8 @@ def main() -> int:
                          "stream: host Arrow batches of 8192 rows pushed through prism_gpu_push_batch on one thread "
                          "per partition, timed from the first push to the merged result (the end-to-end figure; "
                          "bounded by PCIe, reported separately, C2 only)")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="prism_gpu_set_option on the context (for A/B runs of a kernel path)")
     ap.add_argument("--feed-threads", type=int, default=16, help="partitions (= feeding threads) of --feed stream")
     args = ap.parse_args()
     if args.feed == "stream":
@@ -143,6 +145,9 @@ def main() -> int:
     first_row = rows * rank
 
     ctx = Context(local_rank)
+    for opt in args.option:
+        name, _, value = opt.partition("=")
+        ctx.set_option(name, int(value))
     t0 = time.time()
     table = workloads.build_gpu_table(ctx, wl, first_row, rows, total_rows, parts)
     log(f"[rank {rank}] generated {rows:,} rows in {parts} partitions in {time.time() - t0:.1f}s")

@@ -202,6 +202,8 @@ void prism_gpu_ctx_free(prism_gpu_ctx* ctx);
  *                    before it is aggregated (default 4194304)
  *   "part_force"     1: partition whenever the plan's shape allows it, without waiting for
  *                    the streaming kernel to report that its rows scatter (default 0)
+ *   "part2_compact"  0: COUNT(DISTINCT) partitioned twice always keeps two-word records at the
+ *                    second level; 1 (default): one-word records when the pairs allow it
  *   "contains_windows" 0: LIKE '%needle%' over a column without a dictionary always uses the
  *                    byte-wise prefilter; 1 (default): needles of 4 bytes and more are found by
  *                    comparing 4-byte windows with the needle's leading words

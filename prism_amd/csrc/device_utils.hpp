@@ -60,6 +60,38 @@ __device__ __forceinline__ uint32_t bucket_hash32(uint64_t k) {
 // Hash of the high word of a two-word key (the group of a COUNT(DISTINCT) pair).
 __device__ __forceinline__ uint64_t part_hash_hi(uint64_t hi) { return hash64(hi ^ 0xA0761D6478BD642Full); }
 
+// A mixing bijection of [0, 2^bits), bits < 64: multiplications by odd constants and shifts
+// by at least half the width, all invertible modulo 2^bits.  Buckets taken from its top bits
+// are as even as a hash's, and -- unlike with a hash -- a value's bucket and the remaining
+// low bits together still identify the value, so a record that lies in a bucket need not
+// repeat the bits the bucket stands for.
+constexpr uint64_t kBijMul1 = 0x9E3779B97F4A7C15ull, kBijMul2 = 0xD6E8FEB86659FD93ull;
+constexpr uint64_t odd_inverse64(uint64_t a) {
+  uint64_t x = a;  // correct to 3 bits; every step doubles that
+  for (int i = 0; i < 5; ++i) x *= 2 - a * x;
+  return x;
+}
+__host__ __device__ __forceinline__ uint64_t bij_mix(uint64_t v, int bits) {
+  if (bits <= 0) return 0;
+  const uint64_t mask = (1ull << bits) - 1ull;
+  const int s = (bits + 1) / 2;
+  v = (v * kBijMul1) & mask;
+  v ^= v >> s;
+  v = (v * kBijMul2) & mask;
+  v ^= v >> s;
+  return v;
+}
+__host__ __device__ __forceinline__ uint64_t bij_unmix(uint64_t v, int bits) {
+  if (bits <= 0) return 0;
+  const uint64_t mask = (1ull << bits) - 1ull;
+  const int s = (bits + 1) / 2;
+  v ^= v >> s;
+  v = (v * odd_inverse64(kBijMul2)) & mask;
+  v ^= v >> s;
+  v = (v * odd_inverse64(kBijMul1)) & mask;
+  return v;
+}
+
 // One fixed-width value widened to int64.
 __device__ __forceinline__ long long load_value(const void* base, int width, int is_unsigned, uint64_t row) {
   if (width == 8) return ((const long long*)base)[row];

@@ -1328,15 +1328,43 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, const AggParams& ap, uint64_t sele
   // coarse buckets of about half a million rows, fine buckets of about a quarter of the LDS set
   int p1 = 6;
   while (p1 < 11 && (selected >> p1) > (1ull << 19)) ++p1;
-  const uint32_t P1 = 1u << p1;
-  if (P1 > part_max_buckets(words)) return false;
-  const uint32_t set_entries = part2_lds_entries();
+  if ((1u << p1) > part_max_buckets(words)) return false;
   // (a fine bucket of up to half the set's entries is taken in one go; larger ones, in the
   // coarse buckets of very frequent groups, in several passes)
-  const uint64_t fine_rows = set_entries * 3 / 8;
-  int p2 = 0;
-  while (p2 < 10 && (selected >> (p1 + p2)) > fine_rows) ++p2;
-  if ((selected >> (p1 + p2)) > fine_rows) return false;  // more rows than 2^21 fine buckets take
+  auto fine_bits = [&](int coarse_bits, uint32_t entries) {
+    const uint64_t fine_rows = (uint64_t)entries * 3 / 8;
+    int b = 0;
+    while (b < 10 && (selected >> (coarse_bits + b)) > fine_rows) ++b;
+    return (selected >> (coarse_bits + b)) > fine_rows ? -1 : b;
+  };
+  // One-word records at the second level: when both bucket numbers are taken from bijections
+  // of the words, a record in its fine bucket needs only the bits the bucket does not imply;
+  // they must fit 63 bits, the groups of a coarse bucket the LDS counters (9 bits), and x must
+  // have no NULL bit (it would be mixed away).  Half the bytes written and read, and an LDS
+  // set of twice the entries.  Buckets a little finer than the rows alone ask for are taken
+  // when that is what makes the records fit, as long as a fine bucket keeps 128 rows.
+  const int lo_bits = layout.word_bits[0], hi_bits = layout.word_bits[1];
+  bool compact = ctx->part2_compact.load(std::memory_order_relaxed) != 0 && layout.fields[0].null_bit < 0 && lo_bits <= 63;
+  int p2 = -1;
+  if (compact) {
+    int c1 = p1, c2 = fine_bits(c1, part2_lds_entries(true));
+    int most = 0;  // log2 of the coarse buckets the first level can take
+    while ((2u << most) <= part_max_buckets(words)) ++most;
+    const int top1 = std::min<int>({11, hi_bits, most});
+    auto excess = [&]() { return lo_bits + hi_bits - 63 - c1 - c2; };
+    while (c2 >= 0 && c1 < top1 && (excess() > 0 || hi_bits - c1 > 9)) {
+      ++c1;
+      c2 = fine_bits(c1, part2_lds_entries(true));
+    }
+    if (c2 >= 0 && excess() > 0) c2 += excess();
+    compact = c2 >= 0 && c2 <= 10 && c2 <= lo_bits && c1 <= hi_bits && hi_bits - c1 <= 9 && excess() <= 0 &&
+              ((c1 == p1 && c2 == fine_bits(c1, part2_lds_entries(true))) || (selected >> (c1 + c2)) >= 128);
+    if (compact) { p1 = c1; p2 = c2; }
+  }
+  if (!compact) p2 = fine_bits(p1, part2_lds_entries(false));
+  if (p2 < 0) return false;  // more rows than 2^21 fine buckets take
+  const uint32_t P1 = 1u << p1;
+  const uint32_t set_entries = part2_lds_entries(compact);
 
   PartParams q1;
   std::memset(&q1, 0, sizeof(q1));
@@ -1349,11 +1377,12 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, const AggParams& ap, uint64_t sele
   q1.lds_limit = q1.lds_entries / 4 * 3;
   q1.rec_capacity = selected;
   q1.by_hi = 1;
+  q1.hi_bits = compact ? hi_bits : 0;
   Scratch rec[2], rec2[2], d_hist(ctx, (size_t)q1.n_wg * P1 * 4), d_totals(ctx, (size_t)P1 * 4), d_base(ctx, (size_t)(P1 + 1) * 8),
       d_items(ctx, (size_t)q1.max_items * sizeof(PartItem)), d_small(ctx, 256);
   for (int w = 0; w < 2; ++w) {
     rec[w] = Scratch(ctx, selected * 8 + 256);
-    rec2[w] = Scratch(ctx, selected * 8 + 256);
+    if (w == 0 || !compact) rec2[w] = Scratch(ctx, selected * 8 + 256);
     q1.rec[w] = rec[w].as<uint64_t>();
   }
   q1.hist = d_hist.as<uint32_t>();
@@ -1378,7 +1407,10 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, const AggParams& ap, uint64_t sele
   q2.in_lo = rec[0].as<uint64_t>();
   q2.in_hi = rec[1].as<uint64_t>();
   q2.out_lo = rec2[0].as<uint64_t>();
-  q2.out_hi = rec2[1].as<uint64_t>();
+  q2.out_hi = compact ? nullptr : rec2[1].as<uint64_t>();
+  q2.compact = compact ? 1 : 0;
+  q2.lo_bits = lo_bits;
+  q2.hi_bits = hi_bits;
   q2.coarse_base = q1.bucket_base;
   q2.p1_bits = (uint32_t)p1;
   q2.p2_bits = (uint32_t)p2;

@@ -250,6 +250,7 @@ struct PartParams {
   uint32_t* flags;         // [0]: the list overflowed, [1]: rows / groups sent to the HBM table
   uint32_t* queue;         // next item of the aggregation pass (starts at 0)
   int32_t by_hi;           // two-word keys: the bucket follows from the high word alone
+  int32_t hi_bits;         // by_hi: > 0 = the bucket is the top p_bits of bij_mix(high word, hi_bits), 0 = of a hash
 };
 // 8-byte words of a row's record for this plan shape (key words + value columns + one word
 // of validity bits when a value column has NULLs); 0: the shape has no partitioned kernels.
@@ -288,8 +289,14 @@ struct Part2Params {
   uint32_t* overflow;
   uint32_t* queue;              // next fine bucket of the last pass (zero on entry)
   uint32_t* flags;              // [0]: a fine bucket did not fit LDS (the result is void)
+  // compact: both bucket numbers are top bits of bijections (coarse: of the high word's
+  // hi_bits bits, sub: of the low word's lo_bits bits), and a record sorted into its fine
+  // bucket is ONE word, the bits the bucket does not imply: (high rest << (lo_bits - p2_bits))
+  // | low rest, below 2^63.  out_hi is unused then.  Needs p1_bits <= hi_bits <= p1_bits + 9,
+  // p2_bits <= lo_bits, lo_bits - p2_bits + hi_bits - p1_bits <= 63 and no NULL bit in x.
+  int32_t compact, lo_bits, hi_bits;
 };
-uint32_t part2_lds_entries();
+uint32_t part2_lds_entries(bool compact);
 void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q);
 
 // Second level of COUNT(DISTINCT x) GROUP BY k: every occupied entry of the

@@ -61,11 +61,12 @@ __device__ __forceinline__ uint64_t part_hash(uint64_t lo, uint64_t hi) {
 // The hash a row's bucket is taken from (its top bits): for one-word keys 32 bits mixed with
 // three 32-bit multiplies (the two 64-bit multiplies of hash64 are eight), for two-word keys
 // the whole pair, or (pairs of a COUNT(DISTINCT) that is partitioned twice) the high word
-// alone, so that a group's pairs share a bucket.
+// alone, so that a group's pairs share a bucket -- hashed, or mixed by a bijection of its
+// hi_bits bits when the second level stores only what its buckets do not imply.
 template <int KW>
 __device__ __forceinline__ uint64_t part_bucket_hash(const PartParams& q, uint64_t lo, uint64_t hi) {
   if (KW == 1) return (uint64_t)bucket_hash32(lo) << 32;
-  if (q.by_hi) return part_hash_hi(hi);
+  if (q.by_hi) return q.hi_bits > 0 ? bij_mix(hi, q.hi_bits) << (64 - q.hi_bits) : part_hash_hi(hi);
   return part_hash<KW>(lo, hi);
 }
 
@@ -115,9 +116,12 @@ __device__ __forceinline__ PartTile part_tile_next(const AggParams& p, PartSegPo
 // tid + 1024, ... of each).  Every lane loads, rows that do not exist or are not selected
 // load a row that does and are dropped by `live` (bit r).  All loads of one key column are
 // issued before the first is used.
+// skip: key columns (bit k) that are not loaded; their bits of the packed key stay zero (the
+// histogram of a partition by the high word has no use for the columns of the low word).
 template <int KW, int R>
 __device__ __forceinline__ void part_load_keys(const AggParams& p, const PartTile (&tl)[R / 4], uint32_t tid,
-                                               uint64_t (&lo)[R], uint64_t (&hi)[R], uint32_t (&rowc)[R], uint32_t& live) {
+                                               uint64_t (&lo)[R], uint64_t (&hi)[R], uint32_t (&rowc)[R], uint32_t& live,
+                                               uint32_t skip = 0) {
   live = 0;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -138,6 +142,7 @@ __device__ __forceinline__ void part_load_keys(const AggParams& p, const PartTil
   // 1024-thread workgroup has)
   constexpr int B = R < 8 ? R : 8;
   for (int k = 0; k < p.n_keys; ++k) {
+    if ((skip >> k) & 1u) continue;
     const KeySpec& ks = p.keys[k];
 #pragma unroll
     for (int r0 = 0; r0 < R; r0 += B) {
@@ -212,7 +217,7 @@ __device__ __forceinline__ void part_cursor_init(const AggParams& p, PartCursor<
 // cursor's segment and are dropped by `live`).
 template <int NK, int NV, int R, int G>
 __device__ __forceinline__ void part_issue_group(const AggParams& p, PartCursor<NK + NV>& c, uint64_t tile, uint64_t t1, uint32_t tid,
-                                                 unsigned long long (&raw)[NK + NV][R], uint32_t& live) {
+                                                 unsigned long long (&raw)[NK + NV][R], uint32_t& live, uint32_t skip = 0) {
   uint32_t n = 0, row0 = 0;
   if (tile < t1) {
     while (tile >= c.next_base) part_cursor_load<NK, NV>(p, c, c.seg + 1);
@@ -235,6 +240,7 @@ __device__ __forceinline__ void part_issue_group(const AggParams& p, PartCursor<
   }
 #pragma unroll
   for (int k = 0; k < NK; ++k) {
+    if ((skip >> k) & 1u) continue;  // (wave uniform; the words keep what they held)
     const uint32_t width = (uint32_t)p.keys[k].width;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -252,13 +258,13 @@ __device__ __forceinline__ void part_issue_group(const AggParams& p, PartCursor<
 // All the loads of the super-tile that starts at `tile`.
 template <int NK, int NV, int R>
 __device__ __forceinline__ void part_issue(const AggParams& p, PartCursor<NK + NV>& c, uint64_t tile, uint64_t t1, uint32_t tid,
-                                           unsigned long long (&raw)[NK + NV][R], uint32_t& live) {
+                                           unsigned long long (&raw)[NK + NV][R], uint32_t& live, uint32_t skip = 0) {
   live = 0;
-  part_issue_group<NK, NV, R, 0>(p, c, tile, t1, tid, raw, live);
-  if constexpr (R >= 8) part_issue_group<NK, NV, R, 1>(p, c, tile + 1, t1, tid, raw, live);
+  part_issue_group<NK, NV, R, 0>(p, c, tile, t1, tid, raw, live, skip);
+  if constexpr (R >= 8) part_issue_group<NK, NV, R, 1>(p, c, tile + 1, t1, tid, raw, live, skip);
   if constexpr (R >= 16) {
-    part_issue_group<NK, NV, R, 2>(p, c, tile + 2, t1, tid, raw, live);
-    part_issue_group<NK, NV, R, 3>(p, c, tile + 3, t1, tid, raw, live);
+    part_issue_group<NK, NV, R, 2>(p, c, tile + 2, t1, tid, raw, live, skip);
+    part_issue_group<NK, NV, R, 3>(p, c, tile + 3, t1, tid, raw, live, skip);
   }
 }
 
@@ -362,13 +368,22 @@ __global__ __launch_bounds__(kPartBlock) void k_part_hist(AggParams p, PartParam
   constexpr int NA = NK > 0 ? NK : 1;
   PartTile tl[R / 4];
   unsigned long long raw[NA][R];
+  // a partition by the high word: the columns of the low word are not read
+  uint32_t skip = 0;
+  if (KW == 2 && q.by_hi)
+    for (int k = 0; k < p.n_keys; ++k) skip |= (p.keys[k].word ? 0u : 1u) << k;
+  skip = __builtin_amdgcn_readfirstlane(skip);
+#pragma unroll
+  for (int k = 0; k < NA; ++k)
+#pragma unroll
+    for (int r = 0; r < R; ++r) raw[k][r] = 0;
   uint32_t live_next = 0;
   PartCursor<NA> cur;
   PartSegPos pos;
   if (!ahead && t0 < t1) part_seg_init(p, pos, t0);
   if (ahead && t0 < t1) {
     part_cursor_init<NA, 0>(p, cur, t0);
-    part_issue<NA, 0, R>(p, cur, t0, t1, tid, raw, live_next);
+    part_issue<NA, 0, R>(p, cur, t0, t1, tid, raw, live_next, skip);
   }
   for (uint64_t t = t0; t < t1; t += R / 4) {
     uint64_t lo[R], hi[R];
@@ -379,12 +394,12 @@ __global__ __launch_bounds__(kPartBlock) void k_part_hist(AggParams p, PartParam
 #pragma unroll
       for (int r = 0; r < R; ++r) { lo[r] = rec[0][r]; hi[r] = KW == 2 ? rec[KW - 1][r] : 0ull; }
       live = live_next;
-      if (t + R / 4 < t1) part_issue<NA, 0, R>(p, cur, t + R / 4, t1, tid, raw, live_next);
+      if (t + R / 4 < t1) part_issue<NA, 0, R>(p, cur, t + R / 4, t1, tid, raw, live_next, skip);
     } else {
       uint32_t rowc[R];
 #pragma unroll
       for (int j = 0; j < R / 4; ++j) tl[j] = part_tile_next(p, pos, t + j, t1);
-      part_load_keys<KW, R>(p, tl, tid, lo, hi, rowc, live);
+      part_load_keys<KW, R>(p, tl, tid, lo, hi, rowc, live, skip);
     }
 #pragma unroll
     for (int r = 0; r < R; ++r)

@@ -41,14 +41,31 @@ constexpr size_t kP2LdsBytes = 160 * 1024 - 1024;
 typedef const __attribute__((address_space(1))) unsigned long long* P2WordPtr;
 
 __device__ __forceinline__ uint32_t coarse_of(const Part2Params& q, uint64_t hi) {
+  if (q.compact) return (uint32_t)(bij_mix(hi, q.hi_bits) >> (q.hi_bits - (int)q.p1_bits));
   return q.p1_bits ? (uint32_t)(part_hash_hi(hi) >> (64 - q.p1_bits)) : 0u;
 }
 __device__ __forceinline__ uint32_t span_of(const Part2Params& q) {
   const uint32_t s = kP2Counters >> q.p2_bits;
   return s < kP2MaxSpan ? s : kP2MaxSpan;
 }
+// Compact form: the low word mixed by a bijection and then XORed with a hash of the high
+// word -- still a bijection of the low word for any one high word, which is all a record
+// needs, and a value of x that is frequent in many groups lands in a different sub-bucket
+// for each of them.  (Without the XOR the rows of the most frequent x met in ONE sub-bucket
+// of every coarse bucket, six times the average size, and the workgroups that those fell to
+// made the last pass six times as long.)
+__device__ __forceinline__ uint64_t mixed_lo(const Part2Params& q, uint64_t lo, uint64_t hi) {
+  return bij_mix(lo, q.lo_bits) ^ (hash64(hi ^ 0x2545F4914F6CDD1Dull) & ((1ull << q.lo_bits) - 1ull));
+}
 __device__ __forceinline__ uint32_t sub_of(const Part2Params& q, uint64_t lo, uint64_t hi) {
+  if (q.compact) return (uint32_t)(mixed_lo(q, lo, hi) >> (q.lo_bits - (int)q.p2_bits));
   return q.p2_bits ? (uint32_t)(hash64(lo ^ hash64(hi)) >> (64 - q.p2_bits)) : 0u;
+}
+// The one-word record of a pair inside its fine bucket (compact form): what is left of the
+// two mixed words below the bits that chose the buckets.
+__device__ __forceinline__ uint64_t compact_record(const Part2Params& q, uint64_t lo, uint64_t hi) {
+  const int lo_rest = q.lo_bits - (int)q.p2_bits, hi_rest = q.hi_bits - (int)q.p1_bits;
+  return ((bij_mix(hi, q.hi_bits) & ((1ull << hi_rest) - 1ull)) << lo_rest) | (mixed_lo(q, lo, hi) & ((1ull << lo_rest) - 1ull));
 }
 
 __global__ __launch_bounds__(kP2Block) void k_part2_hist(Part2Params q) {
@@ -167,8 +184,12 @@ __global__ __launch_bounds__(kP2Block) void k_part2_scatter(Part2Params q) {
         // beyond the coarse buckets the counters cover: a place of its own
         const uint32_t g = atomicAdd(&q.fine_cursor[((uint64_t)c << q.p2_bits) | s], 1u);
         if (g < q.n_rows) {
-          q.out_lo[g] = lo[r];
-          q.out_hi[g] = hi[r];
+          if (q.compact) {
+            q.out_lo[g] = compact_record(q, lo[r], hi[r]);
+          } else {
+            q.out_lo[g] = lo[r];
+            q.out_hi[g] = hi[r];
+          }
         }
       }
     }
@@ -190,13 +211,23 @@ __global__ __launch_bounds__(kP2Block) void k_part2_scatter(Part2Params q) {
     __syncthreads();
     // out: neighbouring lanes hold neighbouring records of one fine bucket
     const uint32_t n_live = lstart[kP2Counters];
-    for (uint32_t i = threadIdx.x; i < n_live; i += kP2Block) {
-      const unsigned long long w0 = s_lo[i], w1 = s_hi[i];
-      const uint32_t li = (coarse_of(q, w1) - c0) * n_sub + sub_of(q, w0, w1);
-      const uint32_t g = base[li] + (i - lstart[li]);
-      if (g < q.n_rows) {
-        q.out_lo[g] = w0;
-        q.out_hi[g] = w1;
+    if (q.compact) {
+      const int lo_rest = q.lo_bits - (int)q.p2_bits, hi_rest = q.hi_bits - (int)q.p1_bits;
+      for (uint32_t i = threadIdx.x; i < n_live; i += kP2Block) {
+        const uint64_t tl = mixed_lo(q, s_lo[i], s_hi[i]), th = bij_mix(s_hi[i], q.hi_bits);
+        const uint32_t li = ((uint32_t)(th >> hi_rest) - c0) * n_sub + (uint32_t)(tl >> lo_rest);
+        const uint32_t g = base[li] + (i - lstart[li]);
+        if (g < q.n_rows) q.out_lo[g] = ((th & ((1ull << hi_rest) - 1ull)) << lo_rest) | (tl & ((1ull << lo_rest) - 1ull));
+      }
+    } else {
+      for (uint32_t i = threadIdx.x; i < n_live; i += kP2Block) {
+        const unsigned long long w0 = s_lo[i], w1 = s_hi[i];
+        const uint32_t li = (coarse_of(q, w1) - c0) * n_sub + sub_of(q, w0, w1);
+        const uint32_t g = base[li] + (i - lstart[li]);
+        if (g < q.n_rows) {
+          q.out_lo[g] = w0;
+          q.out_hi[g] = w1;
+        }
       }
     }
     __syncthreads();
@@ -328,11 +359,91 @@ __global__ __launch_bounds__(kP2AggBlock) void k_part2_agg(Part2Params q, uint32
   }
 }
 
+// The last pass over one-word records (compact form).  A fine bucket's records share the
+// coarse bucket, so the high rest of a record (at most 9 bits) numbers the group inside it:
+// the group counters are indexed directly, and the set is a plain one-word table (one CAS to
+// claim an entry, nothing to publish).  The groups' keys are rebuilt from (coarse bucket, high
+// rest) through the inverse of the bijection when the counts leave for the outer table.
+__global__ __launch_bounds__(kP2AggBlock) void k_part2_agg_compact(Part2Params q, uint32_t n_fine) {
+  extern __shared__ __align__(16) unsigned long long p2_lds[];
+  __shared__ uint32_t gcnt[kP2Groups];
+  const uint32_t S = q.lds_entries, tid = threadIdx.x;
+  const int lo_rest = q.lo_bits - (int)q.p2_bits, hi_rest = q.hi_bits - (int)q.p1_bits;
+  const uint32_t n_groups = 1u << hi_rest;  // <= kP2Groups
+  unsigned long long* keys = p2_lds;
+  for (uint32_t i = tid; i < kP2Groups; i += kP2AggBlock) gcnt[i] = 0;
+  for (uint32_t f = blockIdx.x; f < n_fine; f += gridDim.x) {
+    __syncthreads();
+    const uint32_t b0 = q.fine_base[f], b1 = q.fine_base[f + 1];
+    if (b1 == b0) continue;
+    // (a fine bucket of more rows than the set is sure to take goes in several passes over
+    // its rows, each taking one residue class of another hash of the record)
+    const uint32_t n = b1 - b0;
+    const uint32_t per_pass = S / 5 * 2;
+    const uint32_t passes = n > S / 2 ? (n + per_pass - 1) / per_pass : 1u;
+    // the part of the set this bucket uses (cleared before every pass): at least twice the
+    // rows a pass may bring, so that small buckets do not pay for clearing the whole table
+    const uint32_t want = passes > 1 ? S : n * 5 / 2 + 64;
+    const uint32_t Sb = want < S ? want : S;
+    auto take = [&](uint64_t rec, uint32_t pass) {
+      uint32_t h = ((uint32_t)rec ^ (uint32_t)(rec >> 32) * 0x85EBCA6Bu);
+      h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+      if (passes > 1 && (uint32_t)(hash64(rec * 0xD6E8FEB86659FD93ull) >> 33) % passes != pass) return;
+      uint32_t idx = __umulhi(h, Sb);
+      for (uint32_t probes = 0; probes < Sb; ++probes) {
+        unsigned long long k = __hip_atomic_load(&keys[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (k == kP2Empty) {
+          k = atomicCAS(&keys[idx], kP2Empty, (unsigned long long)rec);
+          if (k == kP2Empty) {  // seen for the first time: counts for its group
+            atomicAdd(&gcnt[(uint32_t)(rec >> lo_rest)], 1u);
+            return;
+          }
+        }
+        if (k == rec) return;
+        idx = idx + 1 == Sb ? 0u : idx + 1;
+      }
+      q.flags[0] = 1u;  // every entry holds another record (a class far larger than its share): the result is void
+    };
+    constexpr uint32_t kBatch = 8;  // a thread's first rows, requested together and kept for all the passes
+    uint64_t b[kBatch];
+#pragma unroll
+    for (uint32_t j = 0; j < kBatch; ++j) {
+      const uint32_t i = b0 + tid + j * kP2AggBlock, ic = i < b1 ? i : b0;
+      b[j] = __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.out_lo + ic));
+    }
+    for (uint32_t pass = 0; pass < passes; ++pass) {
+      if (pass) __syncthreads();
+      for (uint32_t i = tid; i < Sb; i += kP2AggBlock) keys[i] = kP2Empty;
+      __syncthreads();
+#pragma unroll
+      for (uint32_t j = 0; j < kBatch; ++j)
+        if (b0 + tid + j * kP2AggBlock < b1) take(b[j], pass);
+      for (uint32_t i = b0 + tid + kBatch * kP2AggBlock; i < b1; i += kP2AggBlock)
+        take(__builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.out_lo + i)), pass);
+    }
+    __syncthreads();
+    const uint64_t coarse = f >> q.p2_bits;
+    for (uint32_t i = tid; i < n_groups; i += kP2AggBlock) {
+      const uint32_t c = gcnt[i];
+      if (c == 0) continue;
+      gcnt[i] = 0;
+      const uint64_t hi = bij_unmix((coarse << hi_rest) | i, q.hi_bits);
+      const uint64_t e = global_entry_raw(q.dense, q.capacity, q.g_keys, q.overflow, hi);
+      if (e != ~0ull) {
+        // (no NULL bit in x in this form: every pair counts towards the distinct values)
+        atomicAdd((unsigned long long*)&q.g_state[e], (unsigned long long)c);
+        atomicAdd((unsigned long long*)&q.g_state[(q.capacity + 1) + e], (unsigned long long)c);
+      }
+    }
+  }
+}
+
 }  // namespace
 
-uint32_t part2_lds_entries() {
-  // a workgroup's share of the LDS next to its static arrays (group counters), in 16-byte pairs
-  return (uint32_t)((kP2LdsBytes / kP2AggPerCu - kP2Groups * 16 - 256) / 16) & ~63u;
+uint32_t part2_lds_entries(bool compact) {
+  // a workgroup's share of the LDS next to its static arrays (group counters), in 16-byte
+  // pairs or (compact form) 8-byte records
+  return (uint32_t)((kP2LdsBytes / kP2AggPerCu - kP2Groups * 16 - 256) / (compact ? 8 : 16)) & ~63u;
 }
 
 void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q) {
@@ -340,7 +451,10 @@ void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q) {
   const uint32_t n_fine = 1u << (q.p1_bits + q.p2_bits);
   if (q.p2_bits > 10 || q.p1_bits + q.p2_bits > 21 || q.n_rows >= (1ull << 32) || q.slice_rows == 0)
     fail(PRISM_GPU_EINTERNAL, "bad shape for the second partition level");
-  if (q.lds_entries > part2_lds_entries()) fail(PRISM_GPU_EINTERNAL, "the pair table exceeds LDS");
+  if (q.lds_entries > part2_lds_entries(q.compact != 0)) fail(PRISM_GPU_EINTERNAL, "the pair table exceeds LDS");
+  if (q.compact && (q.hi_bits < (int)q.p1_bits || q.hi_bits - (int)q.p1_bits > 9 || q.lo_bits < (int)q.p2_bits || q.lo_bits > 63 ||
+                    q.lo_bits - (int)q.p2_bits + q.hi_bits - (int)q.p1_bits > 63 || q.x_null_bit >= 0))
+    fail(PRISM_GPU_EINTERNAL, "bad shape for one-word records");
   const uint32_t slices = (uint32_t)ceil_div(q.n_rows, q.slice_rows);
   {
     KernelTimer timer(ctx, "part2_hist", q.n_rows * 16);
@@ -350,18 +464,19 @@ void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q) {
     PRISM_HIP(hipGetLastError());
   }
   {
-    KernelTimer timer(ctx, "part2_scatter", q.n_rows * 32);
+    KernelTimer timer(ctx, "part2_scatter", q.n_rows * (q.compact ? 24 : 32));
     const size_t lds = (size_t)kP2Block * kP2TileRows * 16 + (size_t)(3 * kP2Counters + 1) * 4;
     PRISM_HIP(hipFuncSetAttribute((const void*)k_part2_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     k_part2_scatter<<<dim3(slices), dim3(kP2Block), lds, ctx->stream>>>(q);
     PRISM_HIP(hipGetLastError());
   }
   {
-    KernelTimer timer(ctx, "part2_agg", q.n_rows * 16);
-    const size_t lds = (size_t)q.lds_entries * 16;
-    PRISM_HIP(hipFuncSetAttribute((const void*)k_part2_agg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    KernelTimer timer(ctx, "part2_agg", q.n_rows * (q.compact ? 8 : 16));
+    const size_t lds = (size_t)q.lds_entries * (q.compact ? 8 : 16);
+    auto kernel = q.compact ? k_part2_agg_compact : k_part2_agg;
+    PRISM_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint32_t grid = (uint32_t)std::min<uint64_t>(n_fine, (uint64_t)ctx->n_cus * kP2AggPerCu);
-    k_part2_agg<<<dim3(grid), dim3(kP2AggBlock), lds, ctx->stream>>>(q, n_fine);
+    kernel<<<dim3(grid), dim3(kP2AggBlock), lds, ctx->stream>>>(q, n_fine);
     PRISM_HIP(hipGetLastError());
   }
 }

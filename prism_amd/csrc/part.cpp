@@ -26,6 +26,8 @@ prism_gpu_ctx* ctx_acquire_child(prism_gpu_ctx* parent) {
       c->profiling = parent->profiling;
       c->part_min_rows.store(parent->part_min_rows.load());
       c->part_force.store(parent->part_force.load());
+  c->part2_compact.store(parent->part2_compact.load());
+      c->part2_compact.store(parent->part2_compact.load());
       return c;
     }
   }
@@ -39,6 +41,7 @@ prism_gpu_ctx* ctx_acquire_child(prism_gpu_ctx* parent) {
   c->profiling = parent->profiling;
   c->part_min_rows.store(parent->part_min_rows.load());
   c->part_force.store(parent->part_force.load());
+  c->part2_compact.store(parent->part2_compact.load());
   PRISM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   PRISM_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
   return c.release();

@@ -194,9 +194,17 @@ def test_count_distinct_partitioned_twice(part_ctx, oracle):
     from prism_amd.engine import Plan, Table
 
     wl = workloads.c5(n_services=16, user_bits=14)
-    part_ctx.reset_stats()
-    _synth_both(part_ctx, oracle, wl, 1_500_000, 4, [(wl.query, 2)])
-    assert {"part2_hist", "part2_scatter", "part2_agg"} <= _kernels(part_ctx)
+    # records of one word at the second level (the bits their fine bucket does not imply:
+    # 63-bit ids without NULLs next to a 12-bit group key allow it), then of two words
+    rows = 1_500_000
+    for compact, record_bytes in ((1, 8), (0, 16)):
+        part_ctx.set_option("part2_compact", compact)
+        part_ctx.reset_stats()
+        _synth_both(part_ctx, oracle, wl, rows, 4, [(wl.query, 2)])
+        assert {"part2_hist", "part2_scatter", "part2_agg"} <= _kernels(part_ctx)
+        agg = part_ctx.stats()["kernels"]["part2_agg"]
+        assert agg["algorithmic_bytes"] == agg["launches"] * rows * record_bytes
+    part_ctx.set_option("part2_compact", 1)
 
     rng = np.random.default_rng(21)
     n = 300_000
