@@ -367,6 +367,7 @@ __global__ __launch_bounds__(kP2AggBlock) void k_part2_agg(Part2Params q, uint32
 __global__ __launch_bounds__(kP2AggBlock) void k_part2_agg_compact(Part2Params q, uint32_t n_fine) {
   extern __shared__ __align__(16) unsigned long long p2_lds[];
   __shared__ uint32_t gcnt[kP2Groups];
+  __shared__ uint32_t crowded;  // a row of the bucket found no room on its probe path
   const uint32_t S = q.lds_entries, tid = threadIdx.x;
   const int lo_rest = q.lo_bits - (int)q.p2_bits, hi_rest = q.hi_bits - (int)q.p1_bits;
   const uint32_t n_groups = 1u << hi_rest;  // <= kP2Groups
@@ -376,34 +377,7 @@ __global__ __launch_bounds__(kP2AggBlock) void k_part2_agg_compact(Part2Params q
     __syncthreads();
     const uint32_t b0 = q.fine_base[f], b1 = q.fine_base[f + 1];
     if (b1 == b0) continue;
-    // (a fine bucket of more rows than the set is sure to take goes in several passes over
-    // its rows, each taking one residue class of another hash of the record)
     const uint32_t n = b1 - b0;
-    const uint32_t per_pass = S / 5 * 2;
-    const uint32_t passes = n > S / 2 ? (n + per_pass - 1) / per_pass : 1u;
-    // the part of the set this bucket uses (cleared before every pass): at least twice the
-    // rows a pass may bring, so that small buckets do not pay for clearing the whole table
-    const uint32_t want = passes > 1 ? S : n * 5 / 2 + 64;
-    const uint32_t Sb = want < S ? want : S;
-    auto take = [&](uint64_t rec, uint32_t pass) {
-      uint32_t h = ((uint32_t)rec ^ (uint32_t)(rec >> 32) * 0x85EBCA6Bu);
-      h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
-      if (passes > 1 && (uint32_t)(hash64(rec * 0xD6E8FEB86659FD93ull) >> 33) % passes != pass) return;
-      uint32_t idx = __umulhi(h, Sb);
-      for (uint32_t probes = 0; probes < Sb; ++probes) {
-        unsigned long long k = __hip_atomic_load(&keys[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (k == kP2Empty) {
-          k = atomicCAS(&keys[idx], kP2Empty, (unsigned long long)rec);
-          if (k == kP2Empty) {  // seen for the first time: counts for its group
-            atomicAdd(&gcnt[(uint32_t)(rec >> lo_rest)], 1u);
-            return;
-          }
-        }
-        if (k == rec) return;
-        idx = idx + 1 == Sb ? 0u : idx + 1;
-      }
-      q.flags[0] = 1u;  // every entry holds another record (a class far larger than its share): the result is void
-    };
     constexpr uint32_t kBatch = 8;  // a thread's first rows, requested together and kept for all the passes
     uint64_t b[kBatch];
 #pragma unroll
@@ -411,17 +385,60 @@ __global__ __launch_bounds__(kP2AggBlock) void k_part2_agg_compact(Part2Params q
       const uint32_t i = b0 + tid + j * kP2AggBlock, ic = i < b1 ? i : b0;
       b[j] = __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.out_lo + ic));
     }
-    for (uint32_t pass = 0; pass < passes; ++pass) {
-      if (pass) __syncthreads();
-      for (uint32_t i = tid; i < Sb; i += kP2AggBlock) keys[i] = kP2Empty;
-      __syncthreads();
+    // A bucket of more rows than the set is sure to take (n > S / 2) is first tried in one go
+    // all the same: what makes a bucket large is, as a rule, one very frequent pair, and rows
+    // that repeat a pair need no entry.  Only when a row finds its probe path crowded is the
+    // attempt given up, its counts forgotten, and the bucket taken in several passes over its
+    // rows, each for one residue class of another hash of the record.  (Going straight to
+    // the passes made the buckets of the most frequent pairs cost a dozen walks over tens of
+    // thousands of rows each, and the workgroups they fell to finished long after the rest.)
+    const bool large = n > S / 2;
+    uint32_t passes = 1;
+    for (;;) {
+      // the part of the set in use (cleared before every pass): at least twice the rows a
+      // pass may bring, so that small buckets do not pay for clearing the whole table
+      const uint32_t want = large ? S : n * 5 / 2 + 64;
+      const uint32_t Sb = want < S ? want : S;
+      const uint32_t probe_limit = (large && passes == 1) ? 96u : Sb;
+      auto take = [&](uint64_t rec, uint32_t pass) {
+        uint32_t h = ((uint32_t)rec ^ (uint32_t)(rec >> 32) * 0x85EBCA6Bu);
+        h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+        if (passes > 1 && (uint32_t)(hash64(rec * 0xD6E8FEB86659FD93ull) >> 33) % passes != pass) return;
+        uint32_t idx = __umulhi(h, Sb);
+        for (uint32_t probes = 0; probes < probe_limit; ++probes) {
+          unsigned long long k = __hip_atomic_load(&keys[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (k == kP2Empty) {
+            k = atomicCAS(&keys[idx], kP2Empty, (unsigned long long)rec);
+            if (k == kP2Empty) {  // seen for the first time: counts for its group
+              atomicAdd(&gcnt[(uint32_t)(rec >> lo_rest)], 1u);
+              return;
+            }
+          }
+          if (k == rec) return;
+          idx = idx + 1 == Sb ? 0u : idx + 1;
+        }
+        if (passes == 1) crowded = 1u;
+        else q.flags[0] = 1u;  // a class far larger than its share: the result is void
+      };
+      for (uint32_t pass = 0; pass < passes; ++pass) {
+        if (pass) __syncthreads();
+        for (uint32_t i = tid; i < Sb; i += kP2AggBlock) keys[i] = kP2Empty;
+        if (tid == 0) crowded = 0;
+        __syncthreads();
 #pragma unroll
-      for (uint32_t j = 0; j < kBatch; ++j)
-        if (b0 + tid + j * kP2AggBlock < b1) take(b[j], pass);
-      for (uint32_t i = b0 + tid + kBatch * kP2AggBlock; i < b1; i += kP2AggBlock)
-        take(__builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.out_lo + i)), pass);
+        for (uint32_t j = 0; j < kBatch; ++j)
+          if (b0 + tid + j * kP2AggBlock < b1) take(b[j], pass);
+        for (uint32_t i = b0 + tid + kBatch * kP2AggBlock; i < b1; i += kP2AggBlock)
+          take(__builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.out_lo + i)), pass);
+      }
+      __syncthreads();
+      if (passes > 1 || !crowded) break;
+      for (uint32_t i = tid; i < n_groups; i += kP2AggBlock) gcnt[i] = 0;
+      const uint32_t per_pass = S / 5 * 2;
+      passes = (n + per_pass - 1) / per_pass;
+      if (passes < 2) passes = 2;
+      __syncthreads();
     }
-    __syncthreads();
     const uint64_t coarse = f >> q.p2_bits;
     for (uint32_t i = tid; i < n_groups; i += kP2AggBlock) {
       const uint32_t c = gcnt[i];

@@ -235,6 +235,38 @@ def test_count_distinct_partitioned_twice(part_ctx, oracle):
         g.close()
 
 
+def test_count_distinct_of_one_dominant_group(part_ctx, oracle):
+    """Nine rows in ten belong to one group.  With values that hardly repeat its fine buckets
+    hold far more distinct pairs than the LDS set takes: the attempt to take such a bucket in
+    one go is given up and it goes class by class.  With values that repeat a lot the same
+    buckets are just as large but fit in one go."""
+    import numpy as np
+    import pyarrow as pa
+    from prism_amd.engine import Plan, Table
+
+    rng = np.random.default_rng(33)
+    n = 2_000_000
+    c = np.where(rng.random(n) < 0.9, 17, rng.integers(0, 200, n)).astype(np.int32)
+    for distinct_values in (1 << 40, 300):
+        a = rng.integers(0, distinct_values, n).astype(np.int64) * ((2**62) // distinct_values) - 2**61
+        t = pa.table({"a": pa.array(a), "c": pa.array(c)})
+        g = Table(part_ctx, t.schema)
+        g.append_table(t, 4)
+        try:
+            q = QueryPlan([count_distinct("a")], keys=["c"])
+            plan = Plan(part_ctx, t.schema, q)
+            try:
+                part_ctx.reset_stats()
+                got = plan.execute(g)
+                agg = part_ctx.stats()["kernels"]["part2_agg"]
+                assert agg["launches"] == 1 and agg["algorithmic_bytes"] == n * 8  # one-word records
+            finally:
+                plan.close()
+            assert_tables_match(got, oracle.execute(t, q), 1)
+        finally:
+            g.close()
+
+
 def test_streaming_kernel_hands_over_when_rows_scatter(oracle):
     """No forcing: the streaming kernel runs first, finds that its rows miss the LDS tables,
     stops, and the plan is partitioned from then on (its predicate, evaluated inside the
