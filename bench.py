@@ -278,7 +278,7 @@ def main() -> int:
             tag = {("C2", 1_000_000_000, 64): "c2_1b", ("C3", 100_000_000, 100): "c3", ("C1", 1_000_000_000, 64): "c1_1b",
                    ("C4", 100_000_000, wl.default_partitions): "c4", ("C5", 1_250_000_000, 64): "c5_1p25b"}.get((wl.name, rows, parts))
             symbol = {"group_by": ("k_group_by_stream", "k_part_agg", "k_part_scatter", "k_part_hist", "k_part_offsets",
-                                   "k_part_plan", "k_part2_hist", "k_part2_scan", "k_part2_scatter", "k_part2_agg",
+                                   "k_part_plan", "k_part2_hist", "k_part2_scan", "k_part2_scatter", "k_part2_agg", "k_part2_agg_compact",
                                    "k_group_by_wide", "k_group_by"),
                       "filter_count": ("k_cmp_leaf",), "like_contains": ("k_contains_find", "k_contains_mark")}[kname]
             try:

@@ -547,11 +547,16 @@ void update_merge(const Plan& p, GroupTable& T, const Batch& b) {
 }
 
 // Fold table B into A (used by the multi-threaded path).
-void fold(const Plan& p, GroupTable& A, GroupTable& B) {
+// Merges B's groups into A; with n_slices > 1 only the groups whose key hash falls into
+// `slice` (the share of one FinalPartitioned task behind a hash repartition).
+void fold(const Plan& p, GroupTable& A, GroupTable& B, size_t n_slices = 1, size_t slice = 0) {
   const prism_gpu_plan_desc* d = p.d;
-  A.rows_in += B.rows_in;
-  A.rows_selected += B.rows_selected;
+  if (slice == 0) {
+    A.rows_in += B.rows_in;
+    A.rows_selected += B.rows_selected;
+  }
   for (size_t g = 0; g < B.keys.size(); ++g) {
+    if (n_slices > 1 && (GKeyHash()(B.keys[g]) >> 40) % n_slices != slice) continue;
     GKey k = B.keys[g];
     for (uint32_t i = 0; i < d->n_keys; ++i)
       if (!B.key_strs[i].strs.empty() && !(k.nulls & (1u << i)))
@@ -942,7 +947,39 @@ void run_threads(const Plan& p, const std::vector<const Batch*>& batches, bool m
     });
   for (auto& x : th) x.join();
   for (auto& e : errs) if (e.code) throw e;
-  for (int t = 0; t < nt; ++t) fold(p, T, *parts[t]);
+  // The Final stage.  Many groups and keys that are plain integers: the partial tables are
+  // repartitioned by key hash, one slice per thread (DataFusion's RepartitionExec(Hash) +
+  // AggregateExec(FinalPartitioned)), and the disjoint results are strung together.  Else
+  // (few groups, or string keys, whose ids are per table) one sequential fold.
+  size_t partial_groups = 0;
+  for (auto& part : parts) partial_groups += part->keys.size();
+  bool ints_only = parts[0]->distinct_strs.strs.empty();
+  for (auto& part : parts) {
+    for (auto& ks : part->key_strs) ints_only = ints_only && ks.strs.empty();
+    ints_only = ints_only && part->distinct_strs.strs.empty();
+  }
+  if (partial_groups < 200000 || !ints_only) {
+    for (int t = 0; t < nt; ++t) fold(p, T, *parts[t]);
+    return;
+  }
+  std::vector<std::unique_ptr<GroupTable>> finals;
+  for (int t = 0; t < nt; ++t) { finals.emplace_back(new GroupTable()); init_table(p, *finals.back()); }
+  th.clear();
+  for (int t = 0; t < nt; ++t)
+    th.emplace_back([&, t]() {
+      try {
+        for (auto& part : parts) fold(p, *finals[t], *part, (size_t)nt, (size_t)t);
+      } catch (OracleError& e) { errs[t] = e; }
+    });
+  for (auto& x : th) x.join();
+  for (auto& e : errs) if (e.code) throw e;
+  for (auto& f : finals) {
+    T.rows_in += f->rows_in;
+    T.rows_selected += f->rows_selected;
+    T.keys.insert(T.keys.end(), f->keys.begin(), f->keys.end());
+    T.st.insert(T.st.end(), f->st.begin(), f->st.end());
+    for (auto& st : f->st) st.distinct = nullptr;  // the sets moved with their states
+  }
 }
 
 template <class F>

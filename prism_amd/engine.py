@@ -443,9 +443,18 @@ class Comm:
         import torch.distributed as dist
 
         rank, world = dist.get_rank(), dist.get_world_size()
-        box = [cls.unique_id() if rank == 0 else None]
+        # (a rank 0 that cannot make the id says so to the others instead of leaving them in
+        # the broadcast: every rank then fails alike, and the caller's fallback stays in step)
+        box = [None, None]
+        if rank == 0:
+            try:
+                box[0] = cls.unique_id()
+            except PrismGpuError as e:
+                box[1] = (e.code, e.msg)
         if world > 1:
             dist.broadcast_object_list(box, src=0)
+        if box[0] is None:
+            raise PrismGpuError(*box[1])
         return cls.rccl(ctx, box[0], rank, world)
 
     @classmethod
