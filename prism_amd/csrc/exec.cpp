@@ -691,6 +691,9 @@ struct GroupTable {
   // groups sit in the leading entries in no particular order (the partitioned GROUP BY's
   // output).  Everything that walks the entries works as is; nothing may be inserted by hashing.
   bool list = false;
+  // no group of the table has seen more rows than this (0: unknown); lets ORDER BY COUNT(..)
+  // start its radix select below the bits no count can have
+  uint64_t rows_bound = 0;
   uint64_t capacity = 0;
   int n_slots = 0;
   int key_words = 1;
@@ -791,7 +794,7 @@ constexpr uint64_t kTopKMinEntries = 4096;
 
 // Whether ORDER BY ... LIMIT of this plan can be decided on the device, and how.
 bool topk_order(const prism_gpu_plan* p, const prism_gpu_table* t, const std::vector<KeySrc>& keys, const KeyLayout& layout,
-                const Lowered& low, const std::vector<OutColumn>& cols, TopKOrder& o) {
+                const Lowered& low, const std::vector<OutColumn>& cols, TopKOrder& o, uint64_t rows_bound = 0) {
   if (p->order_by < 0 || p->limit < 0 || p->limit > (1 << 20)) return false;
   std::memset(&o, 0, sizeof(o));
   o.descending = p->descending ? 1 : 0;
@@ -816,6 +819,12 @@ bool topk_order(const prism_gpu_plan* p, const prism_gpu_table* t, const std::ve
     o.kind = kOrdAvg;
   } else {
     o.kind = kOrdI64;
+    // a count is never NULL and lies in [0, rows]: the bits above are the same in every rank
+    if ((r.func == PRISM_AGG_COUNT_STAR || r.func == PRISM_AGG_COUNT) && r.count_slot < 0 && !o.is_unsigned && rows_bound) {
+      int b = 1;
+      while (b < 63 && (rows_bound >> b)) ++b;
+      o.value_bits = b;
+    }
   }
   return true;
 }
@@ -946,7 +955,7 @@ uint64_t emit_groups(prism_gpu_ctx* ctx, const prism_gpu_plan* plan, const prism
     Scratch d_topk;
     const TopKOrder* use_order = nullptr;
     const uint64_t entries = gt.dense ? gt.capacity : gt.capacity + 1;
-    if (!partial && entries >= kTopKMinEntries && topk_order(plan, table, keys, layout, low, cols, order)) {
+    if (!partial && entries >= kTopKMinEntries && topk_order(plan, table, keys, layout, low, cols, order, gt.rows_bound)) {
       d_topk = Scratch(ctx, sizeof(TopKState));
       launch_topk_threshold(ctx, gt.dense, gt.capacity, gt.keys.as<uint64_t>(), gt.keys_hi.as<uint64_t>(),
                             gt.state.as<int64_t>(), order, (uint64_t)std::max<int64_t>(1, plan->limit), d_topk.as<TopKState>());
@@ -1745,20 +1754,22 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
   ap.sd = ss.desc;
   ap.cols = ss.cols_dev;
 
-  Scratch d_scalar(ctx, 256);
+  // a count many workgroups add to: kCountShards partial sums (kernels.hpp), added up here
+  Scratch d_scalar(ctx, kCountBytes);
+  std::vector<unsigned long long> h_count(kCountBytes / 8);
   if (has_pred && count_only) {
     const PredNode& n = *range_a;
     const FieldType& f = table->fields[n.column];
-    PRISM_HIP(hipMemsetAsync(d_scalar.p, 0, 8, ctx->stream));
+    PRISM_HIP(hipMemsetAsync(d_scalar.p, 0, kCountBytes, ctx->stream));
     {
       KernelTimer timer(ctx, "filter_count", ss.rows * f.width);
       launch_cmp_leaf(ctx, ss.desc, ss.col(ss.use(n.column, false)), f.width, f.is_unsigned, n.cmp_mask, n.lit_i64, nullptr,
                       d_scalar.as<unsigned long long>(), range_b ? range_b->cmp_mask : (kLt | kEq | kGt),
                       range_b ? range_b->lit_i64 : 0);
     }
-    unsigned long long c = 0;
-    PRISM_HIP(hipMemcpyAsync(&c, d_scalar.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PRISM_HIP(hipMemcpyAsync(h_count.data(), d_scalar.p, kCountBytes, hipMemcpyDeviceToHost, ctx->stream));
     PRISM_HIP(hipStreamSynchronize(ctx->stream));
+    const unsigned long long c = count_total(h_count.data());
     collect_timings(ctx);
     std::vector<OutColumn> cols = make_columns(partial ? plan->partial_fields : plan->final_fields);
     cols[0].push_int((int64_t)c);
@@ -1780,24 +1791,25 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
   std::shared_ptr<void> fused_landing;
   auto fused_slot = [&]() -> unsigned long long* {
     if (!fused_landing) {
-      fused_landing = lease_pinned(ctx, 64);
-      *(unsigned long long*)fused_landing.get() = 0;
+      fused_landing = lease_pinned(ctx, kCountBytes);
+      std::memset(fused_landing.get(), 0, kCountBytes);
     }
     return (unsigned long long*)fused_landing.get();
   };
+  auto fused_count = [&]() { return count_total(fused_slot()); };
   if (fused) {
     ap.row_mode = kRowsAll;
     ap.selected_out = d_scalar.as<unsigned long long>();
+    ap.selected_sharded = 1;
   }
   if (has_pred && !fused) {
     sel.all = false;
     sel.bits = pe.eval(plan->pred_root);
-    PRISM_HIP(hipMemsetAsync(d_scalar.p, 0, 8, ctx->stream));
+    PRISM_HIP(hipMemsetAsync(d_scalar.p, 0, kCountBytes, ctx->stream));
     launch_bitmap_count(ctx, sel.bits.as<uint64_t>(), n_words, d_scalar.as<unsigned long long>());
-    unsigned long long c = 0;
-    PRISM_HIP(hipMemcpyAsync(&c, d_scalar.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PRISM_HIP(hipMemcpyAsync(h_count.data(), d_scalar.p, kCountBytes, hipMemcpyDeviceToHost, ctx->stream));
     PRISM_HIP(hipStreamSynchronize(ctx->stream));
-    sel.count = selected = c;
+    sel.count = selected = count_total(h_count.data());
     // COUNT(*) alone is the number of TRUE rows: nothing left to aggregate
     bool only_count_star = plan->keys.empty() && !plan->distinct_plan && !capture && !plan->aggs.empty();
     for (const AggPlan& a : plan->aggs) only_count_star = only_count_star && a.func == PRISM_AGG_COUNT_STAR;
@@ -1878,14 +1890,14 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       ap.g_keys_hi = nullptr;
       ap.g_state = gt.state.as<int64_t>();
       ap.overflow = gt.overflow.as<uint32_t>();
-      if (fused) PRISM_HIP(hipMemsetAsync(d_scalar.p, 0, 8, ctx->stream));
+      if (fused) PRISM_HIP(hipMemsetAsync(d_scalar.p, 0, kCountBytes, ctx->stream));
       launch_group_by(ctx, ap, agg_bytes, "agg_global");
       std::vector<int64_t> both((size_t)ap.n_slots * 2);  // entry 0 and the unused extra entry of every slot
       PRISM_HIP(hipMemcpyAsync(both.data(), gt.state.p, both.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-      if (fused) PRISM_HIP(hipMemcpyAsync(fused_slot(), d_scalar.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+      if (fused) PRISM_HIP(hipMemcpyAsync(fused_slot(), d_scalar.p, kCountBytes, hipMemcpyDeviceToHost, ctx->stream));
       PRISM_HIP(hipStreamSynchronize(ctx->stream));
       for (int s = 0; s < ap.n_slots; ++s) g.state[s] = both[(size_t)s * 2];
-      if (fused) selected = *fused_slot();
+      if (fused) selected = fused_count();
     } else {
       // a selection vector of few rows: gather them
       std::vector<int64_t> init(ap.n_slots);
@@ -1997,7 +2009,7 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       ap.g_keys_hi = gt.keys_hi.as<uint64_t>();
       ap.g_state = gt.state.as<int64_t>();
       ap.overflow = gt.overflow.as<uint32_t>();
-      if (fused) PRISM_HIP(hipMemsetAsync(d_scalar.p, 0, 8, ctx->stream));
+      if (fused) PRISM_HIP(hipMemsetAsync(d_scalar.p, 0, kCountBytes, ctx->stream));
       launch_group_by(ctx, ap, (ap.row_mode == kRowsSelvec ? selected : ss.rows) * value_bytes);
       if (dense && !ap.stop_if_scattered) break;
       const uint32_t flag = table_flag(ctx, gt);
@@ -2021,7 +2033,7 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
     }
     if (!dense && !use_part && !outer_ready) plan->learned_capacity.store(capacity, std::memory_order_relaxed);
     // lands with the next synchronisation of the stream (every path below has one before the statistics)
-    if (fused) PRISM_HIP(hipMemcpyAsync(fused_slot(), d_scalar.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (fused) PRISM_HIP(hipMemcpyAsync(fused_slot(), d_scalar.p, kCountBytes, hipMemcpyDeviceToHost, ctx->stream));
     if (capture) {
       PRISM_HIP(hipStreamSynchronize(ctx->stream));
       collect_timings(ctx);
@@ -2033,7 +2045,7 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       st->low = low;
       st->gt = std::move(gt);
       st->slot_ops = slot_ops;
-      if (fused) selected = *fused_slot();
+      if (fused) selected = fused_count();
       st->distinct = plan->distinct_plan ? 1 : 0;
       st->selected = selected;
       {
@@ -2045,6 +2057,7 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       return;
     }
     if (!plan->distinct_plan) {
+      if (!merge_input) gt.rows_bound = ss.rows;  // (merged counts add up over states: no such bound)
       groups_out = emit_groups(ctx, plan, table, keys, layout, low, gt, partial, cols);
     } else if (partial) {
       // inner GROUP BY (keys, x): one row per distinct pair
@@ -2065,7 +2078,7 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
   }
   PRISM_HIP(hipStreamSynchronize(ctx->stream));
   collect_timings(ctx);
-  if (fused && !plan->keys.empty()) selected = *fused_slot();
+  if (fused && !plan->keys.empty()) selected = fused_count();
   if (!partial) sort_and_limit(plan, cols);
   {
     std::lock_guard<std::mutex> g(ctx->mu);

@@ -196,6 +196,7 @@ struct AggParams {
   int32_t n_pred, pred_or;
   FusedLeaf pred[kMaxFusedLeaves];
   unsigned long long* selected_out;
+  int32_t selected_sharded;  // selected_out is a sharded count (kCountShards partial sums), not one word
   int64_t* g_state;     // n_slots arrays of (capacity + 1) entries
   uint32_t* overflow;   // set to 1 when the hash table is full
 };
@@ -325,12 +326,26 @@ void launch_distinct_fold(prism_gpu_ctx* ctx, const DistinctFoldParams& p);
 // k entries reach, and launch_emit then compacts only those.  Entries that tie with the
 // threshold all pass, so the host still sorts the survivors and cuts at k.
 enum TopKKind { kOrdI64 = 0, kOrdAvg = 1, kOrdKeyField = 2 };
+// A count that many workgroups add to is kept as kCountShards partial sums, each in a
+// 128-byte line of its own, and added up by whoever reads it.  Updates of ONE address from
+// all over the chip are carried out one after the other, some tens of nanoseconds each: two
+// thousand workgroups that finish together and each add to one counter keep a kernel alive
+// for 30 to 80 microseconds after its last load (a 50-microsecond kernel twice as long).
+constexpr int kCountShards = 64, kCountShardStride = 16;  // (stride in 8-byte words)
+constexpr size_t kCountBytes = (size_t)kCountShards * kCountShardStride * 8;
+inline unsigned long long count_total(const unsigned long long* shards) {
+  unsigned long long t = 0;
+  for (int i = 0; i < kCountShards; ++i) t += shards[(size_t)i * kCountShardStride];
+  return t;
+}
+
 struct TopKOrder {
   int kind;
   int main_slot, count_slot;  // kOrdI64 / kOrdAvg: value slot; count slot (> 0 <=> not NULL, -1: never NULL)
   int is_unsigned;            // kOrdI64: compare as unsigned
   int descending;
   int word, bit_pos, bits, null_bit;  // kOrdKeyField: where the field sits in the packed key
+  int value_bits;             // kOrdI64, signed, never NULL: every value lies in [0, 2^value_bits); 0 = unknown
 };
 constexpr int kTopKBins = 2048;
 struct TopKState {

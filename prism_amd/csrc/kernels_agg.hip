@@ -503,10 +503,10 @@ __device__ __forceinline__ uint64_t topk_rank(const TopKOrder& o, bool dense, ui
 // whose higher bits match the prefix found so far.
 __global__ __launch_bounds__(kBlock) void k_topk_hist(TopKOrder o, int dense, uint64_t capacity, const uint64_t* g_keys,
                                                      const uint64_t* g_keys_hi, const long long* g_state,
-                                                     TopKState* st, int shift, int bits) {
+                                                     TopKState* st, int shift, int bits, int first_pass) {
   __shared__ uint32_t h[kTopKBins];
   if (st->done) return;
-  const bool first = shift + bits == 64;
+  const bool first = first_pass != 0;
   // (counts and the like use a few low bits: the passes over bits no rank differs in do nothing)
   if (!first && (((st->or_bits ^ st->and_bits) >> shift) & ((1ull << bits) - 1ull)) == 0) return;
   for (int b = threadIdx.x; b < kTopKBins; b += kBlock) h[b] = 0;
@@ -514,23 +514,59 @@ __global__ __launch_bounds__(kBlock) void k_topk_hist(TopKOrder o, int dense, ui
   const uint64_t prefix = st->prefix, mask = st->mask;
   const uint64_t n = dense ? capacity : capacity + 1;
   unsigned long long all_or = 0ull, all_and = ~0ull;
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
-    if (g_state[i] == 0) continue;  // slot 0 counts the rows of the group
-    const uint64_t r = topk_rank(o, dense != 0, capacity, g_keys, g_keys_hi, g_state, i);
-    all_or |= r;
-    all_and &= r;
-    if ((r & mask) != prefix) continue;
-    atomicAdd(&h[(r >> shift) & ((1u << bits) - 1)], 1u);
+  // Eight entries a step, their loads issued before any is looked at: the launch is kept to two
+  // workgroups per CU (see launch_topk_threshold), so a thread has many entries to walk.
+  constexpr int kAhead = 8;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i0 < n; i0 += kAhead * stride) {
+    uint64_t r[kAhead];
+    bool occ[kAhead];
+#pragma unroll
+    for (int j = 0; j < kAhead; ++j) {
+      const uint64_t i = i0 + (uint64_t)j * stride, ic = i < n ? i : i0;
+      occ[j] = i < n && g_state[ic] != 0;  // slot 0 counts the rows of the group
+      r[j] = topk_rank(o, dense != 0, capacity, g_keys, g_keys_hi, g_state, ic);
+    }
+#pragma unroll
+    for (int j = 0; j < kAhead; ++j) {
+      if (occ[j]) {
+        all_or |= r[j];
+        all_and &= r[j];
+      }
+      // The lanes that share the bin of the wave's first entry are counted and added once:
+      // counts and the like put nearly every entry into one bin, and the lanes of an LDS
+      // atomic that meet on one address are served one after the other.
+      bool todo = occ[j] && (r[j] & mask) == prefix;
+      const uint32_t bin = (uint32_t)(r[j] >> shift) & ((1u << bits) - 1);
+      const uint64_t m_todo = __ballot(todo);
+      if (m_todo) {
+        const int leader = __ffsll((long long)m_todo) - 1;
+        const uint32_t bin0 = __shfl(bin, leader);
+        const uint64_t m_same = __ballot(todo && bin == bin0);
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&h[bin0], (uint32_t)__popcll(m_same));
+        todo = todo && bin != bin0;
+      }
+      if (todo) atomicAdd(&h[bin], 1u);
+    }
   }
   if (first) {
+    // one update per workgroup (through LDS): every update of these two words meets all the others
+    __shared__ unsigned long long wg_or, wg_and;
+    if (threadIdx.x == 0) { wg_or = 0ull; wg_and = ~0ull; }
+    __syncthreads();
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       all_or |= __shfl_xor(all_or, off, 64);
       all_and &= __shfl_xor(all_and, off, 64);
     }
     if ((threadIdx.x & 63) == 0) {
-      if (all_or) atomicOr(&st->or_bits, all_or);
-      if (all_and != ~0ull) atomicAnd(&st->and_bits, all_and);
+      atomicOr(&wg_or, all_or);
+      atomicAnd(&wg_and, all_and);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (wg_or) atomicOr(&st->or_bits, wg_or);
+      if (wg_and != ~0ull) atomicAnd(&st->and_bits, wg_and);
     }
   }
   __syncthreads();
@@ -540,7 +576,7 @@ __global__ __launch_bounds__(kBlock) void k_topk_hist(TopKOrder o, int dense, ui
 
 // Picks the bin that holds the k_rem-th largest rank, narrows the prefix to it and
 // clears the histogram for the next pass.  One workgroup.
-__global__ __launch_bounds__(kBlock) void k_topk_pick(TopKState* st, int shift, int bits) {
+__global__ __launch_bounds__(kBlock) void k_topk_pick(TopKState* st, int shift, int bits, int first_pass) {
   constexpr int kPer = kTopKBins / kBlock;
   __shared__ uint64_t part[kBlock];
   __shared__ uint64_t before[kBlock];  // entries in the bins above this thread's bins
@@ -549,7 +585,7 @@ __global__ __launch_bounds__(kBlock) void k_topk_pick(TopKState* st, int shift, 
   const uint64_t k = st->k_rem;
   const int t = threadIdx.x;
   // the pass was skipped: its bits are the same in every rank
-  if (shift + bits != 64 && !done && (((st->or_bits ^ st->and_bits) >> shift) & ((1ull << bits) - 1ull)) == 0) {
+  if (!first_pass && !done && (((st->or_bits ^ st->and_bits) >> shift) & ((1ull << bits) - 1ull)) == 0) {
     if (t == 0) {
       const uint64_t field = ((1ull << bits) - 1ull) << shift;
       st->prefix |= st->and_bits & field;
@@ -871,18 +907,31 @@ void launch_topk_threshold(prism_gpu_ctx* ctx, bool dense, uint64_t capacity, co
   PRISM_HIP(hipMemsetAsync(d_state, 0, sizeof(TopKState), ctx->stream));
   PRISM_HIP(hipMemcpyAsync(&d_state->k_rem, &k, 8, hipMemcpyHostToDevice, ctx->stream));
   PRISM_HIP(hipMemsetAsync(&d_state->and_bits, 0xff, 8, ctx->stream));
+  // Ranks known to agree in their upper bits (counts: no group has more rows than the scan):
+  // the select starts below them, with the common prefix in place.  A valid value v ranks as
+  // v ^ 2^63 when descending and as the complement of that when ascending.
+  int top = 64;
+  if (order.kind == kOrdI64 && !order.is_unsigned && order.count_slot < 0 && order.value_bits > 0 && order.value_bits < 53) {
+    top = order.value_bits;
+    const uint64_t mask = ~0ull << top;
+    const uint64_t preset[2] = {(order.descending ? (1ull << 63) : ~(1ull << 63)) & mask, mask};
+    PRISM_HIP(hipMemcpyAsync(&d_state->prefix, preset, 16, hipMemcpyHostToDevice, ctx->stream));
+  }
   KernelTimer timer(ctx, "topk_select", n * 16);
   // Few workgroups: each ends with updates of the bins its entries fell into, which for
-  // counts and the like are the same few bins for everybody, and updates of one address are
-  // carried out one after the other.
-  const uint32_t grid = (uint32_t)std::min<uint64_t>(stream_grid(ctx, n), std::max<uint64_t>((uint64_t)ctx->n_cus, n / 4096));
-  // 64 rank bits, most significant first: five passes of 11 bits and one of 9
-  for (int hi = 64; hi > 0;) {
+  // counts and the like are the same few bins for everybody, and updates of one address from
+  // all over the chip are carried out one after the other, some tens of nanoseconds each (with
+  // eight workgroups per CU a pass over 8 M entries took 80 us, nearly all of it waiting for
+  // those updates to drain).
+  const uint32_t grid = (uint32_t)std::min<uint64_t>(stream_grid(ctx, n), (uint64_t)ctx->n_cus * 2);
+  // the rank bits below `top`, most significant first, 11 at a time (all 64: five passes of 11 bits and one of 9)
+  for (int hi = top; hi > 0;) {
     const int bits = hi >= 11 ? 11 : hi;
     const int shift = hi - bits;
+    const int first = hi == top ? 1 : 0;
     k_topk_hist<<<dim3(grid), dim3(kBlock), 0, ctx->stream>>>(order, dense ? 1 : 0, capacity, g_keys, g_keys_hi,
-                                                                           (const long long*)g_state, d_state, shift, bits);
-    k_topk_pick<<<dim3(1), dim3(kBlock), 0, ctx->stream>>>(d_state, shift, bits);
+                                                                           (const long long*)g_state, d_state, shift, bits, first);
+    k_topk_pick<<<dim3(1), dim3(kBlock), 0, ctx->stream>>>(d_state, shift, bits, first);
     hi = shift;
   }
   PRISM_HIP(hipGetLastError());

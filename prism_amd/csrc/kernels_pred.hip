@@ -20,7 +20,8 @@ inline uint32_t leaf_grid(prism_gpu_ctx* ctx, uint64_t n_tiles) {
   return (uint32_t)(n_tiles < cap ? (n_tiles ? n_tiles : 1) : cap);
 }
 
-// Adds each block's count with one atomic.
+// Adds each block's count with one atomic, to the block's shard of the count (kCountShards
+// partial sums: see kernels.hpp).
 __device__ __forceinline__ void block_count_add(unsigned long long local, unsigned long long* count) {
   __shared__ unsigned long long partial[kBlock / 64];
   unsigned long long w = wave_sum_u64(local);
@@ -29,7 +30,7 @@ __device__ __forceinline__ void block_count_add(unsigned long long local, unsign
   if (threadIdx.x == 0) {
     unsigned long long t = 0;
     for (int i = 0; i < (int)(kBlock / 64); ++i) t += partial[i];
-    if (t) atomicAdd(count, t);
+    if (t) atomicAdd(count + (size_t)(blockIdx.x & (kCountShards - 1)) * kCountShardStride, t);
   }
 }
 

@@ -725,8 +725,19 @@ __device__ __forceinline__ void consume_ungrouped(const AggParams& p, const Pack
   consume_ungrouped_slots<NV, K32>(p, b, acc, std::make_integer_sequence<int, kUngroupedSlots>{});
 }
 
+// Two partial values of one slot into one.
+__device__ __forceinline__ long long merge_partials(int op, long long a, long long b) {
+  if (op == kSlotMin) return a < b ? a : b;
+  if (op == kSlotMax) return a > b ? a : b;
+  if (op == kSlotAddF64) return __double_as_longlong(__longlong_as_double(a) + __longlong_as_double(b));
+  return (long long)((unsigned long long)a + (unsigned long long)b);
+}
+
+constexpr int kMaxWavesPerBlock = 16;
+
 template <int S>
-__device__ __forceinline__ void finish_ungrouped_slot(const AggParams& p, const long long (&acc)[kUngroupedSlots]) {
+__device__ __forceinline__ void finish_ungrouped_slot(const AggParams& p, const long long (&acc)[kUngroupedSlots],
+                                                      long long (&wave_part)[kUngroupedSlots][kMaxWavesPerBlock]) {
   if (S >= p.n_slots) return;
   const int op = p.slots[S].op;
   long long v = acc[S];
@@ -734,18 +745,32 @@ __device__ __forceinline__ void finish_ungrouped_slot(const AggParams& p, const 
   else if (op == kSlotMax) v = wave_max_i64(v);
   else if (op == kSlotAddF64) v = __double_as_longlong(wave_sum_f64(__longlong_as_double(v)));
   else v = (long long)wave_sum_u64((unsigned long long)v);
-  if ((threadIdx.x & 63u) == 0 && v != slot_identity(op))
-    atomic_apply(&p.g_state[(uint64_t)S * (p.capacity + 1)], (op == kSlotAddOne || op == kSlotAddValid) ? kSlotAddI64 : op, v);
+  if ((threadIdx.x & 63u) == 0) wave_part[S][threadIdx.x >> 6] = v;
 }
 
 template <int... S>
 __device__ __forceinline__ void finish_ungrouped_slots(const AggParams& p, const long long (&acc)[kUngroupedSlots],
+                                                       long long (&wave_part)[kUngroupedSlots][kMaxWavesPerBlock],
                                                        std::integer_sequence<int, S...>) {
-  (finish_ungrouped_slot<S>(p, acc), ...);
+  (finish_ungrouped_slot<S>(p, acc, wave_part), ...);
 }
 
+// The lanes' accumulators become one value per wave, the waves' values one per workgroup (in
+// LDS), and the workgroup applies that to the result with one atomic per slot: every one of
+// these atomics meets all the others on one address, where they are carried out one after
+// the other (a per-wave update was 8 times as many of them: with three slots, tens of
+// thousands that kept the kernel alive long after its last load).  Block-wide.
 __device__ __forceinline__ void finish_ungrouped(const AggParams& p, const long long (&acc)[kUngroupedSlots]) {
-  finish_ungrouped_slots(p, acc, std::make_integer_sequence<int, kUngroupedSlots>{});
+  __shared__ long long wave_part[kUngroupedSlots][kMaxWavesPerBlock];
+  finish_ungrouped_slots(p, acc, wave_part, std::make_integer_sequence<int, kUngroupedSlots>{});
+  __syncthreads();
+  const int s = (int)threadIdx.x;
+  if (s >= p.n_slots || s >= kUngroupedSlots) return;
+  const int op = p.slots[s].op, n_waves = (int)(blockDim.x >> 6);
+  long long v = slot_identity(op);
+  for (int w = 0; w < n_waves; ++w) v = merge_partials(op, v, wave_part[s][w]);
+  if (v != slot_identity(op))
+    atomic_apply(&p.g_state[(uint64_t)s * (p.capacity + 1)], (op == kSlotAddOne || op == kSlotAddValid) ? kSlotAddI64 : op, v);
 }
 
 template <bool K32>
@@ -754,14 +779,6 @@ __device__ __forceinline__ void lds_clear(const AggParams& p, const Lds<K32>& t)
     if (i < t.S) t.keys[i] = (KeyT<K32>)~(KeyT<K32>)0;
     for (int s = 0; s < p.n_slots; ++s) t.state[s * t.stride + i] = slot_identity(p.slots[s].op);
   }
-}
-
-// Two partial values of one slot into one.
-__device__ __forceinline__ long long merge_partials(int op, long long a, long long b) {
-  if (op == kSlotMin) return a < b ? a : b;
-  if (op == kSlotMax) return a > b ? a : b;
-  if (op == kSlotAddF64) return __double_as_longlong(__longlong_as_double(a) + __longlong_as_double(b));
-  return (long long)((unsigned long long)a + (unsigned long long)b);
 }
 
 // Folds the LDS table into the HBM table and empties it.  Block-wide; the caller
@@ -887,7 +904,8 @@ __global__ __launch_bounds__(kStreamBlock, stream_min_waves(NK, NV, K32)) PRISM_
         consume_ungrouped<NV, K32>(p, rows, acc);
       }
       finish_ungrouped(p, acc);
-      if (PRED && lane == 0 && n_selected) atomicAdd(p.selected_out, (unsigned long long)n_selected);
+      if (PRED && lane == 0 && n_selected)
+        atomicAdd(p.selected_out + (p.selected_sharded ? (size_t)(blockIdx.x & (kCountShards - 1)) * kCountShardStride : 0), (unsigned long long)n_selected);
       return;
     }
   }
@@ -982,7 +1000,8 @@ __global__ __launch_bounds__(kStreamBlock, stream_min_waves(NK, NV, K32)) PRISM_
   }
   __syncthreads();
   lds_flush<K32>(p, t);
-  if (PRED && lane == 0 && n_selected) atomicAdd(p.selected_out, (unsigned long long)n_selected);
+  if (PRED && lane == 0 && n_selected)
+        atomicAdd(p.selected_out + (p.selected_sharded ? (size_t)(blockIdx.x & (kCountShards - 1)) * kCountShardStride : 0), (unsigned long long)n_selected);
 }
 
 template <int NK, bool K32, bool PRED>
