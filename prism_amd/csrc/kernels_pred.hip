@@ -649,6 +649,10 @@ __global__ __launch_bounds__(kBlock) void k_contains_find(const ContainsSeg* seg
       const bool inside = p < cc.total;
       if (__ballot(inside && any) == 0ull) continue;
       // rare from here on.  Candidate bit 4 w + off + i: window (w, off) equals needle word i.
+      // (Tried and dropped: settling candidates from the neighbours' registers instead of
+      // loading their bytes again -- no faster, and the registers cost a resident workgroup;
+      // working out on the scalar side which comparisons hit and settling each for the whole
+      // wave at once -- 1.60 ms against 1.28.)
       uint32_t cand = 0;
       if (inside) {
 #pragma unroll
@@ -716,11 +720,15 @@ __global__ __launch_bounds__(kBlock) void k_contains_find(const ContainsSeg* seg
   flush();
 }
 
-// Pass 2: one thread per occurrence.  The number of occurrences is read on the device, so the
-// host need not wait for the first pass before it launches this one.  (Tried and dropped: a
-// search that cuts the range in sixteen or in four per step with the pivots' loads in flight
-// together, also starting from the row that bytes / mean row length suggests; fewer round
-// trips, but more cache lines per occurrence, and twice as slow as the plain binary search.)
+// Pass 2: one thread per occurrence finds its row by binary search over the offsets.  The
+// number of occurrences is read on the device, so the host need not wait for the first pass
+// before it launches this one.  What bounds the search is the cache lines it brings in that
+// nobody else wants: the upper levels of the search are the same few lines for every
+// occurrence of a segment.  (Tried and dropped, all slower, 0.23 to 0.40 ms against 0.156:
+// cutting the range in sixteen or in four per step with the pivots' loads in flight together;
+// four occurrences per thread searched in step; starting from two probes around the row that
+// the occurrence's share of the segment's bytes suggests -- fewer loads or more of them in
+// flight, but more lines of their own per occurrence.)
 __global__ __launch_bounds__(kBlock) void k_contains_mark(const ContainsSeg* segs, const uint64_t* matches,
                                                          const unsigned long long* n_matches, uint64_t capacity,
                                                          uint32_t L, uint64_t* bits) {
