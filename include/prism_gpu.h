@@ -202,6 +202,8 @@ void prism_gpu_ctx_free(prism_gpu_ctx* ctx);
  *                    before it is aggregated (default 4194304)
  *   "part_force"     1: partition whenever the plan's shape allows it, without waiting for
  *                    the streaming kernel to report that its rows scatter (default 0)
+ *   "part_half_blocks" 0: the scatter pass of a partitioned GROUP BY always runs one workgroup of
+ *                    1024 threads per CU; 1 (default): two of 512 threads where the records allow it
  *   "part2_compact"  0: COUNT(DISTINCT) partitioned twice always keeps two-word records at the
  *                    second level; 1 (default): one-word records when the pairs allow it
  *   "contains_windows" 0: LIKE '%needle%' over a column without a dictionary always uses the

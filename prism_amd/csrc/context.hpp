@@ -67,6 +67,7 @@ struct prism_gpu_ctx {
   // ---- tuning (prism_gpu_set_option) ----
   std::atomic<uint64_t> part_min_rows{1ull << 22};  // fewer selected rows: never partition a GROUP BY
   std::atomic<int> part_force{0};                    // 1: partition whenever the plan shape allows it
+  std::atomic<int> part_half_blocks{1};              // 0: the scatter pass of a partitioned GROUP BY always runs one 1024-thread workgroup per CU
   std::atomic<int> part2_compact{1};                 // 0: the second partition level of COUNT(DISTINCT) always keeps two-word records
   std::atomic<int> contains_windows{1};              // 0: substring search always by the byte-wise prefilter
 

@@ -1128,7 +1128,8 @@ uint64_t partitioned_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, AggParam
   std::memset(&q, 0, sizeof(q));
   q.p_bits = p_bits;
   q.n_buckets = P;
-  q.n_wg = part_scan_workgroups(ctx, ap, &q.tiles_per_wg);
+  q.half_blocks = (ctx->part_half_blocks.load(std::memory_order_relaxed) != 0 && part_scatter_halves(words, P)) ? 1 : 0;
+  q.n_wg = part_scan_workgroups(ctx, ap, &q.tiles_per_wg, q.half_blocks != 0);
   // A bucket of more than 4 times the average holds a heavy hitter and is aggregated in
   // slices, by several workgroups, that meet in the HBM table.  (Slices are kept large: every
   // slice sends each of the bucket's ordinary keys it has seen to the HBM table.)
@@ -1335,8 +1336,11 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, const AggParams& ap, uint64_t sele
   const int words = part_record_words(ap, false);
   if (words != 2 || selected == 0 || selected >= (1ull << 32)) return false;
   // coarse buckets of about half a million rows, fine buckets of about a quarter of the LDS set
+  // (at most 1024 of them while the scatter pass can run two half-size workgroups per CU: the
+  // counters of 2048 buckets next to two tiles do not fit the LDS)
+  const int p1_most = ctx->part_half_blocks.load(std::memory_order_relaxed) != 0 && part_scatter_halves(words, 1024) ? 10 : 11;
   int p1 = 6;
-  while (p1 < 11 && (selected >> p1) > (1ull << 19)) ++p1;
+  while (p1 < p1_most && (selected >> p1) > (1ull << 19)) ++p1;
   if ((1u << p1) > part_max_buckets(words)) return false;
   // (a fine bucket of up to half the set's entries is taken in one go; larger ones, in the
   // coarse buckets of very frequent groups, in several passes)
@@ -1359,7 +1363,7 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, const AggParams& ap, uint64_t sele
     int c1 = p1, c2 = fine_bits(c1, part2_lds_entries(true));
     int most = 0;  // log2 of the coarse buckets the first level can take
     while ((2u << most) <= part_max_buckets(words)) ++most;
-    const int top1 = std::min<int>({11, hi_bits, most});
+    const int top1 = std::min<int>({p1_most, hi_bits, most});
     auto excess = [&]() { return lo_bits + hi_bits - 63 - c1 - c2; };
     while (c2 >= 0 && c1 < top1 && (excess() > 0 || hi_bits - c1 > 9)) {
       ++c1;
@@ -1379,7 +1383,8 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, const AggParams& ap, uint64_t sele
   std::memset(&q1, 0, sizeof(q1));
   q1.p_bits = p1;
   q1.n_buckets = P1;
-  q1.n_wg = part_scan_workgroups(ctx, ap, &q1.tiles_per_wg);
+  q1.half_blocks = (ctx->part_half_blocks.load(std::memory_order_relaxed) != 0 && part_scatter_halves(words, P1)) ? 1 : 0;
+  q1.n_wg = part_scan_workgroups(ctx, ap, &q1.tiles_per_wg, q1.half_blocks != 0);
   q1.chunk_rows = 1u << 30;
   q1.max_items = P1 + 4;
   q1.lds_entries = part_lds_entries(ap);

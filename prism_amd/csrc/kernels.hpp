@@ -252,13 +252,16 @@ struct PartParams {
   uint32_t* queue;         // next item of the aggregation pass (starts at 0)
   int32_t by_hi;           // two-word keys: the bucket follows from the high word alone
   int32_t hi_bits;         // by_hi: > 0 = the bucket is the top p_bits of bij_mix(high word, hi_bits), 0 = of a hash
+  int32_t half_blocks;     // the scatter pass runs workgroups of 512 threads, two per CU (n_wg is sized for that)
 };
 // 8-byte words of a row's record for this plan shape (key words + value columns + one word
 // of validity bits when a value column has NULLs); 0: the shape has no partitioned kernels.
 int part_record_words(const AggParams& p, bool vals_nullable);
 uint32_t part_max_buckets(int words);
 uint32_t part_lds_entries(const AggParams& p);
-uint32_t part_scan_workgroups(prism_gpu_ctx* ctx, const AggParams& p, uint32_t* tiles_per_wg);
+// Whether the scatter pass can run two workgroups of 512 threads per CU for this record width and bucket count.
+bool part_scatter_halves(int words, uint32_t n_buckets);
+uint32_t part_scan_workgroups(prism_gpu_ctx* ctx, const AggParams& p, uint32_t* tiles_per_wg, bool two_per_cu = false);
 // (hist_bytes, scatter_bytes, agg_bytes: algorithmic bytes of the three passes, for the statistics)
 // scatter_only: stop once the records lie sorted by bucket (q.rec, q.bucket_base); nothing is aggregated.
 void launch_partitioned_group_by(prism_gpu_ctx* ctx, const AggParams& p, const PartParams& q, bool vals_nullable,

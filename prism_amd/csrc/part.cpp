@@ -27,7 +27,10 @@ prism_gpu_ctx* ctx_acquire_child(prism_gpu_ctx* parent) {
       c->part_min_rows.store(parent->part_min_rows.load());
       c->part_force.store(parent->part_force.load());
   c->part2_compact.store(parent->part2_compact.load());
+  c->part_half_blocks.store(parent->part_half_blocks.load());
       c->part2_compact.store(parent->part2_compact.load());
+  c->part_half_blocks.store(parent->part_half_blocks.load());
+      c->part_half_blocks.store(parent->part_half_blocks.load());
       return c;
     }
   }
@@ -42,6 +45,7 @@ prism_gpu_ctx* ctx_acquire_child(prism_gpu_ctx* parent) {
   c->part_min_rows.store(parent->part_min_rows.load());
   c->part_force.store(parent->part_force.load());
   c->part2_compact.store(parent->part2_compact.load());
+  c->part_half_blocks.store(parent->part_half_blocks.load());
   PRISM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   PRISM_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
   return c.release();

@@ -181,8 +181,16 @@ def test_values_and_nulls_travel_with_the_records(part_ctx, oracle):
 
 
 def test_two_word_keys_and_count_distinct(part_ctx, oracle):
+    """Two-word records: the scatter pass with two workgroups of 512 threads per CU (the
+    default where the shape allows it), then with one of 1024."""
     wl = workloads.c5(n_services=16, user_bits=14)
-    _synth_both(part_ctx, oracle, wl, 1_500_000, 4, [(wl.query, 2)])
+    plain = QueryPlan([count_star()], keys=["user", "service"])  # two-word keys, no COUNT(DISTINCT)
+    try:
+        for halves in (1, 0):
+            part_ctx.set_option("part_half_blocks", halves)
+            _synth_both(part_ctx, oracle, wl, 1_500_000, 4, [(wl.query, 2), (plain, 2)])
+    finally:
+        part_ctx.set_option("part_half_blocks", 1)
 
 
 def test_count_distinct_partitioned_twice(part_ctx, oracle):
