@@ -1331,8 +1331,8 @@ uint64_t distinct_emit_outer(prism_gpu_ctx* ctx, const prism_gpu_plan* plan, con
 // bucket into fine buckets by a hash of the pair, and the fine buckets are deduplicated in
 // LDS and counted per group into `outer`.  False: a fine bucket did not fit (very uneven
 // data) or the outer table overflowed; nothing usable was produced.
-bool partitioned_distinct(prism_gpu_ctx* ctx, const AggParams& ap, uint64_t selected, uint64_t key_bytes, const KeyLayout& layout,
-                          GroupTable& outer) {
+bool partitioned_distinct(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggParams& ap, uint64_t selected, uint64_t key_bytes,
+                          const KeyLayout& layout, GroupTable& outer) {
   const int words = part_record_words(ap, false);
   if (words != 2 || selected == 0 || selected >= (1ull << 32)) return false;
   // coarse buckets of about half a million rows, fine buckets of about a quarter of the LDS set
@@ -1344,8 +1344,15 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, const AggParams& ap, uint64_t sele
   if ((1u << p1) > part_max_buckets(words)) return false;
   // (a fine bucket of up to half the set's entries is taken in one go; larger ones, in the
   // coarse buckets of very frequent groups, in several passes)
+  // Rows that repeat a pair need no entry: when the plan's last run found that only a share
+  // of the rows were distinct pairs, a fine bucket may hold that many more rows (at most four
+  // times as many; half as many again are assumed distinct as were, and the last pass falls
+  // back to several passes per bucket should a bucket's pairs crowd its set all the same).
+  // Fewer, larger fine buckets mean longer runs out of the second scatter pass.
+  const uint32_t seen = plan->distinct_pairs_per_1024.load(std::memory_order_relaxed);
+  const uint64_t rows_per_entry_x8 = seen ? std::min<uint64_t>(32, std::max<uint64_t>(8, 8 * 1024 * 2 / (3 * (uint64_t)seen))) : 8;
   auto fine_bits = [&](int coarse_bits, uint32_t entries) {
-    const uint64_t fine_rows = (uint64_t)entries * 3 / 8;
+    const uint64_t fine_rows = (uint64_t)entries * 3 / 8 * rows_per_entry_x8 / 8;
     int b = 0;
     while (b < 10 && (selected >> (coarse_bits + b)) > fine_rows) ++b;
     return (selected >> (coarse_bits + b)) > fine_rows ? -1 : b;
@@ -1442,14 +1449,21 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, const AggParams& ap, uint64_t sele
   q2.overflow = outer.overflow.as<uint32_t>();
   q2.queue = (uint32_t*)(d_small.as<uint8_t>() + 32);
   q2.flags = (uint32_t*)(d_small.as<uint8_t>() + 40);
+  q2.pairs = compact ? (unsigned long long*)(d_small.as<uint8_t>() + 64) : nullptr;  // [64, 128) of the block
   launch_distinct_second_level(ctx, q2);
-  uint32_t flag = 0;
-  PRISM_HIP(hipMemcpyAsync(&flag, q2.flags, 4, hipMemcpyDeviceToHost, ctx->stream));
+  struct { uint32_t flags[2]; uint64_t pad[2]; unsigned long long pairs[8]; } h{};
+  static_assert(sizeof(h) == 88, "layout of the small block from offset 40 on");
+  PRISM_HIP(hipMemcpyAsync(&h, q2.flags, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
   PRISM_HIP(hipStreamSynchronize(ctx->stream));
   collect_timings(ctx);
-  if (flag != 0 || table_overflowed(ctx, outer)) {
+  if (h.flags[0] != 0 || table_overflowed(ctx, outer)) {
     outer = GroupTable();
     return false;
+  }
+  if (compact) {
+    unsigned long long pairs = 0;
+    for (unsigned long long v : h.pairs) pairs += v;
+    plan->distinct_pairs_per_1024.store((uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, pairs * 1024 / selected)), std::memory_order_relaxed);
   }
   return true;
 }
@@ -1996,7 +2010,7 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
     if (plan->distinct_plan && layout.words == 2 && !partial && !capture && part_ok && ap.n_pred == 0 &&
         selected >= (part_forced(ctx) ? 1ull : (1ull << 24)) && plan->part_mode.load(std::memory_order_relaxed) >= 0) {
       KernelTimer timer(ctx, "group_by", ss.rows * value_bytes);
-      outer_ready = partitioned_distinct(ctx, ap, selected, key_bytes, layout, outer_q);
+      outer_ready = partitioned_distinct(ctx, plan, ap, selected, key_bytes, layout, outer_q);
       if (!outer_ready) plan->part_mode.store(-1, std::memory_order_relaxed);  // uneven data: the one-table way from now on
     }
     if (use_part && !outer_ready) {

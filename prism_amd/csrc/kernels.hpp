@@ -299,6 +299,7 @@ struct Part2Params {
   // | low rest, below 2^63.  out_hi is unused then.  Needs p1_bits <= hi_bits <= p1_bits + 9,
   // p2_bits <= lo_bits, lo_bits - p2_bits + hi_bits - p1_bits <= 63 and no NULL bit in x.
   int32_t compact, lo_bits, hi_bits;
+  unsigned long long* pairs;    // [8] (one-word records): distinct pairs counted, as eight partial sums; may be null
 };
 uint32_t part2_lds_entries(bool compact);
 void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q);

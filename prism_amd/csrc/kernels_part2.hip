@@ -372,6 +372,7 @@ __global__ __launch_bounds__(kP2AggBlock) void k_part2_agg_compact(Part2Params q
   const int lo_rest = q.lo_bits - (int)q.p2_bits, hi_rest = q.hi_bits - (int)q.p1_bits;
   const uint32_t n_groups = 1u << hi_rest;  // <= kP2Groups
   unsigned long long* keys = p2_lds;
+  unsigned long long my_pairs = 0;  // distinct pairs this thread handed to the outer table
   for (uint32_t i = tid; i < kP2Groups; i += kP2AggBlock) gcnt[i] = 0;
   for (uint32_t f = blockIdx.x; f < n_fine; f += gridDim.x) {
     __syncthreads();
@@ -428,8 +429,19 @@ __global__ __launch_bounds__(kP2AggBlock) void k_part2_agg_compact(Part2Params q
 #pragma unroll
         for (uint32_t j = 0; j < kBatch; ++j)
           if (b0 + tid + j * kP2AggBlock < b1) take(b[j], pass);
-        for (uint32_t i = b0 + tid + kBatch * kP2AggBlock; i < b1; i += kP2AggBlock)
-          take(__builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.out_lo + i)), pass);
+        // (what lies beyond the first rows is fetched once per pass, again a batch at a time so
+        // that a thread waits for memory once per batch)
+        for (uint32_t base = b0 + kBatch * kP2AggBlock; base < b1; base += kBatch * kP2AggBlock) {
+          uint64_t more[kBatch];
+#pragma unroll
+          for (uint32_t j = 0; j < kBatch; ++j) {
+            const uint32_t i = base + tid + j * kP2AggBlock, ic = i < b1 ? i : b0;
+            more[j] = __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.out_lo + ic));
+          }
+#pragma unroll
+          for (uint32_t j = 0; j < kBatch; ++j)
+            if (base + tid + j * kP2AggBlock < b1) take(more[j], pass);
+        }
       }
       __syncthreads();
       if (passes > 1 || !crowded) break;
@@ -444,6 +456,7 @@ __global__ __launch_bounds__(kP2AggBlock) void k_part2_agg_compact(Part2Params q
       const uint32_t c = gcnt[i];
       if (c == 0) continue;
       gcnt[i] = 0;
+      my_pairs += c;
       const uint64_t hi = bij_unmix((coarse << hi_rest) | i, q.hi_bits);
       const uint64_t e = global_entry_raw(q.dense, q.capacity, q.g_keys, q.overflow, hi);
       if (e != ~0ull) {
@@ -452,6 +465,18 @@ __global__ __launch_bounds__(kP2AggBlock) void k_part2_agg_compact(Part2Params q
         atomicAdd((unsigned long long*)&q.g_state[(q.capacity + 1) + e], (unsigned long long)c);
       }
     }
+  }
+  // the distinct pairs of the whole query, for the sizing of the next run's fine buckets: one
+  // update per workgroup, spread over eight words
+  if (q.pairs) {
+    __shared__ unsigned long long wg_pairs;
+    __syncthreads();
+    if (tid == 0) wg_pairs = 0;
+    __syncthreads();
+    const unsigned long long w = wave_sum_u64(my_pairs);
+    if ((tid & 63u) == 0 && w) atomicAdd(&wg_pairs, w);
+    __syncthreads();
+    if (tid == 0 && wg_pairs) atomicAdd(&q.pairs[blockIdx.x & 7u], wg_pairs);
   }
 }
 
