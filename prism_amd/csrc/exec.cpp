@@ -540,7 +540,11 @@ struct PredEval {
                                      bits.as<uint64_t>());
             }
           }
-          launch_mask_validity(ctx, ss.desc, ss.col(col), n.negated, bits.as<uint64_t>());
+          // NULL rows are not TRUE, and NOT LIKE flips the rest: nothing to do for a plain LIKE
+          // over chunks without a validity bitmap
+          bool any_validity = false;
+          for (const Chunk* ch : ss.chunks) any_validity = any_validity || ch->cols[n.column].validity != nullptr;
+          if (n.negated || any_validity) launch_mask_validity(ctx, ss.desc, ss.col(col), n.negated, bits.as<uint64_t>());
           return bits;
         }
         const uint8_t* d_toks = to_device(toks.data(), toks.size() * sizeof(LikeToken));
