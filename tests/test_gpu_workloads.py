@@ -4,6 +4,7 @@ generation of the same rows; plus the high-cardinality string (ClickBench URL-li
 path, where no dictionary exists and the raw-string kernels run."""
 import numpy as np
 import pyarrow as pa
+import pyarrow.compute as pc
 import pytest
 
 from tests import helpers
@@ -312,6 +313,64 @@ def test_full_size_c2_invariants(gpu_ctx):
         assert a + b == rows and abs(a / rows - (1 - 12_345 / 50_000)) < 1e-3
     finally:
         table.close()
+
+
+def test_large_c5_same_counts_on_every_route(oracle):
+    """C5's query over 2.5e8 rows (large enough for the pairs to be partitioned twice), checked
+    without the CPU: the distinct counts are the same whether the second partition level keeps
+    one-word or two-word records, whether the scatter pass runs workgroups of 512 or of 1024
+    threads, and when nothing is partitioned at all (one set of pairs in HBM, a different
+    algorithm altogether); no group has more distinct users than rows; and a sample of the
+    table agrees with the CPU checker."""
+    from prism_amd.engine import Context, Plan
+
+    wl = workloads.c5()
+    rows, parts = 250_000_000, 16
+    ctx = Context(0)
+    table = workloads.build_gpu_table(ctx, wl, 0, rows, rows, parts)
+
+    def run(q, partitions=None):
+        plan = Plan(ctx, wl.schema, q)
+        try:
+            ctx.reset_stats()
+            out = plan.execute(table, partitions)
+            return out, {k for k, v in ctx.stats()["kernels"].items() if v["launches"]}
+        finally:
+            plan.close()
+
+    def sort(t):
+        return t.take(pc.sort_indices(t, [(t.schema.names[0], "ascending"), (t.schema.names[1], "ascending")]))
+
+    try:
+        base, ran = run(wl.query)
+        assert "part2_agg" in ran
+        base = sort(base)
+        for name, value in (("part2_compact", 0), ("part_half_blocks", 0)):
+            ctx.set_option(name, value)
+            other, ran = run(wl.query)
+            ctx.set_option(name, 1)
+            assert "part2_agg" in ran
+            assert sort(other).equals(base), name
+        ctx.set_option("part_min_rows", 1 << 40)  # nothing is partitioned: the pairs go into one table in HBM
+        other, ran = run(wl.query)
+        ctx.set_option("part_min_rows", 4_194_304)
+        assert "part2_agg" not in ran and sort(other).equals(base)
+        counts, _ = run(QueryPlan([count_star()], keys=wl.query.keys))
+        counts = sort(counts)
+        assert counts.column(0).equals(base.column(0)) and counts.column(1).equals(base.column(1))
+        distinct = np.array(base.column(2).to_pylist(), dtype=np.int64)
+        n = np.array(counts.column(2).to_pylist(), dtype=np.int64)
+        assert n.sum() == rows and (distinct >= 1).all() and (distinct <= n).all()
+        # the first partition against the CPU checker
+        got, _ = run(wl.query, range(1))
+        st = oracle.SynthTable(wl.schema, wl.make_cols(), wl.seed, 0, workloads.partition_bounds(rows, parts, 0)[1], rows,
+                               n_parts=8, threads=8)
+        want, _ = st.execute(wl.query, threads=8)
+        st.close()
+        assert_tables_match(got, workloads.decode_dictionary_columns(wl, want), 2)
+    finally:
+        table.close()
+        ctx.close()
 
 
 def test_full_size_c1_and_c3_invariants(gpu_ctx):
