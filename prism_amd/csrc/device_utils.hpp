@@ -65,7 +65,10 @@ __device__ __forceinline__ uint64_t part_hash_hi(uint64_t hi) { return hash64(hi
 // are as even as a hash's, and -- unlike with a hash -- a value's bucket and the remaining
 // low bits together still identify the value, so a record that lies in a bucket need not
 // repeat the bits the bucket stands for.
+// (Widths of up to 32 bits -- group keys -- are mixed in 32-bit arithmetic: a 64-bit multiply
+// is half a dozen instructions on this part, and these run once or twice per row.)
 constexpr uint64_t kBijMul1 = 0x9E3779B97F4A7C15ull, kBijMul2 = 0xD6E8FEB86659FD93ull;
+constexpr uint32_t kBijMul1w = 0x9E3779B1u, kBijMul2w = 0x85EBCA6Bu;
 constexpr uint64_t odd_inverse64(uint64_t a) {
   uint64_t x = a;  // correct to 3 bits; every step doubles that
   for (int i = 0; i < 5; ++i) x *= 2 - a * x;
@@ -73,8 +76,17 @@ constexpr uint64_t odd_inverse64(uint64_t a) {
 }
 __host__ __device__ __forceinline__ uint64_t bij_mix(uint64_t v, int bits) {
   if (bits <= 0) return 0;
-  const uint64_t mask = (1ull << bits) - 1ull;
   const int s = (bits + 1) / 2;
+  if (bits <= 32) {
+    const uint32_t m = bits == 32 ? 0xffffffffu : (1u << bits) - 1u;
+    uint32_t x = (uint32_t)v;
+    x = (x * kBijMul1w) & m;
+    x ^= x >> s;
+    x = (x * kBijMul2w) & m;
+    x ^= x >> s;
+    return x;
+  }
+  const uint64_t mask = (1ull << bits) - 1ull;
   v = (v * kBijMul1) & mask;
   v ^= v >> s;
   v = (v * kBijMul2) & mask;
@@ -83,8 +95,17 @@ __host__ __device__ __forceinline__ uint64_t bij_mix(uint64_t v, int bits) {
 }
 __host__ __device__ __forceinline__ uint64_t bij_unmix(uint64_t v, int bits) {
   if (bits <= 0) return 0;
-  const uint64_t mask = (1ull << bits) - 1ull;
   const int s = (bits + 1) / 2;
+  if (bits <= 32) {
+    const uint32_t m = bits == 32 ? 0xffffffffu : (1u << bits) - 1u;
+    uint32_t x = (uint32_t)v;
+    x ^= x >> s;
+    x = (x * (uint32_t)odd_inverse64(kBijMul2w)) & m;
+    x ^= x >> s;
+    x = (x * (uint32_t)odd_inverse64(kBijMul1w)) & m;
+    return x;
+  }
+  const uint64_t mask = (1ull << bits) - 1ull;
   v ^= v >> s;
   v = (v * odd_inverse64(kBijMul2)) & mask;
   v ^= v >> s;

@@ -1349,12 +1349,13 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggPar
   // (a fine bucket of up to half the set's entries is taken in one go; larger ones, in the
   // coarse buckets of very frequent groups, in several passes)
   // Rows that repeat a pair need no entry: when the plan's last run found that only a share
-  // of the rows were distinct pairs, a fine bucket may hold that many more rows (at most four
-  // times as many; half as many again are assumed distinct as were, and the last pass falls
-  // back to several passes per bucket should a bucket's pairs crowd its set all the same).
-  // Fewer, larger fine buckets mean longer runs out of the second scatter pass.
+  // of the rows were distinct pairs, a fine bucket may hold as many more rows as keeps its
+  // expected distinct pairs where they would be if every row were one (at most four times as
+  // many rows; the last pass falls back to several passes per bucket should a bucket's pairs
+  // crowd its set all the same, and the share is learnt anew on every run).  Fewer, larger
+  // fine buckets mean longer runs out of the second scatter pass and less work per bucket.
   const uint32_t seen = plan->distinct_pairs_per_1024.load(std::memory_order_relaxed);
-  const uint64_t rows_per_entry_x8 = seen ? std::min<uint64_t>(32, std::max<uint64_t>(8, 8 * 1024 * 2 / (3 * (uint64_t)seen))) : 8;
+  const uint64_t rows_per_entry_x8 = seen ? std::min<uint64_t>(32, std::max<uint64_t>(8, 8 * 1024 / (uint64_t)seen)) : 8;
   auto fine_bits = [&](int coarse_bits, uint32_t entries) {
     const uint64_t fine_rows = (uint64_t)entries * 3 / 8 * rows_per_entry_x8 / 8;
     int b = 0;

@@ -53,6 +53,24 @@ __device__ __forceinline__ long long part_widen(unsigned long long raw, int widt
   return is_unsigned ? (long long)(uint16_t)raw : (long long)(int16_t)(uint16_t)raw;
 }
 
+// A key column's field of the packed key, before it is shifted into place: value - bias, or
+// for date_bin the bucket number - bias.  Keys whose values span less than 2^32 (KeySpec::
+// fast32) take the 32-bit form, (uint32)(value - base) / stride with a 32-bit multiply-high: the
+// 64-bit date_bin is some 25 instructions a row, and these kernels run it once per pass.
+__device__ __forceinline__ uint64_t part_field(const KeySpec& ks, unsigned long long raw) {
+  if (ks.fast32) {
+    uint32_t f = (uint32_t)part_widen(raw, ks.width, ks.is_unsigned) - (uint32_t)ks.base;
+    if (ks.date_bin) {
+      const uint32_t q = __umulhi(ks.magic32, f);
+      f = (((f - q) >> ks.pre32) + q) >> ks.shift32;
+    }
+    return f;
+  }
+  long long v = part_widen(raw, ks.width, ks.is_unsigned);
+  if (ks.date_bin) v = bucket_number(v, ks);
+  return (uint64_t)v - (uint64_t)ks.bias;
+}
+
 template <int KW>
 __device__ __forceinline__ uint64_t part_hash(uint64_t lo, uint64_t hi) {
   return KW == 2 ? hash64(lo ^ hash64(hi)) : hash64(lo);
@@ -175,9 +193,7 @@ __device__ __forceinline__ void part_load_keys(const AggParams& p, const PartTil
 #pragma unroll
       for (int i = 0; i < B; ++i) {
         const int r = r0 + i;
-        long long v = part_widen(raw[i], ks.width, ks.is_unsigned);
-        if (ks.date_bin) v = bucket_number(v, ks);
-        const uint64_t field = ((ok >> i) & 1u) ? (((uint64_t)v - (uint64_t)ks.bias) << ks.bit_pos) : (1ull << (ks.null_bit >= 0 ? ks.null_bit : 0));
+        const uint64_t field = ((ok >> i) & 1u) ? (part_field(ks, raw[i]) << ks.bit_pos) : (1ull << (ks.null_bit >= 0 ? ks.null_bit : 0));
         if (KW == 2 && ks.word) hi[r] |= field; else lo[r] |= field;
       }
     }
@@ -291,9 +307,7 @@ __device__ __forceinline__ void part_finish(const AggParams& p, const unsigned l
     const KeySpec& ks = p.keys[k];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      long long v = part_widen(raw[k][r], ks.width, ks.is_unsigned);
-      if (ks.date_bin) v = bucket_number(v, ks);
-      const uint64_t field = ((uint64_t)v - (uint64_t)ks.bias) << ks.bit_pos;
+      const uint64_t field = part_field(ks, raw[k][r]) << ks.bit_pos;
       if (KW == 2 && ks.word) hi[r] |= field; else lo[r] |= field;
     }
   }

@@ -48,14 +48,22 @@ __device__ __forceinline__ uint32_t span_of(const Part2Params& q) {
   const uint32_t s = kP2Counters >> q.p2_bits;
   return s < kP2MaxSpan ? s : kP2MaxSpan;
 }
-// Compact form: the low word mixed by a bijection and then XORed with a hash of the high
+// Compact form: the low word times an odd constant (a bijection modulo 2^lo_bits whose top
+// bits depend on every bit of the word), its upper 32 bits then XORed with a hash of the high
 // word -- still a bijection of the low word for any one high word, which is all a record
 // needs, and a value of x that is frequent in many groups lands in a different sub-bucket
 // for each of them.  (Without the XOR the rows of the most frequent x met in ONE sub-bucket
 // of every coarse bucket, six times the average size, and the workgroups that those fell to
-// made the last pass six times as long.)
+// made the last pass six times as long.)  One 64-bit multiply and two 32-bit ones; the first
+// version (two 64-bit multiplies and a 64-bit hash, computed in the scatter pass twice)
+// spent more instructions on mixing than on everything else.
 __device__ __forceinline__ uint64_t mixed_lo(const Part2Params& q, uint64_t lo, uint64_t hi) {
-  return bij_mix(lo, q.lo_bits) ^ (hash64(hi ^ 0x2545F4914F6CDD1Dull) & ((1ull << q.lo_bits) - 1ull));
+  const uint64_t t = (lo * kBijMul1) & ((1ull << q.lo_bits) - 1ull);
+  uint32_t h = ((uint32_t)hi ^ (uint32_t)(hi >> 32) * 0x85EBCA6Bu) * 0x7FEB352Du;
+  h = (h ^ (h >> 15)) * 0x846CA68Bu;
+  h ^= h >> 16;
+  const uint64_t mask = q.lo_bits >= 32 ? (uint64_t)h << (q.lo_bits - 32) : (uint64_t)(h >> (32 - q.lo_bits));
+  return t ^ mask;
 }
 __device__ __forceinline__ uint32_t sub_of(const Part2Params& q, uint64_t lo, uint64_t hi) {
   if (q.compact) return (uint32_t)(mixed_lo(q, lo, hi) >> (q.lo_bits - (int)q.p2_bits));
@@ -176,7 +184,17 @@ __global__ __launch_bounds__(kP2Block) void k_part2_scatter(Part2Params q) {
       hi[r] = __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.in_hi + ic));
       where[r] = ~0u;
       if (!in) continue;
-      const uint32_t c = coarse_of(q, hi[r]), s = sub_of(q, lo[r], hi[r]);
+      uint32_t c, s;
+      if (q.compact) {
+        // from here on the record is its two mixed words: the copy-out then only shifts and masks
+        lo[r] = mixed_lo(q, lo[r], hi[r]);
+        hi[r] = bij_mix(hi[r], q.hi_bits);
+        c = (uint32_t)(hi[r] >> (q.hi_bits - (int)q.p1_bits));
+        s = (uint32_t)(lo[r] >> (q.lo_bits - (int)q.p2_bits));
+      } else {
+        c = coarse_of(q, hi[r]);
+        s = sub_of(q, lo[r], hi[r]);
+      }
       if (c - c0 < span) {
         const uint32_t li = (c - c0) * n_sub + s;
         where[r] = li | (atomicAdd(&cnt[li], 1u) << 12);
@@ -185,7 +203,8 @@ __global__ __launch_bounds__(kP2Block) void k_part2_scatter(Part2Params q) {
         const uint32_t g = atomicAdd(&q.fine_cursor[((uint64_t)c << q.p2_bits) | s], 1u);
         if (g < q.n_rows) {
           if (q.compact) {
-            q.out_lo[g] = compact_record(q, lo[r], hi[r]);
+            const int lo_rest = q.lo_bits - (int)q.p2_bits, hi_rest = q.hi_bits - (int)q.p1_bits;
+            q.out_lo[g] = ((hi[r] & ((1ull << hi_rest) - 1ull)) << lo_rest) | (lo[r] & ((1ull << lo_rest) - 1ull));
           } else {
             q.out_lo[g] = lo[r];
             q.out_hi[g] = hi[r];
@@ -214,7 +233,7 @@ __global__ __launch_bounds__(kP2Block) void k_part2_scatter(Part2Params q) {
     if (q.compact) {
       const int lo_rest = q.lo_bits - (int)q.p2_bits, hi_rest = q.hi_bits - (int)q.p1_bits;
       for (uint32_t i = threadIdx.x; i < n_live; i += kP2Block) {
-        const uint64_t tl = mixed_lo(q, s_lo[i], s_hi[i]), th = bij_mix(s_hi[i], q.hi_bits);
+        const uint64_t tl = s_lo[i], th = s_hi[i];  // (staged mixed)
         const uint32_t li = ((uint32_t)(th >> hi_rest) - c0) * n_sub + (uint32_t)(tl >> lo_rest);
         const uint32_t g = base[li] + (i - lstart[li]);
         if (g < q.n_rows) q.out_lo[g] = ((th & ((1ull << hi_rest) - 1ull)) << lo_rest) | (tl & ((1ull << lo_rest) - 1ull));
