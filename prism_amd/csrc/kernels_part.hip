@@ -83,9 +83,11 @@ __device__ __forceinline__ uint64_t part_hash(uint64_t lo, uint64_t hi) {
 // hi_bits bits when the second level stores only what its buckets do not imply.
 // (by_hi with one-word keys: the histogram pass of such a partition, run over the high word's
 // columns alone, whose packed value then is the one word.)
-template <int KW>
+// (HIST: only the histogram kernel of one-word keys looks at by_hi; the other one-word
+// kernels never see such a partition and are spared the branch and its registers.)
+template <int KW, bool HIST = false>
 __device__ __forceinline__ uint64_t part_bucket_hash(const PartParams& q, uint64_t lo, uint64_t hi) {
-  if (q.by_hi) {
+  if ((KW == 2 || HIST) && q.by_hi) {
     const uint64_t group = KW == 2 ? hi : lo;
     return q.hi_bits > 0 ? bij_mix(group, q.hi_bits) << (64 - q.hi_bits) : part_hash_hi(group);
   }
@@ -305,10 +307,27 @@ __device__ __forceinline__ void part_finish(const AggParams& p, const unsigned l
 #pragma unroll
   for (int k = 0; k < NK; ++k) {
     const KeySpec& ks = p.keys[k];
+    // (the choice between the 32-bit and the 64-bit form is made once per column, outside the
+    // rows: inside, both forms' temporaries were live and cost the one-word scatter kernel spills)
+    if (ks.fast32) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const uint64_t field = part_field(ks, raw[k][r]) << ks.bit_pos;
-      if (KW == 2 && ks.word) hi[r] |= field; else lo[r] |= field;
+      for (int r = 0; r < R; ++r) {
+        uint32_t f = (uint32_t)part_widen(raw[k][r], ks.width, ks.is_unsigned) - (uint32_t)ks.base;
+        if (ks.date_bin) {
+          const uint32_t q = __umulhi(ks.magic32, f);
+          f = (((f - q) >> ks.pre32) + q) >> ks.shift32;
+        }
+        const uint64_t field = (uint64_t)f << ks.bit_pos;
+        if (KW == 2 && ks.word) hi[r] |= field; else lo[r] |= field;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        long long v = part_widen(raw[k][r], ks.width, ks.is_unsigned);
+        if (ks.date_bin) v = bucket_number(v, ks);
+        const uint64_t field = ((uint64_t)v - (uint64_t)ks.bias) << ks.bit_pos;
+        if (KW == 2 && ks.word) hi[r] |= field; else lo[r] |= field;
+      }
     }
   }
 #pragma unroll
@@ -430,7 +449,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_hist(AggParams p, PartParam
     }
 #pragma unroll
     for (int r = 0; r < R; ++r)
-      if ((live >> r) & 1u) atomicAdd(&h[(uint32_t)(part_bucket_hash<KW>(q, lo[r], hi[r]) >> shift)], 1u);
+      if ((live >> r) & 1u) atomicAdd(&h[(uint32_t)(part_bucket_hash<KW, true>(q, lo[r], hi[r]) >> shift)], 1u);
   }
   __syncthreads();
   for (uint32_t b = tid; b < P; b += kPartBlock) q.hist[(uint64_t)blockIdx.x * P + b] = h[b];
