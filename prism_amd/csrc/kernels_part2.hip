@@ -418,36 +418,52 @@ __global__ __launch_bounds__(kP2AggBlock) void k_part2_agg_compact(Part2Params q
       // the part of the set in use (cleared before every pass): at least twice the rows a
       // pass may bring, so that small buckets do not pay for clearing the whole table
       const uint32_t want = large ? S : n * 5 / 2 + 64;
-      const uint32_t Sb = want < S ? want : S;
-      const uint32_t probe_limit = (large && passes == 1) ? 96u : Sb;
+      const uint32_t Sb = (want < S ? want : S) & ~1u;
+      const uint32_t probe_limit = (large && passes == 1) ? 64u : Sb;
+      // Buckets of two entries, read with one 16-byte load: a wave's look-up takes as many
+      // steps as its slowest lane, and with single entries and linear probing that was five
+      // or six steps a row at a third load.  A record sits in the first bucket on its path
+      // that had a free entry when it came; entries are never removed, so a bucket with a
+      // free entry ends every search, and a free entry is only ever claimed by compare-and-swap.
+      // (Reading the home buckets of a thread's eight rows ahead, so that the LDS latencies
+      // overlap, made the pass slower, 7.5 -> 10.7 ms: rows that repeat a frequent pair then
+      // all see its entry still free and fight over it.)
+      const uint32_t nb = Sb >> 1;
       auto take = [&](uint64_t rec, uint32_t pass) {
         uint32_t h = ((uint32_t)rec ^ (uint32_t)(rec >> 32) * 0x85EBCA6Bu);
         h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
         if (passes > 1 && (uint32_t)(hash64(rec * 0xD6E8FEB86659FD93ull) >> 33) % passes != pass) return;
-        uint32_t idx = __umulhi(h, Sb);
+        uint32_t bkt = __umulhi(h, nb);
         for (uint32_t probes = 0; probes < probe_limit; ++probes) {
-          unsigned long long k = __hip_atomic_load(&keys[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if (k == kP2Empty) {
-            k = atomicCAS(&keys[idx], kP2Empty, (unsigned long long)rec);
-            if (k == kP2Empty) {  // seen for the first time: counts for its group
+          asm volatile("" ::: "memory");  // the bucket is read afresh in every step
+          const ulonglong2 c = *(const ulonglong2*)&keys[2 * (size_t)bkt];
+          if (c.x == rec || c.y == rec) return;
+          if (c.x == kP2Empty || c.y == kP2Empty) {
+            const uint32_t e = 2 * bkt + (c.x == kP2Empty ? 0u : 1u);
+            const unsigned long long old = atomicCAS(&keys[e], kP2Empty, (unsigned long long)rec);
+            if (old == kP2Empty) {  // seen for the first time: counts for its group
               atomicAdd(&gcnt[(uint32_t)(rec >> lo_rest)], 1u);
               return;
             }
+            if (old == rec) return;
+            continue;  // another record took the entry: look at the bucket again
           }
-          if (k == rec) return;
-          idx = idx + 1 == Sb ? 0u : idx + 1;
+          bkt = bkt + 1 == nb ? 0u : bkt + 1;
         }
         if (passes == 1) crowded = 1u;
         else q.flags[0] = 1u;  // a class far larger than its share: the result is void
+      };
+      auto take_batch = [&](const uint64_t (&r)[kBatch], uint32_t first, uint32_t pass) {
+#pragma unroll
+        for (uint32_t j = 0; j < kBatch; ++j)
+          if (first + tid + j * kP2AggBlock < b1) take(r[j], pass);
       };
       for (uint32_t pass = 0; pass < passes; ++pass) {
         if (pass) __syncthreads();
         for (uint32_t i = tid; i < Sb; i += kP2AggBlock) keys[i] = kP2Empty;
         if (tid == 0) crowded = 0;
         __syncthreads();
-#pragma unroll
-        for (uint32_t j = 0; j < kBatch; ++j)
-          if (b0 + tid + j * kP2AggBlock < b1) take(b[j], pass);
+        take_batch(b, b0, pass);
         // (what lies beyond the first rows is fetched once per pass, again a batch at a time so
         // that a thread waits for memory once per batch)
         for (uint32_t base = b0 + kBatch * kP2AggBlock; base < b1; base += kBatch * kP2AggBlock) {
@@ -457,9 +473,7 @@ __global__ __launch_bounds__(kP2AggBlock) void k_part2_agg_compact(Part2Params q
             const uint32_t i = base + tid + j * kP2AggBlock, ic = i < b1 ? i : b0;
             more[j] = __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.out_lo + ic));
           }
-#pragma unroll
-          for (uint32_t j = 0; j < kBatch; ++j)
-            if (base + tid + j * kP2AggBlock < b1) take(more[j], pass);
+          take_batch(more, base, pass);
         }
       }
       __syncthreads();
