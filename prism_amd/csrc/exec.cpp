@@ -1972,7 +1972,8 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
     bool vals_nullable = false;
     for (int j = 0; j < ap.n_vals; ++j)
       for (const Chunk* ch : ss.chunks) vals_nullable = vals_nullable || ch->cols[ss.uses[ap.vals[j].col].column].validity != nullptr;
-    bool part_ok = ap.row_mode != kRowsSelvec && selected >= part_min_rows(ctx) && part_record_words(ap, vals_nullable) > 0;
+    // (nothing selected: nothing to partition -- and the partitioning passes size their work by the rows)
+    bool part_ok = ap.row_mode != kRowsSelvec && selected > 0 && selected >= part_min_rows(ctx) && part_record_words(ap, vals_nullable) > 0;
     for (const Chunk* ch : ss.chunks) part_ok = part_ok && ch->rows < (1ull << 29);  // byte offsets inside a column fit 32 bits
     uint64_t key_bytes = 0;
     for (auto& sp : layout.specs) key_bytes += sp.width;
@@ -1988,10 +1989,15 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       if (!est) est = plan->groups_hint;
       wide_fits = words > 0 && est > 0 && est <= (uint64_t)part_max_buckets(words) * (part_lds_entries(probe) / 2);
     }
-    const bool use_part = part_ok && ap.n_pred == 0 && plan->part_mode.load(std::memory_order_relaxed) >= 0 &&
+    // (A state kept for an exchange between GPUs stays a directly indexed table whenever the
+    // agreed key space allows one: whether to partition depends on this rank's rows and on what
+    // its plan has learnt, and a rank that came with a list where the others hold dense tables
+    // would enter a different collective.)
+    const bool state_stays_dense = capture != nullptr && total_bits <= kDenseMaxBits;
+    const bool use_part = part_ok && !state_stays_dense && ap.n_pred == 0 && plan->part_mode.load(std::memory_order_relaxed) >= 0 &&
                           (wide_fits || (layout.words == 1 && prefers_part) || (layout.words == 2 && part_forced(ctx)));
     // otherwise the streaming kernel runs, and reports it when its rows scatter
-    ap.stop_if_scattered = (!use_part && part_ok && plan->part_mode.load(std::memory_order_relaxed) == 0) ? 1 : 0;
+    ap.stop_if_scattered = (!use_part && part_ok && !state_stays_dense && plan->part_mode.load(std::memory_order_relaxed) == 0) ? 1 : 0;
     // The packed key indexes the table directly when the key space is small, or when it is
     // not much larger than the number of rows (say GROUP BY a timestamp in ms over sorted
     // data: neighbouring rows then update neighbouring entries, where a hash table would

@@ -1129,9 +1129,9 @@ bool part_scatter_halves(int words, uint32_t P) {
 uint32_t part_scan_workgroups(prism_gpu_ctx* ctx, const AggParams& p, uint32_t* tiles_per_wg, bool two_per_cu) {
   // whole scan tiles per workgroup, a multiple of 4 (the widest super-tile); one workgroup per CU, or two
   uint64_t per = ceil_div(p.sd.n_tiles, (uint64_t)ctx->n_cus * (two_per_cu ? 2 : 1));
-  per = ceil_div(per, 4) * 4;
+  per = std::max<uint64_t>(4, ceil_div(per, 4) * 4);  // (an empty scan still gets one workgroup)
   *tiles_per_wg = (uint32_t)per;
-  return (uint32_t)ceil_div(p.sd.n_tiles, per);
+  return (uint32_t)std::max<uint64_t>(1, ceil_div(p.sd.n_tiles, per));
 }
 
 void launch_partitioned_group_by(prism_gpu_ctx* ctx, const AggParams& p_scan, const PartParams& q, bool vals_nullable,

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity: random tables, plans, partitionings and execution routes (single,
 PARTIAL -> merge, streaming, device-resident state), GPU against the CPU oracle.
-usage: python scripts/fuzz_parity.py [iterations] [seed]   (needs a GPU)
+usage: [FUZZ_OPTIONS=name=value,...] python scripts/fuzz_parity.py [iterations] [seed]   (needs a GPU)
 Prints one line per failure with the seed that reproduces it; exit code 1 if any."""
 import os
 import sys
@@ -116,6 +116,11 @@ def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     ctx = Context(0)
+    # FUZZ_OPTIONS="part_force=1,part_min_rows=0": context options for the whole run (say, every
+    # GROUP BY through the partitioned kernels)
+    for opt in filter(None, os.environ.get("FUZZ_OPTIONS", "").split(",")):
+        name, _, value = opt.partition("=")
+        ctx.set_option(name, int(value))
     failures = 0
     unsupported = 0
     for it in range(iters):

@@ -280,6 +280,52 @@ def test_count_distinct_of_one_dominant_group(part_ctx, oracle):
             g.close()
 
 
+def test_forced_partitioning_of_nothing_and_states_for_an_exchange(part_ctx, oracle):
+    """Partitioning forced at any size: a scan that selects no rows is not partitioned (the
+    passes size their work by the rows), and a state kept for an exchange between GPUs stays a
+    directly indexed table whenever the agreed key space allows one, whatever this rank's rows
+    and plan would choose -- ranks that held different kinds of table would enter different
+    collectives."""
+    import torch
+    from prism_amd.engine import Plan, Table
+
+    t = helpers.random_table(5000, seed=77, nulls=False)
+    g = Table(part_ctx, t.schema)
+    g.append_table(t, 3)
+    try:
+        q = QueryPlan([count_star(), sum_("value")], keys=["i16"])
+        plan = Plan(part_ctx, t.schema, q)
+        try:
+            assert plan.execute(g, [17]).num_rows == 0  # no such partition: nothing scanned
+            stats = plan.scan_stats(g)
+            states = [plan.aggregate(g, [p], stats) for p in (0, 1, 2, 17)]
+            infos = [s.describe() for s in states]
+            assert all(i.dense for i in infos) and len({i.entries for i in infos}) == 1
+            # folded like a reduce between ranks would: slot by slot, in place
+            e = infos[0].entries
+            bufs = []
+            for s_, info in zip(states, infos):
+                b = torch.zeros(max(1, info.export_bytes // 8), dtype=torch.int64, device="cuda:0")
+                torch.cuda.synchronize()
+                s_.export_to(b.data_ptr(), info.export_bytes)
+                bufs.append(b)
+            acc = bufs[0]
+            for b in bufs[1:]:
+                for sl in range(infos[0].n_slots):
+                    assert infos[0].slot_merge[sl] == abi.SLOT_SUM_I64
+                    acc[sl * e:(sl + 1) * e] += b[sl * e:(sl + 1) * e]
+            torch.cuda.synchronize()
+            states[0].import_from(acc.data_ptr(), infos[0].export_bytes)
+            got = states[0].finish()
+            for s_ in states:
+                s_.close()
+        finally:
+            plan.close()
+        assert_tables_match(got, oracle.execute(t, q), 1)
+    finally:
+        g.close()
+
+
 def test_streaming_kernel_hands_over_when_rows_scatter(oracle):
     """No forcing: the streaming kernel runs first, finds that its rows miss the LDS tables,
     stops, and the plan is partitioned from then on (its predicate, evaluated inside the
