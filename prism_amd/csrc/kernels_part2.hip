@@ -69,13 +69,6 @@ __device__ __forceinline__ uint32_t sub_of(const Part2Params& q, uint64_t lo, ui
   if (q.compact) return (uint32_t)(mixed_lo(q, lo, hi) >> (q.lo_bits - (int)q.p2_bits));
   return q.p2_bits ? (uint32_t)(hash64(lo ^ hash64(hi)) >> (64 - q.p2_bits)) : 0u;
 }
-// The one-word record of a pair inside its fine bucket (compact form): what is left of the
-// two mixed words below the bits that chose the buckets.
-__device__ __forceinline__ uint64_t compact_record(const Part2Params& q, uint64_t lo, uint64_t hi) {
-  const int lo_rest = q.lo_bits - (int)q.p2_bits, hi_rest = q.hi_bits - (int)q.p1_bits;
-  return ((bij_mix(hi, q.hi_bits) & ((1ull << hi_rest) - 1ull)) << lo_rest) | (mixed_lo(q, lo, hi) & ((1ull << lo_rest) - 1ull));
-}
-
 __global__ __launch_bounds__(kP2Block) void k_part2_hist(Part2Params q) {
   __shared__ uint32_t cnt[kP2Counters];
   const uint32_t n_sub = 1u << q.p2_bits, span = span_of(q);
