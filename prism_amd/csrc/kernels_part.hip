@@ -1018,6 +1018,11 @@ __global__ __launch_bounds__(kPartBlock) void k_part_agg(AggParams p, PartParams
   }
 }
 
+// (Tried and dropped for rows that arrive clustered by bucket -- time-ordered rows partitioned
+// by a group key that holds the time bucket: no tile at all, one output cursor per bucket in
+// LDS, a row takes its place with one LDS atomic and is stored there straight from the
+// registers, in the hope that the stores of neighbouring places meet in the L2.  No barriers,
+// but 6.7 against 4.9 ms at 4e8 rows and 21.6 against 15.1 ms at 1.25e9.)
 using PartKernel = void (*)(AggParams, PartParams);
 
 struct PartKernels {
