@@ -1177,15 +1177,12 @@ uint64_t partitioned_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, AggParam
     list.capacity = list_cap;
     list.n_slots = n_slots;
     list.key_words = ap.key_words;
+    // (the entries past the last group -- empty keys, and a zero in slot 0, which counts a group's
+    // rows -- are written once the number of groups is known: clearing the whole list up front
+    // was two passes over tens of megabytes per query)
     list.keys = Scratch(ctx, (list_cap + 1) * 8);
-    PRISM_HIP(hipMemsetAsync(list.keys.p, 0xff, (list_cap + 1) * 8, ctx->stream));
-    if (ap.key_words == 2) {
-      list.keys_hi = Scratch(ctx, (list_cap + 1) * 8);
-      PRISM_HIP(hipMemsetAsync(list.keys_hi.p, 0xff, (list_cap + 1) * 8, ctx->stream));
-    }
+    if (ap.key_words == 2) list.keys_hi = Scratch(ctx, (list_cap + 1) * 8);
     list.state = Scratch(ctx, (list_cap + 1) * 8 * (size_t)n_slots);
-    // slot 0 counts a group's rows: zero marks the entries past the end (and the extra entry)
-    PRISM_HIP(hipMemsetAsync(list.state.p, 0, (list_cap + 1) * 8, ctx->stream));
     list.overflow = Scratch(ctx, 256);
     PRISM_HIP(hipMemsetAsync(list.overflow.p, 0, 4, ctx->stream));
     PRISM_HIP(hipMemsetAsync(d_small.p, 0, 64, ctx->stream));
@@ -1230,6 +1227,12 @@ uint64_t partitioned_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, AggParam
       // the list was too short (the count is exact now): once more
       list_cap = groups + 1024;
       continue;
+    }
+    {
+      const uint64_t tail = list_cap + 1 - groups;  // the entries past the groups, and the extra entry
+      PRISM_HIP(hipMemsetAsync(list.keys.as<uint64_t>() + groups, 0xff, tail * 8, ctx->stream));
+      if (ap.key_words == 2) PRISM_HIP(hipMemsetAsync(list.keys_hi.as<uint64_t>() + groups, 0xff, tail * 8, ctx->stream));
+      PRISM_HIP(hipMemsetAsync(list.state.as<int64_t>() + groups, 0, tail * 8, ctx->stream));
     }
     if (h.flags[1]) plan->part_table_capacity.store(fb_cap, std::memory_order_relaxed);
     // More groups than the largest number of buckets can hold in LDS: most of them went
