@@ -728,7 +728,11 @@ __global__ __launch_bounds__(kBlock) void k_contains_find(const ContainsSeg* seg
 // cutting the range in sixteen or in four per step with the pivots' loads in flight together;
 // four occurrences per thread searched in step; starting from two probes around the row that
 // the occurrence's share of the segment's bytes suggests -- fewer loads or more of them in
-// flight, but more lines of their own per occurrence.)
+// flight, but more lines of their own per occurrence.  Also dropped: no second pass at all,
+// the first keeping the offsets of the 512 rows around each chunk in LDS and looking the rows
+// of a chunk's occurrences up there while the next chunk's loads are in flight -- the window's
+// load and hand-over cost 0.10 ms, the look-ups 0.22 ms (they hold up the workgroup's barrier)
+// and the registers one resident workgroup per CU, 0.15 ms: 1.77 ms against 1.46 for both passes.)
 __global__ __launch_bounds__(kBlock) void k_contains_mark(const ContainsSeg* segs, const uint64_t* matches,
                                                          const unsigned long long* n_matches, uint64_t capacity,
                                                          uint32_t L, uint64_t* bits) {

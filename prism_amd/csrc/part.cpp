@@ -17,20 +17,25 @@ namespace prism {
 
 // ---- child contexts ------------------------------------------------------------------
 
+namespace {
+// a child context runs with its parent's settings as they are when it is taken
+void copy_options(prism_gpu_ctx* c, prism_gpu_ctx* parent) {
+  c->profiling = parent->profiling;
+  c->part_min_rows.store(parent->part_min_rows.load());
+  c->part_force.store(parent->part_force.load());
+  c->part2_compact.store(parent->part2_compact.load());
+  c->part_half_blocks.store(parent->part_half_blocks.load());
+  c->contains_windows.store(parent->contains_windows.load());
+}
+}  // namespace
+
 prism_gpu_ctx* ctx_acquire_child(prism_gpu_ctx* parent) {
   {
     std::lock_guard<std::mutex> g(parent->mu);
     if (!parent->idle_children.empty()) {
       prism_gpu_ctx* c = parent->idle_children.back();
       parent->idle_children.pop_back();
-      c->profiling = parent->profiling;
-      c->part_min_rows.store(parent->part_min_rows.load());
-      c->part_force.store(parent->part_force.load());
-  c->part2_compact.store(parent->part2_compact.load());
-  c->part_half_blocks.store(parent->part_half_blocks.load());
-      c->part2_compact.store(parent->part2_compact.load());
-  c->part_half_blocks.store(parent->part_half_blocks.load());
-      c->part_half_blocks.store(parent->part_half_blocks.load());
+      copy_options(c, parent);
       return c;
     }
   }
@@ -41,11 +46,7 @@ prism_gpu_ctx* ctx_acquire_child(prism_gpu_ctx* parent) {
   c->lds_per_block_max = parent->lds_per_block_max;
   c->parent = parent;
   c->stage_bytes = prism_gpu_ctx::kChildStageBytes;
-  c->profiling = parent->profiling;
-  c->part_min_rows.store(parent->part_min_rows.load());
-  c->part_force.store(parent->part_force.load());
-  c->part2_compact.store(parent->part2_compact.load());
-  c->part_half_blocks.store(parent->part_half_blocks.load());
+  copy_options(c.get(), parent);
   PRISM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   PRISM_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
   return c.release();
