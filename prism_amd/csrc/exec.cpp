@@ -515,11 +515,12 @@ struct PredEval {
           // there are rows (a one-letter needle, say), segment by segment with the search
           // for the row done in place
           std::vector<ContainsSeg> csegs(ss.segs.size());
+          const uint64_t chunk_bytes = contains_chunk_bytes(contains_block(ctx, (uint32_t)needle.size()));
           uint64_t n_chunks = 0;
           for (size_t s = 0; s < ss.segs.size(); ++s) {
             const DeviceColumn& dc = ss.chunks[s]->cols[n.column];
             csegs[s] = {(const int32_t*)dc.values, dc.bytes, ss.segs[s].rows, dc.n_bytes, ss.segs[s].tile_base, n_chunks};
-            n_chunks += ceil_div(dc.n_bytes, kContainsChunkBytes);
+            n_chunks += ceil_div(dc.n_bytes, chunk_bytes);
           }
           const ContainsSeg* d_csegs = (const ContainsSeg*)to_device(csegs.data(), csegs.size() * sizeof(ContainsSeg));
           const uint64_t match_capacity = std::max<uint64_t>(ss.rows, 1u << 16);

@@ -70,12 +70,18 @@ struct ContainsSeg {
   uint64_t rows;
   uint64_t n_bytes;
   uint64_t tile_base;
-  uint64_t chunk_base;  // chunks of kContainsChunkBytes before this segment
+  uint64_t chunk_base;  // chunks (of contains_chunk_bytes(contains_block(..))) before this segment
 };
-#ifndef PRISM_CONTAINS_CHUNK_BYTES
-#define PRISM_CONTAINS_CHUNK_BYTES 16384
-#endif
-constexpr uint64_t kContainsChunkBytes = PRISM_CONTAINS_CHUNK_BYTES;
+// Threads of a workgroup of the first pass, and the bytes of a chunk that go with them (four
+// 16-byte pieces a thread).  Needles of four bytes and more (the window search): workgroups of
+// ONE wave, 32 of them on a CU -- a wave then walks its chunks at its own pace and the loads
+// of the CU's waves spread out in time, where four waves in step at a barrier per chunk asked
+// for theirs in bursts (C4: 1.30 -> 1.21 ms for 6.5 GB of strings; 128 threads: 1.26).
+// Shorter needles may occur all over (a one-letter needle: most chunks fill the list's LDS
+// buffer several times) and keep the larger workgroup, whose larger buffer means four times
+// fewer additions to the list's one counter (9.9 ms against 16.7 with single waves).
+uint32_t contains_block(const prism_gpu_ctx* ctx, uint32_t needle_len);
+constexpr uint64_t contains_chunk_bytes(uint32_t block) { return (uint64_t)block * 64; }
 bool launch_contains_all(prism_gpu_ctx* ctx, const ContainsSeg* d_segs, uint32_t n_segs, uint64_t n_chunks,
                          const uint8_t* d_needle, uint32_t needle_len, uint64_t* d_matches, uint64_t match_capacity,
                          unsigned long long* d_n_matches, uint64_t* bits);

@@ -452,7 +452,7 @@ void launch_str_leaf(prism_gpu_ctx* ctx, const ScanDesc& sd, const ColPtr* col, 
 
 namespace {
 
-// Pass 1: every workgroup walks a contiguous share of 16-KiB chunks of the concatenated
+// Pass 1: every workgroup walks a contiguous share of chunks (64 bytes a thread) of the concatenated
 // segments; a lane tests the 16 byte positions of each of its four 16-byte pieces.  The
 // four bytes a lane needs beyond its own piece come from its neighbour's registers; only
 // those after the wave's last lane are loaded.  (Measured and dropped: a second register
@@ -472,11 +472,12 @@ struct ContainsChunk {
 // vector instructions per word instead of 10, the comparisons leave wave-wide masks in scalar
 // registers (nothing is packed per lane), and a window that matches four needle bytes is
 // nearly always an occurrence, so the per-candidate loop hardly ever runs.
-template <int S>
-__global__ __launch_bounds__(kBlock) void k_contains_find(const ContainsSeg* segs, uint32_t n_segs, uint64_t n_chunks,
+template <int S, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_contains_find(const ContainsSeg* segs, uint32_t n_segs, uint64_t n_chunks,
                                                          const uint8_t* needle, uint32_t L, uint64_t* matches,
                                                          uint64_t capacity, unsigned long long* n_matches) {
-  constexpr int K = (int)(kContainsChunkBytes / (kBlock * 16));
+  constexpr int K = 4;  // 16-byte pieces a thread and chunk
+  constexpr uint64_t kChunkBytes = contains_chunk_bytes(BLOCK);
   const uint32_t k = L < 4 ? L : 4;
   uint32_t first = 0;
   for (uint32_t i = 0; i < k; ++i) first |= (uint32_t)needle[i] << (8 * i);
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(kBlock) void k_contains_find(const ContainsSeg* seg
   const int lane = threadIdx.x & 63;
   // Occurrences are collected in LDS and moved to the list a few hundred at a time: one
   // atomic on the list's counter per occurrence would serialise on that one address.
-  constexpr uint32_t kBuf = 1024;
+  constexpr uint32_t kBuf = BLOCK >= 256 ? 1024 : 256;
   __shared__ uint64_t buf[kBuf];
   __shared__ uint32_t buf_n;
   __shared__ unsigned long long flush_base;
@@ -497,7 +498,7 @@ __global__ __launch_bounds__(kBlock) void k_contains_find(const ContainsSeg* seg
     const uint32_t n = buf_n < kBuf ? buf_n : kBuf;
     if (threadIdx.x == 0) flush_base = atomicAdd(n_matches, (unsigned long long)n);
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += kBlock)
+    for (uint32_t i = threadIdx.x; i < n; i += BLOCK)
       if (flush_base + i < capacity) matches[flush_base + i] = buf[i];
     __syncthreads();
     if (threadIdx.x == 0) buf_n = 0;
@@ -519,7 +520,7 @@ __global__ __launch_bounds__(kBlock) void k_contains_find(const ContainsSeg* seg
       next_chunk_base = seg_cursor + 1 < n_segs ? uniform_u64(segs[seg_cursor + 1].chunk_base) : ~0ull;
     }
     ContainsChunk cc = cur_seg;
-    cc.base = (c - seg_chunk_base) * kContainsChunkBytes;
+    cc.base = (c - seg_chunk_base) * kChunkBytes;
     return cc;
   };
   // d[q][0..3]: the lane's 16 bytes of piece q; d[q][4]: the 4 bytes after the wave's last
@@ -533,8 +534,8 @@ __global__ __launch_bounds__(kBlock) void k_contains_find(const ContainsSeg* seg
     const uint64_t gb = (uint64_t)cc.bytes;
 #pragma unroll
     for (int q = 0; q < K; ++q) {
-      const uint64_t p = cc.base + (uint64_t)q * (kBlock * 16) + (uint64_t)threadIdx.x * 16;
-      const uint64_t wave_end = cc.base + (uint64_t)q * (kBlock * 16) + (uint64_t)((threadIdx.x >> 6) + 1) * 1024;
+      const uint64_t p = cc.base + (uint64_t)q * (BLOCK * 16) + (uint64_t)threadIdx.x * 16;
+      const uint64_t wave_end = cc.base + (uint64_t)q * (BLOCK * 16) + (uint64_t)((threadIdx.x >> 6) + 1) * 1024;
       const u32x4_t own = __builtin_nontemporal_load((gvec_t)(gb + (p < cc.total ? p : 0)));
       d[q][0] = own.x; d[q][1] = own.y; d[q][2] = own.z; d[q][3] = own.w;
       // the buffer is padded by the loader, so the 4 bytes after the last piece are readable
@@ -551,7 +552,7 @@ __global__ __launch_bounds__(kBlock) void k_contains_find(const ContainsSeg* seg
   auto search = [&](const ContainsChunk& cc, uint32_t (&d)[K][5]) {
 #pragma unroll
     for (int q = 0; q < K; ++q) {
-      const uint64_t p = cc.base + (uint64_t)q * (kBlock * 16) + (uint64_t)threadIdx.x * 16;
+      const uint64_t p = cc.base + (uint64_t)q * (BLOCK * 16) + (uint64_t)threadIdx.x * 16;
       const uint32_t from_next = (uint32_t)__shfl_down((int)d[q][0], 1);
       const uint32_t after = lane == 63 ? d[q][4] : from_next;
       uint32_t z[4];
@@ -626,7 +627,7 @@ __global__ __launch_bounds__(kBlock) void k_contains_find(const ContainsSeg* seg
   auto search_grams = [&](const ContainsChunk& cc, uint32_t (&d)[K][5]) {
 #pragma unroll
     for (int q = 0; q < K; ++q) {
-      const uint64_t p = cc.base + (uint64_t)q * (kBlock * 16) + (uint64_t)threadIdx.x * 16;
+      const uint64_t p = cc.base + (uint64_t)q * (BLOCK * 16) + (uint64_t)threadIdx.x * 16;
       uint32_t after = 0;
       if (S < 4) {
         const uint32_t from_next = (uint32_t)__shfl_down((int)d[q][0], 1);
@@ -756,6 +757,23 @@ __global__ __launch_bounds__(kBlock) void k_contains_mark(const ContainsSeg* seg
 
 }  // namespace
 
+uint32_t contains_block(const prism_gpu_ctx* ctx, uint32_t needle_len) {
+  const bool windows = ctx->contains_windows.load(std::memory_order_relaxed) != 0;
+  return windows && needle_len >= 4 ? 64u : 256u;
+}
+
+namespace {
+template <int BLOCK>
+void launch_contains_find(prism_gpu_ctx* ctx, int s, uint32_t grid, const ContainsSeg* d_segs, uint32_t n_segs, uint64_t n_chunks,
+                          const uint8_t* d_needle, uint32_t needle_len, uint64_t* d_matches, uint64_t match_capacity,
+                          unsigned long long* d_n_matches) {
+  auto kernel = s == 4 ? k_contains_find<4, BLOCK> : s == 2 ? k_contains_find<2, BLOCK>
+                : s == 1 ? k_contains_find<1, BLOCK> : k_contains_find<0, BLOCK>;
+  kernel<<<dim3(grid), dim3(BLOCK), 0, ctx->stream>>>(d_segs, n_segs, n_chunks, d_needle, needle_len, d_matches, match_capacity,
+                                                     d_n_matches);
+}
+}  // namespace
+
 bool launch_contains_all(prism_gpu_ctx* ctx, const ContainsSeg* d_segs, uint32_t n_segs, uint64_t n_chunks,
                          const uint8_t* d_needle, uint32_t needle_len, uint64_t* d_matches, uint64_t match_capacity,
                          unsigned long long* d_n_matches, uint64_t* bits) {
@@ -763,10 +781,12 @@ bool launch_contains_all(prism_gpu_ctx* ctx, const ContainsSeg* d_segs, uint32_t
   PRISM_HIP(hipMemsetAsync(d_n_matches, 0, 8, ctx->stream));
   const uint32_t grid = (uint32_t)std::min<uint64_t>(n_chunks, (uint64_t)ctx->n_cus * 8);
   const bool windows = ctx->contains_windows.load(std::memory_order_relaxed) != 0;
-  auto kernel = !windows ? k_contains_find<0> : needle_len >= 7 ? k_contains_find<4> : needle_len >= 5 ? k_contains_find<2>
-                : needle_len == 4 ? k_contains_find<1> : k_contains_find<0>;
-  kernel<<<dim3(grid), dim3(kBlock), 0, ctx->stream>>>(d_segs, n_segs, n_chunks, d_needle, needle_len, d_matches, match_capacity,
-                                                      d_n_matches);
+  const int s = !windows ? 0 : needle_len >= 7 ? 4 : needle_len >= 5 ? 2 : needle_len == 4 ? 1 : 0;
+  // as many workgroups as are resident together (2048 threads a CU)
+  const uint32_t block = contains_block(ctx, needle_len);
+  const uint32_t find_grid = (uint32_t)std::min<uint64_t>(n_chunks, (uint64_t)ctx->n_cus * (2048 / block));
+  if (block == 64) launch_contains_find<64>(ctx, s, find_grid, d_segs, n_segs, n_chunks, d_needle, needle_len, d_matches, match_capacity, d_n_matches);
+  else launch_contains_find<256>(ctx, s, find_grid, d_segs, n_segs, n_chunks, d_needle, needle_len, d_matches, match_capacity, d_n_matches);
   PRISM_HIP(hipGetLastError());
   // a list that overflowed leaves bits of real occurrences behind, which the caller's
   // fallback sets again
