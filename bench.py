@@ -80,6 +80,180 @@ def stream_feed(args) -> int:
     return 0
 
 
+DOMINANT = {"C1": "filter_count", "C2": "group_by", "C3": "group_by", "C4": "like_contains", "C4G": "like_contains", "C5": "group_by"}
+SYMBOLS = {"group_by": ("k_group_by_stream", "k_part_agg", "k_part_scatter", "k_part_hist", "k_part_offsets",
+                        "k_part_plan", "k_part2_hist", "k_part2_scan", "k_part2_scatter", "k_part2_agg", "k_part2_agg_compact",
+                        "k_group_by_wide", "k_group_by", "k_chunk_scatter", "k_chunk_agg", "k_chunk_split"),
+           "filter_count": ("k_cmp_leaf",), "like_contains": ("k_contains_find", "k_contains_mark")}
+
+
+def profile_tag(wl, rows, parts):
+    return {("C2", 1_000_000_000, 64): "c2_1b", ("C3", 100_000_000, 100): "c3", ("C1", 1_000_000_000, 64): "c1_1b",
+            ("C4", 100_000_000, 100): "c4", ("C5", 1_250_000_000, 64): "c5_1p25b",
+            ("C3_17M", 100_000_000, 100): "c3_17m"}.get((wl.name, rows, parts))
+
+
+def price_dominant_kernel(wl, rows, parts, stats, groups, world):
+    """`roofline` of one workload: algorithmic bytes of a launch over the dominant kernel's
+    average HIP-event duration (measured live, on the library's stream), against the 8 TB/s
+    HBM peak; `traffic` is the committed PMC measurement of the same command (PMC passes
+    cannot run inside this process), null when the configuration differs."""
+    kname = DOMINANT[wl.name.split("_")[0]]
+    ks = stats["kernels"].get(kname)
+    if not ks or not ks["launches"]:
+        return None
+    avg_s = ks["total_ms"] / ks["launches"] / 1e3
+    alg = rows * wl.bytes_per_row + (groups * wl.bytes_per_group if world == 1 else 0)
+    achieved = alg / avg_s / 1e9
+    traffic = traffic_source = profile_avg_ms = None
+    tag = profile_tag(wl, rows, parts)
+    if tag and world == 1:
+        for rnd in ("r3", "r2"):
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", rnd, f"{tag}_traffic.json")))
+                ks_prof = [tj["kernels"][k] for k in SYMBOLS[kname] if k in tj["kernels"] and tj["kernels"][k]["calls"] >= 3]
+                if ks_prof:
+                    traffic = sum((k["fetch_bytes_per_launch"] or 0) + (k["write_bytes_per_launch"] or 0) for k in ks_prof)
+                    profile_avg_ms = sum(k["avg_ns"] for k in ks_prof) / 1e6
+                    traffic_source = f"profiles/{rnd}/{tag}_traffic.json (rocprofv3 --pmc passes of the same command, not collected in this run)"
+                    break
+            except (OSError, KeyError, ValueError, TypeError):
+                continue
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
+                "kernel_avg_ms": avg_s * 1e3, "algorithmic_bytes_per_launch": alg,
+                "frac_uses": "kernel_avg_ms: HIP events around the launch, measured in this run",
+                "traffic_source": traffic_source, "profile_kernel_avg_ms": profile_avg_ms}
+    try:  # the streaming-read rate a plain sum kernel reaches on this part (committed measurement)
+        ceil_gbs = json.load(open(os.path.join(ROOT, "profiles", "r1", "read_ceiling.json")))["read_GBps"]
+        roofline["measured_read_ceiling"] = ceil_gbs
+        roofline["frac_of_measured_ceiling"] = achieved / ceil_gbs
+    except (OSError, KeyError, ValueError):
+        pass
+    return roofline
+
+
+def extra_workloads(ctx, steps: int, warmup: int, sample_rows_cap: int = 16_000_000):
+    """The other configurations, a few steps each, for the same record as the headline: per
+    workload the step time, the dominant kernel's HIP-event time, the roofline fraction on
+    algorithmic bytes, the ratio of measured to algorithmic HBM traffic (from the committed
+    profile of the same command) and whether a sample of the result equals the CPU oracle's."""
+    import dataclasses
+
+    from oracle import pyoracle
+    from prism_amd import workloads
+    from prism_amd.engine import Plan
+    from tests.helpers import assert_tables_match, assert_topk_match
+
+    c3_17m = dataclasses.replace(workloads.c3(id_bits=26), name="C3_17M")
+    todo = [("C1@1e7", workloads.c1(), 10_000_000, 10), ("C1@1e9", workloads.c1(), 1_000_000_000, 64),
+            ("C3", workloads.c3(), 100_000_000, 100), ("C3@17.6M groups", c3_17m, 100_000_000, 100),
+            ("C4", workloads.c4(), 100_000_000, 100), ("C5@1.25e9", workloads.c5(), 1_250_000_000, 64)]
+    out = {}
+    for label, wl, rows, parts in todo:
+        t_all = time.time()
+        entry = {"query": wl.description, "rows": rows, "partitions": parts}
+        try:
+            table = workloads.build_gpu_table(ctx, wl, 0, rows, rows, parts)
+            plan = Plan(ctx, wl.schema, wl.query)
+            try:
+                # parity on the leading partitions (bounded: the oracle is a scalar restatement)
+                k = max(1, min(parts, sample_rows_cap * parts // rows))
+                sample = workloads.partition_bounds(rows, parts, k - 1)[1]
+                st = pyoracle.SynthTable(wl.schema, wl.make_cols(), wl.seed, 0, sample, rows, n_parts=max(k, 16), threads=16)
+                try:
+                    want, _ = st.execute(wl.query, threads=min(16, os.cpu_count() or 1))
+                finally:
+                    st.close()
+                want = workloads.decode_dictionary_columns(wl, want)
+                got = plan.execute(table, range(k))
+                if wl.query.limit is not None:
+                    assert_topk_match(got, want, wl.query.order_by)
+                else:
+                    assert_tables_match(got, want, wl.n_keys)
+                entry["parity"] = True
+                entry["parity_sample_rows"] = sample
+                for _ in range(warmup):
+                    plan.execute(table)
+                ctx.reset_stats()
+                ctx.set_profiling(True)
+                t0 = time.perf_counter()
+                result = None
+                for _ in range(steps):
+                    result = plan.execute(table)
+                elapsed = time.perf_counter() - t0
+                ctx.set_profiling(False)
+                stats = ctx.stats()
+                roof = price_dominant_kernel(wl, rows, parts, stats, result.num_rows if wl.n_keys else 1, 1)
+                entry.update({"steps": steps, "ms_per_step": elapsed / steps * 1e3, "rows_per_s": rows / (elapsed / steps),
+                              "groups": result.num_rows})
+                if roof:
+                    entry.update({"kernel": roof["kernel"], "kernel_ms": roof["kernel_avg_ms"], "frac": roof["frac"],
+                                  "algorithmic_bytes": roof["algorithmic_bytes_per_launch"], "traffic": roof["traffic"],
+                                  "traffic_ratio": (roof["traffic"] / roof["algorithmic_bytes_per_launch"]) if roof["traffic"] else None,
+                                  "traffic_source": roof["traffic_source"], "profile_kernel_avg_ms": roof["profile_kernel_avg_ms"]})
+                entry["kernels"] = {n: v["total_ms"] / max(1, v["launches"]) for n, v in stats["kernels"].items()
+                                    if not n.startswith("host:")}
+            finally:
+                plan.close()
+                table.close()
+        except Exception as e:  # noqa: BLE001 - one workload failing must not take the headline line with it
+            entry["parity"] = entry.get("parity", False)
+            entry["error"] = f"{type(e).__name__}: {e}"[:400]
+        entry["wall_s"] = round(time.time() - t_all, 1)
+        log(f"[workloads] {label}: " + json.dumps({k_: v for k_, v in entry.items() if k_ not in ('kernels', 'query')}))
+        out[label] = entry
+    return out
+
+
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher around it: starts N ranks of this script
+    (one per GPU) as children through torch.distributed.run and relays rank 0's JSON line.
+    This process never touches the GPU: the ranks are fresh processes, nothing is re-executed."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"[launcher] starting {n} ranks: {' '.join(cmd)}")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:
+        if out.lstrip().startswith("{") and ('"metric"' in out or '"check_launch"' in out):
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        log("[launcher] the ranks printed no result line")
+        rc = 1
+    return rc
+
+
+def check_launch(args) -> int:
+    """The ranks meet (gloo, CPU) and count themselves; rank 0 prints one line."""
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([1, rank], dtype=torch.int64)
+    dist.all_reduce(t)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"check_launch": True, "n_gpus_asked": args.gpus, "ranks_met": int(t[0]), "rank_sum": int(t[1])}), flush=True)
+    dist.destroy_process_group()
+    return 0
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,9 +277,18 @@ def main() -> int:
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="prism_gpu_set_option on the context (for A/B runs of a kernel path)")
     ap.add_argument("--feed-threads", type=int, default=16, help="partitions (= feeding threads) of --feed stream")
+    ap.add_argument("--check-launch", action="store_true",
+                    help="only bring the ranks up (gloo rendezvous + one all-reduce, no GPU) and print what met; "
+                         "lets a box without GPUs check that --gpus N starts N ranks")
+    ap.add_argument("--no-extra-workloads", action="store_true",
+                    help="skip the `workloads` object (C1, C3, C4, C5 run for a few steps after the headline's timed region)")
     args = ap.parse_args()
     if args.feed == "stream":
         return stream_feed(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus)
+    if args.check_launch:
+        return check_launch(args)
 
     # Exactly one line goes to stdout: RCCL prints a version banner there when the
     # communicator is created, so everything else written to fd 1 is sent to stderr and the
@@ -262,45 +445,7 @@ def main() -> int:
         # full-size, size-independent checks: every row lands in exactly one group
         if args.workload in ("C2",):
             assert sum(result.column("COUNT(*)").to_pylist()) == total_rows, "COUNT(*) does not add up to the rows scanned"
-        kname = {"C1": "filter_count", "C2": "group_by", "C3": "group_by", "C4": "like_contains", "C4G": "like_contains",
-                 "C5": "group_by"}[args.workload]
-        ks = stats["kernels"].get(kname)
-        roofline = None
-        if ks and ks["launches"]:
-            avg_s = ks["total_ms"] / ks["launches"] / 1e3
-            groups = result.num_rows if wl.n_keys else 1
-            alg = rows * wl.bytes_per_row + (groups * wl.bytes_per_group if world == 1 else 0)
-            achieved = alg / avg_s / 1e9
-            # HBM bytes per launch of this kernel: PMC passes (FETCH_SIZE, WRITE_SIZE) cannot run
-            # inside this process, so the figure is the one scripts/profile_workload.sh measured
-            # for this exact command line and committed; null when the configuration differs.
-            traffic = traffic_source = profile_avg_ms = None
-            tag = {("C2", 1_000_000_000, 64): "c2_1b", ("C3", 100_000_000, 100): "c3", ("C1", 1_000_000_000, 64): "c1_1b",
-                   ("C4", 100_000_000, wl.default_partitions): "c4", ("C5", 1_250_000_000, 64): "c5_1p25b"}.get((wl.name, rows, parts))
-            symbol = {"group_by": ("k_group_by_stream", "k_part_agg", "k_part_scatter", "k_part_hist", "k_part_offsets",
-                                   "k_part_plan", "k_part2_hist", "k_part2_scan", "k_part2_scatter", "k_part2_agg", "k_part2_agg_compact",
-                                   "k_group_by_wide", "k_group_by"),
-                      "filter_count": ("k_cmp_leaf",), "like_contains": ("k_contains_find", "k_contains_mark")}[kname]
-            try:
-                if tag and world == 1:
-                    tj = json.load(open(os.path.join(ROOT, "profiles", "r2", f"{tag}_traffic.json")))
-                    ks_prof = [tj["kernels"][k] for k in symbol if k in tj["kernels"] and tj["kernels"][k]["calls"] >= 5]
-                    if ks_prof:
-                        traffic = sum((k["fetch_bytes_per_launch"] or 0) + (k["write_bytes_per_launch"] or 0) for k in ks_prof)
-                        profile_avg_ms = sum(k["avg_ns"] for k in ks_prof) / 1e6
-                        traffic_source = f"profiles/r2/{tag}_traffic.json (rocprofv3 --pmc passes of the same command, not collected in this run)"
-            except (OSError, KeyError, ValueError, TypeError):
-                pass
-            roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
-                        "kernel_avg_ms": avg_s * 1e3, "algorithmic_bytes_per_launch": alg,
-                        "traffic_source": traffic_source, "profile_kernel_avg_ms": profile_avg_ms}
-            try:  # the streaming-read rate a plain sum kernel reaches on this part (committed measurement)
-                ceil_gbs = json.load(open(os.path.join(ROOT, "profiles", "r1", "read_ceiling.json")))["read_GBps"]
-                roofline["measured_read_ceiling"] = ceil_gbs
-                roofline["frac_of_measured_ceiling"] = achieved / ceil_gbs
-            except (OSError, KeyError, ValueError):
-                pass
+        roofline = price_dominant_kernel(wl, rows, parts, stats, result.num_rows if wl.n_keys else 1, world)
         ms_per_step = elapsed / args.steps * 1e3
         line = {
             "metric": "rows/sec scanned+aggregated (node)",
@@ -328,14 +473,22 @@ def main() -> int:
             "kernels": {n: {"launches": v["launches"], "avg_ms": v["total_ms"] / max(1, v["launches"])}
                         for n, v in stats["kernels"].items()},
         }
+        if world == 1 and not grouped and args.workload == "C2" and not args.rows and not args.no_extra_workloads:
+            # the other configurations, after the headline's timed region and with its table gone
+            single.close()
+            table.close()
+            single = table = None
+            line["workloads"] = extra_workloads(ctx, steps=5, warmup=2)
         print(json.dumps(line), file=json_out, flush=True)
 
     if comm is not None:
         comm.close()
-    single.close()
+    if single is not None:
+        single.close()
     if partial:
         partial.close()
-    table.close()
+    if table is not None:
+        table.close()
     ctx.close()
     if grouped:
         dist.destroy_process_group()

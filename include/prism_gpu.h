@@ -209,6 +209,8 @@ void prism_gpu_ctx_free(prism_gpu_ctx* ctx);
  *   "contains_windows" 0: LIKE '%needle%' over a column without a dictionary always uses the
  *                    byte-wise prefilter; 1 (default): needles of 4 bytes and more are found by
  *                    comparing 4-byte windows with the needle's leading words
+ *   "sharded_fail_phase" tests only: this context's rank fails on purpose in the given local
+ *                    phase (1..5) of prism_gpu_execute_sharded (default 0: never)
  * Unknown names are PRISM_GPU_EINVAL. */
 int prism_gpu_set_option(prism_gpu_ctx* ctx, const char* name, int64_t value);
 
@@ -301,8 +303,9 @@ int prism_gpu_execute(prism_gpu_plan* plan, prism_gpu_table* table,
  * *n_groups (host memory) receives the number of rows; if it exceeds out_stride the call fails
  * with PRISM_GPU_EINVAL and nothing was written past the buffers.
  *
- * Every call on a GPU uses that GPU's one array: calls from one process are serialised by the
- * library, calls from different processes that overlap on one GPU race.  The array keeps the
+ * The array belongs to the process (it is part of the library's loaded code object) and to
+ * the device: every process has its own copy per GPU, and the calls of one process on one GPU
+ * are serialised by the library.  Different processes never share it.  The array keeps the
  * last call's contents; each call clears what it needs. */
 int prism_gpu_execute_noalloc(prism_gpu_plan* plan, prism_gpu_table* table,
                               const uint32_t* partition_ids, size_t n_partitions,
@@ -442,7 +445,16 @@ int prism_gpu_table_dictionary_digest(prism_gpu_table* table, int32_t column,
  * same exchange over three functions of the caller, on page-locked host copies of the
  * buffers: for hosts with a fabric of their own, and for tests in which several ranks
  * share one GPU (which RCCL does not allow).  Failures of the transport are reported as
- * PRISM_GPU_ERCCL. */
+ * PRISM_GPU_ERCCL; an RCCL communicator whose collective failed is aborted (which releases
+ * peers still inside it) and refuses further calls.
+ *
+ * A rank's own failure (out of memory, a table overflow, a bad table) does not strand the
+ * others: every small all-gather of the exchange carries a status word per rank, and one
+ * is placed in front of each bulk collective, so when one rank fails every rank returns an
+ * error at the same point -- the failing rank its own, the others that rank's status code
+ * with a message naming it.  String columns that travel as dictionary codes (GROUP BY keys
+ * and the column of a COUNT(DISTINCT)) must have equal dictionaries on all ranks, else
+ * PRISM_GPU_EINVAL on every rank. */
 typedef struct prism_gpu_comm prism_gpu_comm;
 #define PRISM_GPU_COMM_ID_BYTES 128
 

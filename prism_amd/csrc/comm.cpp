@@ -32,6 +32,7 @@ struct Rccl {
   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommAbort) CommAbort = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclReduce) Reduce = nullptr;
@@ -64,6 +65,7 @@ Rccl& rccl() {
   r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
   r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
   r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+  r.CommAbort = (decltype(r.CommAbort))sym("ncclCommAbort");
   r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
   r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
   r.Reduce = (decltype(r.Reduce))sym("ncclReduce");
@@ -94,6 +96,7 @@ struct prism_gpu_comm {
   int rank = 0, world = 1;
   ncclComm_t nccl = nullptr;
   bool callbacks = false;
+  bool aborted = false;  // a collective failed: the communicator was torn down and takes no more calls
   prism_gpu_transport cb{};
   std::mutex mu;
   prism_gpu_comm_stats stats{};
@@ -260,76 +263,184 @@ void comm_stats(prism_gpu_comm* c, prism_gpu_comm_stats* out) {
   *out = c->stats;
 }
 
-int execute_sharded(prism_gpu_comm* c, prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids,
-                    size_t n_partitions, int root, ArrowArray* out) {
+namespace {
+
+// A rank's own failure between two collectives.  It is kept until the next small all-gather,
+// which carries a status word of every rank: a failure on one rank then becomes an error on
+// all of them at the same point of the exchange, instead of one rank unwinding while the
+// others wait in the next collective for good.
+struct LocalStatus {
+  int code = 0;
+  std::string msg;
+  template <class F>
+  void run(F&& f) {
+    if (code) return;
+    try {
+      f();
+    } catch (const Error& e) {
+      code = e.code ? e.code : PRISM_GPU_EINTERNAL;
+      msg = e.msg;
+    } catch (const std::bad_alloc&) {
+      code = PRISM_GPU_EOOM;
+      msg = "host memory exhausted";
+    } catch (const std::exception& e) {
+      code = PRISM_GPU_EINTERNAL;
+      msg = std::string("internal error: ") + e.what();
+    }
+  }
+};
+
+// All-gather of n payload words per rank with the rank's status in front.  Returns the
+// gathered block ((n + 1) words per rank); throws on every rank when any rank reports a
+// failure: the rank's own error where it happened, "rank r failed" elsewhere.
+std::vector<int64_t> agree(prism_gpu_comm* c, const LocalStatus& st, const int64_t* mine, size_t n, const char* where) {
+  std::vector<int64_t> vec(n + 1, 0), all((n + 1) * (size_t)c->world);
+  vec[0] = st.code;
+  if (n && !st.code) std::memcpy(vec.data() + 1, mine, n * 8);
+  allgather_small(c, vec.data(), n + 1, all.data());
+  if (st.code) fail(st.code, st.msg);
+  for (int r = 0; r < c->world; ++r) {
+    const int64_t code = all[(size_t)r * (n + 1)];
+    if (code != 0)
+      fail((int)code, "rank " + std::to_string(r) + " of the communicator failed " + where + " (status " + std::to_string(code) +
+                          "); the query was given up on every rank");
+  }
+  return all;
+}
+
+// Test hook (prism_gpu_set_option "sharded_fail_phase"): the rank fails on purpose in the
+// given local phase of execute_sharded.
+void maybe_fail(prism_gpu_ctx* ctx, int phase) {
+  if (ctx->sharded_fail_phase.load(std::memory_order_relaxed) == phase)
+    fail(PRISM_GPU_EINTERNAL, "failure injected in phase " + std::to_string(phase) + " of the sharded execution");
+}
+
+int execute_sharded_impl(prism_gpu_comm* c, prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids,
+                         size_t n_partitions, int root, ArrowArray* out) {
   prism_gpu_ctx* ctx = c->ctx;
-  if (plan->ctx != ctx || table->ctx != ctx) fail(PRISM_GPU_EINVAL, "communicator, plan and table belong to different contexts");
-  if (root < 0 || root >= c->world) fail(PRISM_GPU_EINVAL, "root is not a rank of the communicator");
-  // what the device-resident state does not cover is refused before any collective, and for
-  // reasons every rank sees alike (the plan; the key width follows from the agreed statistics)
-  if (plan->keys.empty()) fail(PRISM_GPU_EUNSUPPORTED, "the sharded form needs a GROUP BY (ungrouped aggregates exchange PARTIAL batches)");
-  if (plan->mixed) fail(PRISM_GPU_EUNSUPPORTED, "COUNT(DISTINCT) next to other aggregates runs on one GPU only");
-  if (plan->mode != PRISM_MODE_SINGLE) fail(PRISM_GPU_EINVAL, "the sharded form runs plans in SINGLE mode: it does the merge itself");
-  bind(ctx);
   const int world = c->world, rank = c->rank;
   const size_t n_cols = plan->fields.size();
 
   // ---- 1. the statistics the keys are packed from, agreed with one all-gather ----
-  std::vector<prism_gpu_col_stats> mine(n_cols), agreed(n_cols);
-  scan_stats(plan, table, partition_ids, n_partitions, mine.data());
-  std::vector<int> string_keys;
+  // String columns that travel as dictionary codes -- GROUP BY keys, and the column of a
+  // COUNT(DISTINCT), which is packed like a key -- must have the same dictionary on every rank.
+  std::vector<int> coded;
   for (const KeyPlan& k : plan->keys)
-    if (plan->fields[k.column].is_string) string_keys.push_back(k.column);
-  const size_t vec_n = n_cols * 3 + string_keys.size();
-  std::vector<int64_t> vec(vec_n), all(vec_n * (size_t)world);
-  for (size_t i = 0; i < n_cols; ++i) {
-    vec[i * 3] = mine[i].min;
-    vec[i * 3 + 1] = mine[i].max;
-    vec[i * 3 + 2] = (int64_t)mine[i].nulls;
-  }
-  for (size_t i = 0; i < string_keys.size(); ++i) {
-    uint64_t digest = 0;
-    uint32_t n_values = 0;
-    table_dictionary_digest(table, string_keys[i], &digest, &n_values);
-    vec[n_cols * 3 + i] = (int64_t)digest;
-  }
-  allgather_small(c, vec.data(), vec_n, all.data());
-  for (size_t i = 0; i < n_cols; ++i) {
-    agreed[i] = {INT64_MAX, INT64_MIN, 0};
-    for (int r = 0; r < world; ++r) {
-      const int64_t* v = all.data() + (size_t)r * vec_n + i * 3;
-      if (v[0] > v[1]) { agreed[i].nulls += (uint64_t)v[2]; continue; }  // no value on that rank
-      agreed[i].min = std::min(agreed[i].min, v[0]);
-      agreed[i].max = std::max(agreed[i].max, v[1]);
-      agreed[i].nulls += (uint64_t)v[2];
+    if (plan->fields[k.column].is_string) coded.push_back(k.column);
+  if (plan->distinct_plan && plan->distinct_col >= 0 && plan->fields[plan->distinct_col].is_string) coded.push_back(plan->distinct_col);
+  const size_t vec_n = n_cols * 3 + coded.size();
+  std::vector<prism_gpu_col_stats> mine(n_cols), agreed(n_cols);
+  std::vector<int64_t> vec(vec_n, 0);
+  LocalStatus status;
+  status.run([&] {
+    scan_stats(plan, table, partition_ids, n_partitions, mine.data());
+    for (size_t i = 0; i < n_cols; ++i) {
+      vec[i * 3] = mine[i].min;
+      vec[i * 3 + 1] = mine[i].max;
+      vec[i * 3 + 2] = (int64_t)mine[i].nulls;
     }
+    for (size_t i = 0; i < coded.size(); ++i) {
+      uint64_t digest = 0;
+      uint32_t n_values = 0;
+      table_dictionary_digest(table, coded[i], &digest, &n_values);
+      vec[n_cols * 3 + i] = (int64_t)digest;
+    }
+    maybe_fail(ctx, 1);
+  });
+  {
+    const std::vector<int64_t> all = agree(c, status, vec.data(), vec_n, "while it collected its column statistics");
+    const size_t stride = vec_n + 1;
+    for (size_t i = 0; i < n_cols; ++i) {
+      agreed[i] = {INT64_MAX, INT64_MIN, 0};
+      for (int r = 0; r < world; ++r) {
+        const int64_t* v = all.data() + (size_t)r * stride + 1 + i * 3;
+        if (v[0] > v[1]) { agreed[i].nulls += (uint64_t)v[2]; continue; }  // no value on that rank
+        agreed[i].min = std::min(agreed[i].min, v[0]);
+        agreed[i].max = std::max(agreed[i].max, v[1]);
+        agreed[i].nulls += (uint64_t)v[2];
+      }
+    }
+    // (every rank sees the same digests, so every rank takes this exit or none does)
+    for (size_t i = 0; i < coded.size(); ++i)
+      for (int r = 1; r < world; ++r)
+        if (all[(size_t)r * stride + 1 + n_cols * 3 + i] != all[1 + n_cols * 3 + i])
+          fail(PRISM_GPU_EINVAL, "string column `" + plan->fields[coded[i]].name +
+                                     "` has different dictionaries on different ranks (its values travel as dictionary codes)");
   }
-  for (size_t i = 0; i < string_keys.size(); ++i)
-    for (int r = 1; r < world; ++r)
-      if (all[(size_t)r * vec_n + n_cols * 3 + i] != all[n_cols * 3 + i])
-        fail(PRISM_GPU_EINVAL, "string key column `" + plan->fields[string_keys[i]].name +
-                                   "` has different dictionaries on different ranks (string keys travel as dictionary codes)");
 
   // ---- 2. this rank's share ----
   StateGuard local;
-  local.st = aggregate_state(plan, table, partition_ids, n_partitions, agreed.data());
+  status.run([&] {
+    local.st = aggregate_state(plan, table, partition_ids, n_partitions, agreed.data());
+    maybe_fail(ctx, 2);
+  });
   const auto t0 = std::chrono::steady_clock::now();
   auto done = [&](int has) {
     std::lock_guard<std::mutex> g(c->mu);
     c->stats.exchange_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return has;
   };
-  StateView v = state_view(local.st);
+  StateView v;
+  status.run([&] { v = state_view(local.st); });
+  if (world == 1) {
+    if (status.code) fail(status.code, status.msg);
+    state_finish(local.st, out);
+    return done(1);
+  }
 
   // ---- 3a. small key space: the accumulator arrays are reduced in place ----
+  // (dense or not follows from the agreed statistics: the same on every rank that got this far)
+  OwnerParams op{};
+  Scratch d_counts, send;
+  std::vector<uint64_t> send_counts(world, 0);
+  const bool two = !status.code && v.key_words == 2;
+  const int width = status.code ? 0 : 1 + (two ? 1 : 0) + v.n_slots;
+  const uint64_t n = status.code ? 0 : v.entries;
+  uint64_t* send_keys = nullptr;
+  if (!status.code && !v.dense) {
+    // ---- 3b. large key space: rows to their owners, merge there, the owners' groups to root ----
+    // Rows travel in compact column form: keys, high words (two-word keys), one column per slot.
+    status.run([&] {
+      op.keys = v.keys;
+      op.keys_hi = v.keys_hi;
+      op.state = v.state;
+      op.n = n;
+      op.n_slots = v.n_slots;
+      op.world = (uint32_t)world;
+      // all pairs of a COUNT(DISTINCT) group must meet on one rank: the owner follows from the group alone
+      op.owner_of = v.distinct == 1 ? (two ? kOwnerHighWord : kOwnerHighBits) : kOwnerKey;
+      op.shift = v.pair_shift;
+      d_counts = Scratch(ctx, 8 * 64);
+      send = Scratch(ctx, std::max<uint64_t>(1, n) * 8 * (uint64_t)width);
+      launch_owner_count(ctx, op, d_counts.as<unsigned long long>());
+      std::vector<uint64_t> cursor(world, 0);
+      PRISM_HIP(hipMemcpyAsync(send_counts.data(), d_counts.p, 8 * (size_t)world, hipMemcpyDeviceToHost, ctx->stream));
+      PRISM_HIP(hipStreamSynchronize(ctx->stream));
+      for (int r = 1; r < world; ++r) cursor[r] = cursor[r - 1] + send_counts[r - 1];
+      PRISM_HIP(hipMemcpyAsync(d_counts.p, cursor.data(), 8 * (size_t)world, hipMemcpyHostToDevice, ctx->stream));
+      send_keys = send.as<uint64_t>();
+      uint64_t* const send_hi = two ? send_keys + n : nullptr;
+      int64_t* const send_state = (int64_t*)(send_keys + (two ? 2 : 1) * n);
+      launch_owner_scatter(ctx, op, d_counts.as<unsigned long long>(), send_keys, send_hi, send_state);
+      PRISM_HIP(hipStreamSynchronize(ctx->stream));
+    });
+  }
+  // who sends how much to whom (all zero from a rank with a dense state); the status of phase 2
+  std::vector<int64_t> counts_all;
+  {
+    const std::vector<int64_t> all = agree(c, status, (const int64_t*)send_counts.data(), (size_t)world, "while it aggregated its partitions");
+    counts_all.resize((size_t)world * world);
+    for (int s = 0; s < world; ++s)
+      std::memcpy(counts_all.data() + (size_t)s * world, all.data() + (size_t)s * (world + 1) + 1, 8 * (size_t)world);
+  }
   if (v.dense) {
     for (int s = 0; s < v.n_slots;) {
       int e = s + 1;
       const bool f64 = v.slot_ops[s] == kSlotAddF64;
       while (e < v.n_slots && reduce_of(v.slot_ops[e]) == reduce_of(v.slot_ops[s]) && (v.slot_ops[e] == kSlotAddF64) == f64) ++e;
       // slot arrays lie dense_stride apart, one spare entry between two: a run of slots is one array
-      const size_t n = (size_t)(e - s) * v.dense_stride - (v.dense_stride - v.entries);
-      reduce_device(c, v.dense_state + (uint64_t)s * v.dense_stride, n, f64 ? PRISM_REDUCE_F64 : PRISM_REDUCE_I64, reduce_of(v.slot_ops[s]), root);
+      const size_t cnt = (size_t)(e - s) * v.dense_stride - (v.dense_stride - v.entries);
+      reduce_device(c, v.dense_state + (uint64_t)s * v.dense_stride, cnt, f64 ? PRISM_REDUCE_F64 : PRISM_REDUCE_I64, reduce_of(v.slot_ops[s]), root);
       s = e;
     }
     PRISM_HIP(hipStreamSynchronize(ctx->stream));
@@ -337,68 +448,54 @@ int execute_sharded(prism_gpu_comm* c, prism_gpu_plan* plan, prism_gpu_table* ta
     state_finish(local.st, out);
     return done(1);
   }
-  if (world == 1) {
-    state_finish(local.st, out);
-    return done(1);
-  }
 
-  // ---- 3b. large key space: rows to their owners, merge there, the owners' groups to root ----
-  // Rows travel in compact column form: keys, high words (two-word keys), one column per slot.
-  const bool two = v.key_words == 2;
-  const int width = 1 + (two ? 1 : 0) + v.n_slots;
-  const uint64_t n = v.entries;
-  OwnerParams op{};
-  op.keys = v.keys;
-  op.keys_hi = v.keys_hi;
-  op.state = v.state;
-  op.n = n;
-  op.n_slots = v.n_slots;
-  op.world = (uint32_t)world;
-  // all pairs of a COUNT(DISTINCT) group must meet on one rank: the owner follows from the group alone
-  op.owner_of = v.distinct == 1 ? (two ? kOwnerHighWord : kOwnerHighBits) : kOwnerKey;
-  op.shift = v.pair_shift;
-  Scratch d_counts(ctx, 8 * 64), send(ctx, std::max<uint64_t>(1, n) * 8 * (uint64_t)width);
-  launch_owner_count(ctx, op, d_counts.as<unsigned long long>());
-  std::vector<uint64_t> send_counts(world, 0), cursor(world, 0);
-  PRISM_HIP(hipMemcpyAsync(send_counts.data(), d_counts.p, 8 * (size_t)world, hipMemcpyDeviceToHost, ctx->stream));
-  PRISM_HIP(hipStreamSynchronize(ctx->stream));
-  for (int r = 1; r < world; ++r) cursor[r] = cursor[r - 1] + send_counts[r - 1];
-  PRISM_HIP(hipMemcpyAsync(d_counts.p, cursor.data(), 8 * (size_t)world, hipMemcpyHostToDevice, ctx->stream));
-  uint64_t* const send_keys = send.as<uint64_t>();
-  uint64_t* const send_hi = two ? send_keys + n : nullptr;
-  int64_t* const send_state = (int64_t*)(send_keys + (two ? 2 : 1) * n);
-  launch_owner_scatter(ctx, op, d_counts.as<unsigned long long>(), send_keys, send_hi, send_state);
-  // who sends how much to whom
-  std::vector<int64_t> counts_all((size_t)world * world);
-  allgather_small(c, (const int64_t*)send_counts.data(), (size_t)world, counts_all.data());
   std::vector<uint64_t> recv_counts(world);
   uint64_t recv_total = 0;
   for (int s = 0; s < world; ++s) recv_total += recv_counts[s] = (uint64_t)counts_all[(size_t)s * world + rank];
-  Scratch recv(ctx, std::max<uint64_t>(1, recv_total) * 8 * (uint64_t)width);
+  // (the receive block is allocated before the collective: a rank that cannot have it must not
+  // leave the others inside the all-to-all, so the allocation's outcome is agreed first)
+  Scratch recv;
+  status.run([&] {
+    recv = Scratch(ctx, std::max<uint64_t>(1, recv_total) * 8 * (uint64_t)width);
+    maybe_fail(ctx, 3);
+  });
+  agree(c, status, nullptr, 0, "before the all-to-all of its group rows");
   alltoallv_columns(c, width, send_keys, n, send_counts, recv.as<uint64_t>(), recv_total, recv_counts);
   PRISM_HIP(hipStreamSynchronize(ctx->stream));
   collect_timings(ctx);
   send.reset();
 
   // the owner's table: same key packing, no rows of its own
-  StateGuard owned;
+  StateGuard owned, outer;
   const uint32_t no_partition = 0xFFFFFFFFu;
-  owned.st = aggregate_state(plan, table, &no_partition, 1, agreed.data());
-  {
+  prism_gpu_state* work = nullptr;
+  StateView w;
+  status.run([&] {
+    owned.st = aggregate_state(plan, table, &no_partition, 1, agreed.data());
     const uint64_t* rk = recv.as<uint64_t>();
     state_merge_rows(owned.st, rk, two ? rk + recv_total : nullptr, (const int64_t*)(rk + (two ? 2 : 1) * recv_total), recv_total);
+    recv.reset();
+    // COUNT(DISTINCT): the owner holds every pair of its groups, so it can count them; what goes
+    // on to the root are (group, count) rows of groups no other rank has
+    work = owned.st;
+    if (v.distinct == 1) {
+      outer.st = state_distinct_outer(owned.st);
+      work = outer.st;
+    }
+    w = state_view(work);
+    maybe_fail(ctx, 4);
+  });
+  // the owner's groups that can still make the result
+  Scratch lead_keys, lead_hi, lead_state;
+  int64_t n_lead_i = 0;
+  status.run([&] {
+    if (!w.dense) n_lead_i = (int64_t)state_leading_rows(work, lead_keys, lead_hi, lead_state);
+  });
+  std::vector<int64_t> lead_all(world);
+  {
+    const std::vector<int64_t> all = agree(c, status, &n_lead_i, 1, "while it merged the group rows it owns");
+    for (int s = 0; s < world; ++s) lead_all[s] = all[(size_t)s * 2 + 1];
   }
-  recv.reset();
-
-  // COUNT(DISTINCT): the owner holds every pair of its groups, so it can count them; what goes
-  // on to the root are (group, count) rows of groups no other rank has
-  StateGuard outer;
-  prism_gpu_state* work = owned.st;
-  if (v.distinct == 1) {
-    outer.st = state_distinct_outer(owned.st);
-    work = outer.st;
-  }
-  StateView w = state_view(work);
   if (w.dense) {
     for (int s = 0; s < w.n_slots; ++s)
       reduce_device(c, w.dense_state + (uint64_t)s * w.dense_stride, w.entries, PRISM_REDUCE_I64, reduce_of(w.slot_ops[s]), root);
@@ -408,27 +505,28 @@ int execute_sharded(prism_gpu_comm* c, prism_gpu_plan* plan, prism_gpu_table* ta
     return done(1);
   }
 
-  // the owner's groups that can still make the result
   const bool wtwo = w.key_words == 2;
   const int wwidth = 1 + (wtwo ? 1 : 0) + w.n_slots;
-  Scratch lead_keys, lead_hi, lead_state;
-  const uint64_t n_lead = state_leading_rows(work, lead_keys, lead_hi, lead_state);
-  std::vector<int64_t> lead_all(world);
-  const int64_t n_lead_i = (int64_t)n_lead;
-  allgather_small(c, &n_lead_i, 1, lead_all.data());
+  const uint64_t n_lead = (uint64_t)n_lead_i;
   std::vector<uint64_t> to_root(world, 0), from_all(world, 0);
   to_root[root] = n_lead;
   uint64_t root_total = 0;
   if (rank == root)
     for (int s = 0; s < world; ++s) root_total += from_all[s] = (uint64_t)lead_all[s];
   // keys, high words and slot columns sit in separate blocks: sent as separate column sets
-  Scratch gathered(ctx, std::max<uint64_t>(1, root_total) * 8 * (uint64_t)wwidth);
+  Scratch gathered;
+  status.run([&] {
+    gathered = Scratch(ctx, std::max<uint64_t>(1, root_total) * 8 * (uint64_t)wwidth);
+    maybe_fail(ctx, 5);
+  });
+  agree(c, status, nullptr, 0, "before its leading groups went to the root");
   uint64_t* const gk = gathered.as<uint64_t>();
   alltoallv_columns(c, 1, lead_keys.as<uint64_t>(), n_lead, to_root, gk, root_total, from_all);
   if (wtwo) alltoallv_columns(c, 1, lead_hi.as<uint64_t>(), n_lead, to_root, gk + root_total, root_total, from_all);
   alltoallv_columns(c, w.n_slots, lead_state.as<uint64_t>(), n_lead, to_root, gk + (wtwo ? 2 : 1) * root_total, root_total, from_all);
   PRISM_HIP(hipStreamSynchronize(ctx->stream));
   if (rank != root) return done(0);
+  // (no collective follows: what fails from here on fails on the root alone, and the others are done)
   StateGuard empty_inner, final_state;
   if (v.distinct == 1) {
     empty_inner.st = aggregate_state(plan, table, &no_partition, 1, agreed.data());
@@ -439,6 +537,34 @@ int execute_sharded(prism_gpu_comm* c, prism_gpu_plan* plan, prism_gpu_table* ta
   state_merge_rows(final_state.st, gk, wtwo ? gk + root_total : nullptr, (const int64_t*)(gk + (wtwo ? 2 : 1) * root_total), root_total);
   state_finish(final_state.st, out);
   return done(1);
+}
+
+}  // namespace
+
+int execute_sharded(prism_gpu_comm* c, prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids,
+                    size_t n_partitions, int root, ArrowArray* out) {
+  prism_gpu_ctx* ctx = c->ctx;
+  if (plan->ctx != ctx || table->ctx != ctx) fail(PRISM_GPU_EINVAL, "communicator, plan and table belong to different contexts");
+  if (root < 0 || root >= c->world) fail(PRISM_GPU_EINVAL, "root is not a rank of the communicator");
+  if (c->aborted) fail(PRISM_GPU_ERCCL, "the communicator was torn down after a collective failed; create a new one");
+  // what the device-resident state does not cover is refused before any collective, and for
+  // reasons every rank sees alike (the plan; the key width follows from the agreed statistics)
+  if (plan->keys.empty()) fail(PRISM_GPU_EUNSUPPORTED, "the sharded form needs a GROUP BY (ungrouped aggregates exchange PARTIAL batches)");
+  if (plan->mixed) fail(PRISM_GPU_EUNSUPPORTED, "COUNT(DISTINCT) next to other aggregates runs on one GPU only");
+  if (plan->mode != PRISM_MODE_SINGLE) fail(PRISM_GPU_EINVAL, "the sharded form runs plans in SINGLE mode: it does the merge itself");
+  bind(ctx);
+  try {
+    return execute_sharded_impl(c, plan, table, partition_ids, n_partitions, root, out);
+  } catch (const Error& e) {
+    // A collective that failed leaves the ranks out of step (some may be inside it still): the
+    // RCCL communicator is aborted, which also releases peers blocked in it, and takes no more calls.
+    if (e.code == PRISM_GPU_ERCCL && c->nccl && c->world > 1) {
+      (void)rccl().CommAbort(c->nccl);
+      c->nccl = nullptr;
+      c->aborted = true;
+    }
+    throw;
+  }
 }
 
 }  // namespace prism

@@ -322,8 +322,9 @@ void rle_decode(const uint8_t* p, const uint8_t* end, int bit_width, size_t coun
     const uint64_t h = v.varint();
     if (h & 1) {  // bit-packed: groups of 8 values
       const uint64_t groups = h >> 1;
+      // (checked before multiplying: a huge group count would wrap the byte count round to a small one)
+      if (groups > (uint64_t)(v.end - v.p) / (uint64_t)bit_width) bad("bit-packed run beyond the page");
       const uint64_t bytes = groups * (uint64_t)bit_width;
-      if (bytes > (uint64_t)(v.end - v.p)) bad("bit-packed run beyond the page");
       const uint8_t* b = v.p;
       uint64_t bitpos = 0;
       const uint64_t values = groups * 8;
@@ -418,8 +419,10 @@ void decode_chunk(const uint8_t* file, size_t len, const Leaf& leaf, const Chunk
   const bool strings = leaf.physical == kByteArray;
   int64_t pos = cm.data_page_offset;
   if (cm.dictionary_page_offset > 0 && cm.dictionary_page_offset < pos) pos = cm.dictionary_page_offset;
+  if (pos < 4 || pos > (int64_t)len || cm.total_compressed < 0 || cm.total_compressed > (int64_t)len - pos)
+    bad("column chunk of `" + leaf.name + "` lies outside the file");
+  if (rows < 0 || cm.num_values < 0) bad("negative row or value count in `" + leaf.name + "`");
   const int64_t chunk_end = pos + cm.total_compressed;
-  if (pos < 4 || chunk_end > (int64_t)len) bad("column chunk of `" + leaf.name + "` lies outside the file");
   Dictionary dict;
   std::vector<uint8_t> page, levels_buf;
   std::vector<uint32_t> def, idx;
@@ -431,7 +434,8 @@ void decode_chunk(const uint8_t* file, size_t len, const Leaf& leaf, const Chunk
     Thrift t{file + pos, file + chunk_end};
     const PageHeader h = read_page_header(t);
     const uint8_t* body = t.p;
-    if (h.compressed < 0 || h.uncompressed < 0 || body + h.compressed > file + chunk_end) bad("page of `" + leaf.name + "` lies outside its chunk");
+    if (h.compressed < 0 || h.uncompressed < 0 || (int64_t)h.compressed > (file + chunk_end) - body) bad("page of `" + leaf.name + "` lies outside its chunk");
+    if (h.num_values < 0 || h.def_len < 0 || h.rep_len < 0) bad("negative count or length in a page header of `" + leaf.name + "`");
     pos = (int64_t)(body - file) + h.compressed;
     if (h.type != 0 && h.type != 2 && h.type != 3) continue;  // index pages and the like
 
@@ -443,7 +447,7 @@ void decode_chunk(const uint8_t* file, size_t len, const Leaf& leaf, const Chunk
     if (h.type == 3) {
       if (h.rep_len != 0) unsupported("repetition levels in `" + leaf.name + "`");
       const int64_t lv = (int64_t)h.def_len + h.rep_len;
-      if (lv > h.compressed) bad("levels longer than the page");
+      if (lv > h.compressed || lv > h.uncompressed) bad("levels longer than the page");
       def_p = body;
       def_end = body + h.def_len;
       const uint8_t* data = body + lv;

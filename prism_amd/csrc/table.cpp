@@ -54,6 +54,7 @@ struct StageWriter {
   uint8_t* dst = nullptr;  // device address the next flushed byte goes to
   int half = -1;
   size_t fill = 0;
+  uint64_t staged = 0;  // bytes handed to the copy stream; the owner adds them to the statistics under ctx->mu
   explicit StageWriter(prism_gpu_ctx* c) : ctx(c) {}
   void begin(void* device_dst) { flush(); dst = (uint8_t*)device_dst; }
   void acquire() {
@@ -79,7 +80,7 @@ struct StageWriter {
     PRISM_HIP(hipMemcpyAsync(dst, ctx->stage[half], fill, hipMemcpyHostToDevice, ctx->copy_stream));
     PRISM_HIP(hipEventRecord(ctx->stage_done[half], ctx->copy_stream));
     ctx->stage_used[half] = true;
-    ctx->stats.bytes_staged += fill;
+    staged += fill;
     dst += fill;
     half = -1;
     fill = 0;
@@ -93,6 +94,8 @@ void stage_copy(prism_gpu_ctx* ctx, void* dst, const void* src, size_t bytes) {
   w.begin(dst);
   w.write(src, bytes);
   w.flush();
+  std::lock_guard<std::mutex> gs(ctx->mu);
+  ctx->stats.bytes_staged += w.staged;
 }
 
 bool bit_at(const uint8_t* bits, int64_t i) { return (bits[i >> 3] >> (i & 7)) & 1; }
@@ -222,6 +225,7 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
     n += batch->length;
   }
   if (n == 0) return;
+  // (prism_gpu_table_append cuts larger batches up itself; the streaming path gathers about 2^20 rows per chunk)
   if (n > 0x1fffffff) fail(PRISM_GPU_EUNSUPPORTED, "a chunk may hold at most 2^29-1 rows");
 
   auto t0 = std::chrono::steady_clock::now();
@@ -413,6 +417,7 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
   {
     std::lock_guard<std::mutex> gs(ctx->mu);
     ctx->stats.staging_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    ctx->stats.bytes_staged += w.staged;
   }
   guard.armed = false;
   t->chunks.push_back(std::move(ch));
@@ -420,7 +425,26 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
 
 void table_append(prism_gpu_table* t, uint32_t partition_id, ArrowArray* batch, bool take) {
   ArrowArray* one[1] = {batch};
-  table_append_batches(t, partition_id, one, 1, take);
+  constexpr int64_t kMaxChunkRows = 1ll << 28;
+  if (!batch || batch->length <= kMaxChunkRows || batch->offset < 0) {
+    table_append_batches(t, partition_id, one, 1, take);
+    return;
+  }
+  // A batch of more rows than a chunk holds (kernels address a chunk's column with 32-bit byte
+  // offsets) becomes several chunks of the partition: row ranges of the same buffers, borrowed.
+  struct Releaser {
+    ArrowArray* b;
+    bool take;
+    ~Releaser() { if (take && b->release) b->release(b); }
+  } releaser{batch, take};
+  for (int64_t first = 0; first < batch->length; first += kMaxChunkRows) {
+    ArrowArray slice = *batch;
+    slice.offset = batch->offset + first;
+    slice.length = std::min<int64_t>(kMaxChunkRows, batch->length - first);
+    slice.release = nullptr;
+    ArrowArray* part[1] = {&slice};
+    table_append_batches(t, partition_id, part, 1, false);
+  }
 }
 
 void table_synth(prism_gpu_table* t, uint32_t partition_id, uint64_t seed, uint64_t first_row, uint64_t n_rows,

@@ -154,3 +154,23 @@ def test_callbacks_transport_two_ranks():
     # rank 0 receives word 0 of rank 0 and words 0..1 of rank 1; rank 1 the rest, in rank order
     assert out[0][6] == [0, 1000, 1001]
     assert out[1][6] == [1, 2, 1002, 1003, 1004, 1005]
+
+
+def test_bench_gpus_n_starts_n_ranks_by_itself():
+    """`python bench.py --gpus 2` with no launcher around it: the script starts two ranks as
+    child processes (torch.distributed.run) before it touches any GPU and relays rank 0's
+    line.  --check-launch stops after the rendezvous, which needs no GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--check-launch"], capture_output=True,
+                       text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    got = json.loads(lines[0])
+    assert got == {"check_launch": True, "n_gpus_asked": 2, "ranks_met": 2, "rank_sum": 1}

@@ -208,3 +208,117 @@ def test_ranks_share_the_gpu_and_exchange_inside_the_library(world):
     for p in procs:
         p.join(timeout=60)
     assert results == {r: "ok" for r in range(world)}, results
+
+
+def _failing_rank_worker(rank: int, world: int, port: int, q):
+    """Two ranks sharing GPU 0.  (a) COUNT(DISTINCT) over a string column whose dictionaries
+    differ between the ranks; (b) one rank fails on purpose in each local phase of the sharded
+    execution.  Every rank must come back with an error: nobody waits in a collective."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import pyarrow as pa
+    import torch.distributed as dist
+
+    from prism_amd import _cabi as abi_
+    from prism_amd import workloads
+    from prism_amd.distributed import exchange_and_finish, make_comm
+    from prism_amd.engine import Context, Plan, PrismGpuError, Table
+    from prism_amd.plan import QueryPlan as Q, count_distinct as cd, count_star as cs
+    from tests.helpers import assert_tables_match
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    ctx = Context(0)
+    comm = make_comm(ctx)
+    log = []
+    try:
+        # (a) the same strings, appended in a different order on each rank: different codes
+        names = [f"user-{i:03d}" for i in range(40)]
+        order = names if rank == 0 else names[::-1]
+        t = pa.table({"g": pa.array([i % 5 for i in range(4000)], pa.int64()),
+                      "who": pa.array([order[(i * 7 + i // 40) % 40] for i in range(4000)], pa.string())})
+        g = Table(ctx, t.schema)
+        g.append_table(t, 2)
+        plan = Plan(ctx, t.schema, Q([cd("who")], keys=["g"]))
+        try:
+            exchange_and_finish(plan, g, None, comm, 0)
+            log.append("no error for differing dictionaries")
+        except PrismGpuError as e:
+            if e.code != abi_.EINVAL or "dictionar" not in e.msg:
+                log.append(f"differing dictionaries: {e.code} {e.msg}")
+        finally:
+            plan.close()
+        # the same dictionary everywhere: the counts are right (40 names in every group)
+        g2 = Table(ctx, t.schema)
+        g2.set_dictionary("who", names)
+        g2.append_table(t, 2)
+        plan = Plan(ctx, t.schema, Q([cd("who")], keys=["g"]))
+        try:
+            got = exchange_and_finish(plan, g2, None, comm, 0)
+        finally:
+            plan.close()
+        if rank == 0:
+            both = pa.concat_tables([pa.table({"g": t.column("g"), "who": pa.array([names[(i * 7 + i // 40) % 40] for i in range(4000)])}),
+                                     pa.table({"g": t.column("g"), "who": pa.array([names[::-1][(i * 7 + i // 40) % 40] for i in range(4000)])})])
+            from oracle import pyoracle
+
+            assert_tables_match(got, pyoracle.execute(both, Q([cd("who")], keys=["g"])), 1)
+        g.close()
+        g2.close()
+
+        # (b) rank 1 fails in phase k: both ranks get an error, then the next query works again
+        c3 = workloads.c3(id_bits=16)
+        c2 = workloads.c2()
+        rows = 100_000
+        for wl, phases in ((c2, (1, 2)), (c3, (1, 2, 3, 4, 5))):
+            table = workloads.build_gpu_table(ctx, wl, rows * rank, rows, rows * world, 2)
+            plan = Plan(ctx, wl.schema, Q([cs()], keys=wl.query.keys))
+            try:
+                for phase in phases:
+                    if rank == 1:
+                        ctx.set_option("sharded_fail_phase", phase)
+                    try:
+                        exchange_and_finish(plan, table, None, comm, 0)
+                        log.append(f"{wl.name} phase {phase}: no error on rank {rank}")
+                    except PrismGpuError as e:
+                        if rank == 1 and "injected" not in e.msg:
+                            log.append(f"{wl.name} phase {phase}: rank 1 got {e.msg}")
+                        if rank == 0 and "rank 1" not in e.msg:
+                            log.append(f"{wl.name} phase {phase}: rank 0 got {e.msg}")
+                    ctx.set_option("sharded_fail_phase", 0)
+                    got = exchange_and_finish(plan, table, None, comm, 0)  # the communicator is still in step
+                    if rank == 0 and sum(got.column("COUNT(*)").to_pylist()) != rows * world:
+                        log.append(f"{wl.name} after phase {phase}: wrong counts")
+            finally:
+                plan.close()
+                table.close()
+        q.put((rank, "ok" if not log else "; ".join(log)))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+
+        q.put((rank, traceback.format_exc() + repr(e)))
+    finally:
+        comm.close()
+        ctx.close()
+        dist.destroy_process_group()
+
+
+def test_a_failure_on_one_rank_is_an_error_on_every_rank():
+    import socket
+
+    import torch.multiprocessing as mp
+
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_failing_rank_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert results == {r: "ok" for r in range(world)}, results

@@ -141,3 +141,38 @@ def test_library_decodes_the_parquet_files_itself(gpu_ctx):
         assert e.value.code == -2 and "`value`" in e.value.msg
     finally:
         g.close()
+
+
+def test_a_batch_of_more_rows_than_a_chunk_holds_becomes_several_chunks(gpu_ctx):
+    """prism_gpu_table_append takes a RecordBatch of any length (DataFusion's are small, a
+    caller that concatenates a partition first is not): beyond 2^28 rows it is cut into chunks
+    of the same partition.  COUNT / SUM / MIN / MAX and a GROUP BY equal numpy's."""
+    import numpy as np
+
+    from prism_amd.engine import Plan, Table
+    from prism_amd.plan import min_
+
+    n = (1 << 28) + 12_345
+    v = (np.arange(n, dtype=np.int64) % 977).astype(np.int16)
+    t = pa.table({"v": pa.array(v)})
+    g = Table(gpu_ctx, t.schema)
+    try:
+        g.append_table(t, 1)
+        del t
+        assert g.num_rows == n and g.num_partitions == 1
+        plan = Plan(gpu_ctx, g.schema, QueryPlan([count_star(), sum_("v"), min_("v"), max_("v")]))
+        try:
+            got = plan.execute(g).to_pylist()[0]
+        finally:
+            plan.close()
+        assert list(got.values()) == [n, int(v.astype(np.int64).sum()), 0, 976]
+        plan = Plan(gpu_ctx, g.schema, QueryPlan([count_star()], keys=["v"]))
+        try:
+            by_v = plan.execute(g)
+        finally:
+            plan.close()
+        counts = dict(zip(by_v.column("v").to_pylist(), by_v.column("COUNT(*)").to_pylist()))
+        want = np.bincount(v.astype(np.int64), minlength=977)
+        assert counts == {i: int(c) for i, c in enumerate(want)}
+    finally:
+        g.close()

@@ -103,3 +103,126 @@ def test_what_is_not_covered_says_so():
         engine.parquet_read(broken)
     except engine.PrismGpuError as err:
         assert err.code in (abi.EINVAL, abi.EUNSUPPORTED)
+
+
+# ---- hostile header fields: the decoder is reachable from the C ABI with bytes it did not write ----
+
+def _varint_at(data: bytes, p: int):
+    """(value, next position) of the ULEB128 varint at p."""
+    v, shift = 0, 0
+    while True:
+        b = data[p]
+        p += 1
+        v |= (b & 0x7F) << shift
+        shift += 7
+        if not b & 0x80:
+            return v, p
+
+
+def _page_header_fields(data: bytes, pos: int):
+    """Walks the Thrift compact PageHeader at `pos` and returns {(struct field, field): (offset of the
+    zigzag varint, its byte length)} for the i32 fields of the header (struct field 0) and of its
+    nested DataPageHeader (5) / DataPageHeaderV2 (8), and the offset of the page body."""
+    out = {}
+
+    def walk(p, outer):
+        last = 0
+        while True:
+            b = data[p]
+            p += 1
+            if b == 0:
+                return p
+            delta, ty = b >> 4, b & 15
+            if delta == 0:
+                fid, p = _varint_at(data, p)
+                fid = (fid >> 1) ^ -(fid & 1)
+            else:
+                fid = last + delta
+            last = fid
+            if ty in (1, 2):
+                continue
+            if ty in (5, 6):  # i32 / i64: zigzag varint
+                _, q = _varint_at(data, p)
+                out[(outer, fid)] = (p, q - p)
+                p = q
+            elif ty == 12:
+                p = walk(p, fid)
+            elif ty == 8:  # binary
+                n, p = _varint_at(data, p)
+                p += n
+            else:
+                raise AssertionError(f"unexpected thrift type {ty} in a page header")
+
+    body = walk(pos, 0)
+    return out, body
+
+
+def _negate_in_place(data: bytearray, off: int, length: int):
+    """Makes the zigzag varint at `off` decode to a negative number without changing its length."""
+    data[off] |= 1  # zigzag: odd = negative
+
+
+def _first_data_page(data: bytes, column: int = 0) -> int:
+    md = pq.ParquetFile(io.BytesIO(data)).metadata
+    return md.row_group(0).column(column).data_page_offset
+
+
+@pytest.mark.parametrize("version", ["1.0", "2.0"])
+def test_negative_num_values_in_a_page_header_is_einval(version):
+    t = pa.table({"a": pa.array(np.arange(1000, dtype=np.int64))}, schema=pa.schema([pa.field("a", pa.int64(), nullable=False)]))
+    data = bytearray(_write(t, data_page_version=version, compression="none", use_dictionary=False))
+    fields, _ = _page_header_fields(bytes(data), _first_data_page(bytes(data)))
+    off, ln = fields[(8 if version == "2.0" else 5, 1)]  # num_values
+    _negate_in_place(data, off, ln)
+    with pytest.raises(engine.PrismGpuError) as e:
+        engine.parquet_read(bytes(data))
+    assert e.value.code == abi.EINVAL
+
+
+def test_negative_level_lengths_and_sizes_are_einval():
+    t = pa.table({"a": pa.array([None if i % 7 == 0 else i for i in range(1000)], type=pa.int64())})
+    good = _write(t, data_page_version="2.0", compression="none", use_dictionary=False)
+    fields, _ = _page_header_fields(good, _first_data_page(good))
+    # DataPageHeaderV2: 5 = definition_levels_byte_length, 6 = repetition_levels_byte_length (0: "negative zero"
+    # stays zero, skipped); PageHeader: 2 = uncompressed_page_size, 3 = compressed_page_size
+    for key in [(8, 5), (0, 2), (0, 3)]:
+        data = bytearray(good)
+        off, ln = fields[key]
+        _negate_in_place(data, off, ln)
+        with pytest.raises(engine.PrismGpuError) as e:
+            engine.parquet_read(bytes(data))
+        assert e.value.code == abi.EINVAL, key
+
+
+def test_bit_packed_run_with_a_wrapping_group_count_is_einval():
+    rng = np.random.default_rng(5)
+    t = pa.table({"a": pa.array(rng.integers(0, 200, 5000), type=pa.int64())},
+                 schema=pa.schema([pa.field("a", pa.int64(), nullable=False)]))
+    data = bytearray(_write(t, data_page_version="1.0", compression="none", use_dictionary=True))
+    _, body = _page_header_fields(bytes(data), _first_data_page(bytes(data)))
+    # body[0] is the bit width of the dictionary indices, then the first run header of the hybrid:
+    # bit width 32 and a bit-packed run of 2^59 groups, whose byte count wraps round to zero in 64 bits
+    data[body] = 32
+    header = ((1 << 59) << 1) | 1
+    p = body + 1
+    while True:
+        b = header & 0x7F
+        header >>= 7
+        data[p] = b | (0x80 if header else 0)
+        p += 1
+        if not header:
+            break
+    with pytest.raises(engine.PrismGpuError) as e:
+        engine.parquet_read(bytes(data))
+    assert e.value.code == abi.EINVAL
+
+
+def test_a_column_chunk_that_claims_bytes_outside_the_file_is_einval():
+    t = pa.table({"a": pa.array(np.arange(100, dtype=np.int64))})
+    good = _write(t, data_page_version="2.0", compression="none", use_dictionary=False)
+    # chop the file's middle out but keep the footer: offsets in the metadata now point past the data
+    md_len = int.from_bytes(good[-8:-4], "little")
+    broken = good[:4] + good[-(md_len + 8):]
+    with pytest.raises(engine.PrismGpuError) as e:
+        engine.parquet_read(broken)
+    assert e.value.code == abi.EINVAL

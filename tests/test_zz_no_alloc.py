@@ -1,7 +1,8 @@
 """prism_gpu_execute_noalloc (the entry point that allocates no device memory) against
 prism_gpu_execute on the same plan and partitions, through the C ABI: two calls in a row,
 the second over a smaller input, so that whatever the first call left in the library's
-device array would show."""
+device array would show.  The whole-table result is also checked against the CPU oracle, so
+that a fault shared by both entry points would not pass."""
 import numpy as np
 import pyarrow as pa
 import pytest
@@ -69,6 +70,18 @@ def test_noalloc_matches_execute_twice_second_call_smaller(gpu_ctx):
                     got = _rows_from_buffers(plan, wl.dictionaries, values.cpu().numpy(), valid.cpu().numpy(), n)
                     assert n == len(want) and n > 0
                     assert got == want  # integers and keys exactly; AVG is the same division of the same sums
+                    if partitions is None:
+                        from oracle import pyoracle
+                        from tests.helpers import assert_tables_match
+
+                        st = pyoracle.SynthTable(wl.schema, wl.make_cols(), wl.seed, 0, rows, rows, n_parts=parts)
+                        try:
+                            oracle_rows, _ = st.execute(q)
+                        finally:
+                            st.close()
+                        oracle_rows = workloads.decode_dictionary_columns(wl, oracle_rows)
+                        assert_tables_match(plan.execute(table, None), oracle_rows, 2)
+                        assert n == oracle_rows.num_rows
                 # buffers too short: an error, and nothing written past them
                 with pytest.raises(PrismGpuError) as e:
                     plan.execute_noalloc(table, None, values.data_ptr(), valid.data_ptr(), 16)
