@@ -478,7 +478,7 @@ def main() -> int:
             single.close()
             table.close()
             single = table = None
-            line["workloads"] = extra_workloads(ctx, steps=5, warmup=2)
+            line["workloads"] = extra_workloads(ctx, steps=5, warmup=3)
         print(json.dumps(line), file=json_out, flush=True)
 
     if comm is not None:
