@@ -204,6 +204,10 @@ void prism_gpu_ctx_free(prism_gpu_ctx* ctx);
  *                    the streaming kernel to report that its rows scatter (default 0)
  *   "part_half_blocks" 0: the scatter pass of a partitioned GROUP BY always runs one workgroup of
  *                    1024 threads per CU; 1 (default): two of 512 threads where the records allow it
+ *   "part_wc"        0: GROUP BY <one-word key> with COUNT(*) alone is always partitioned with a
+ *                    histogram pass; 1 (default): without one (hot keys counted in LDS, fixed
+ *                    segments per workgroup and bucket), falling back when a segment overflows
+ *   "part_wc_min_rows" fewer selected rows never take that path (default 8388608)
  *   "part2_compact"  0: COUNT(DISTINCT) partitioned twice always keeps two-word records at the
  *                    second level; 1 (default): one-word records when the pairs allow it
  *   "contains_windows" 0: LIKE '%needle%' over a column without a dictionary always uses the

@@ -138,6 +138,7 @@ struct prism_gpu_plan {
   std::atomic<int> part_mode{0};
   std::atomic<uint64_t> part_groups{0};
   std::atomic<uint64_t> part_table_capacity{0};  // capacity that the HBM table behind the LDS tables needed last time
+  std::atomic<int> wc_mode{0};  // -1: the histogram-free GROUP BY overflowed a segment or an LDS table on this plan's data
   // COUNT(DISTINCT) partitioned twice: distinct pairs per 1024 rows of the last run (0: not run yet);
   // rows that repeat a pair need no entry of the LDS sets, so fine buckets may hold more rows
   std::atomic<uint32_t> distinct_pairs_per_1024{0};

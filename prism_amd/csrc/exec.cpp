@@ -1109,6 +1109,88 @@ uint64_t emit_groups(prism_gpu_ctx* ctx, const prism_gpu_plan* plan, const prism
 uint64_t part_min_rows(const prism_gpu_ctx* ctx) { return ctx->part_min_rows; }
 bool part_forced(const prism_gpu_ctx* ctx) { return ctx->part_force != 0; }
 
+// GROUP BY <one-word key> -> COUNT(*) without a histogram pass (kernels_wc.hip).  True: `gt`
+// is the list of the groups and *groups_out their number.  False: a segment or an LDS table
+// overflowed (nothing usable was produced; the plan remembers, and the caller partitions with
+// the histogram).
+bool wc_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggParams& ap, uint64_t selected, uint64_t key_bytes,
+                 const std::vector<int>& slot_ops, GroupTable& gt, uint64_t* groups_out) {
+  WcParams w;
+  std::memset(&w, 0, sizeof(w));
+  const uint64_t per = std::max<uint64_t>(1, ceil_div(ap.sd.n_tiles, (uint64_t)ctx->n_cus));
+  w.tiles_per_wg = (uint32_t)per;
+  w.n_wg = (uint32_t)std::max<uint64_t>(1, ceil_div(ap.sd.n_tiles, per));
+  const uint32_t P = wc_buckets();
+  // a segment: the rows a (workgroup, bucket) pair expects, half as many again, and a margin
+  // for small scans whose counts vary more
+  const uint64_t mean = ceil_div(selected, (uint64_t)w.n_wg * P);
+  uint64_t cap = pow2_ceil(std::max<uint64_t>(64, mean + mean / 2 + 64));
+  while ((1ull << w.cap_shift) < cap) ++w.cap_shift;
+  w.lds_entries = wc_lds_entries(w.n_wg);
+  w.sample_tiles = (uint32_t)std::min<uint64_t>(64, ap.sd.n_tiles);
+  // a candidate: a key seen this often in the sample (1/32768 of it, at least 4 times)
+  w.hot_threshold = (uint32_t)std::max<uint64_t>(4, ((uint64_t)w.sample_tiles * kTileRows) >> 15);
+  const uint64_t n_cm = wc_sample_counters();
+  Scratch rec(ctx, ((uint64_t)P * w.n_wg << w.cap_shift) * 8 + 256), seg_count(ctx, (uint64_t)P * w.n_wg * 4),
+      cm(ctx, n_cm * 4), cand(ctx, (uint64_t)wc_max_candidates() * 8), hot(ctx, (uint64_t)wc_hot_slots() * 16), d_small(ctx, 256);
+  w.rec = rec.as<uint64_t>();
+  w.seg_count = seg_count.as<uint32_t>();
+  w.cm = cm.as<uint32_t>();
+  w.cand = cand.as<uint64_t>();
+  w.hot_keys = hot.as<uint64_t>();
+  w.hot_count = (unsigned long long*)(hot.as<uint64_t>() + wc_hot_slots());
+  // one small block: [0] the list cursor (8 bytes), [8] the candidates, [16] three flags
+  w.list_cursor = d_small.as<unsigned long long>();
+  w.n_cand = (uint32_t*)(d_small.as<uint8_t>() + 8);
+  w.flags = (uint32_t*)(d_small.as<uint8_t>() + 16);
+  uint64_t groups_est = plan->part_groups.load(std::memory_order_relaxed);
+  if (!groups_est) groups_est = plan->groups_hint;
+  uint64_t list_cap = groups_est ? groups_est + groups_est / 16 + 1024 : std::min<uint64_t>(selected, 1ull << 25);
+  list_cap = std::max<uint64_t>(1, std::min(list_cap, selected + wc_hot_slots()));
+  for (;;) {
+    GroupTable list;
+    list.list = true;
+    list.capacity = list_cap;
+    list.n_slots = 1;
+    list.key_words = 1;
+    list.keys = Scratch(ctx, (list_cap + 1) * 8);
+    list.state = Scratch(ctx, (list_cap + 1) * 8);
+    list.overflow = Scratch(ctx, 256);
+    PRISM_HIP(hipMemsetAsync(list.overflow.p, 0, 4, ctx->stream));
+    PRISM_HIP(hipMemsetAsync(d_small.p, 0, 64, ctx->stream));
+    PRISM_HIP(hipMemsetAsync(cm.p, 0, n_cm * 4, ctx->stream));
+    PRISM_HIP(hipMemsetAsync(w.hot_count, 0, (size_t)wc_hot_slots() * 8, ctx->stream));
+    w.list_keys = list.keys.as<uint64_t>();
+    w.list_state = list.state.as<int64_t>();
+    w.list_capacity = list_cap;
+    {
+      KernelTimer timer(ctx, "group_by", selected * key_bytes);
+      launch_wc_group_by(ctx, ap, w, key_bytes);
+    }
+    struct { unsigned long long cursor; uint32_t n_cand, pad; uint32_t flags[4]; } h{};
+    HostTimer ht_wait(ctx, "host:part_wait");
+    PRISM_HIP(hipMemcpyAsync(&h, d_small.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    PRISM_HIP(hipStreamSynchronize(ctx->stream));
+    if (h.flags[1] || h.flags[2]) {
+      plan->wc_mode.store(-1, std::memory_order_relaxed);
+      return false;
+    }
+    const uint64_t groups = h.cursor;
+    if (groups > list_cap || h.flags[0]) {
+      // the list was too short (the count is exact now): once more
+      list_cap = groups + 1024;
+      continue;
+    }
+    const uint64_t tail = list_cap + 1 - groups;  // the entries past the groups, and the extra entry
+    PRISM_HIP(hipMemsetAsync(list.keys.as<uint64_t>() + groups, 0xff, tail * 8, ctx->stream));
+    PRISM_HIP(hipMemsetAsync(list.state.as<int64_t>() + groups, 0, tail * 8, ctx->stream));
+    gt = std::move(list);
+    *groups_out = groups;
+    plan->part_groups.store(std::max<uint64_t>(1, groups), std::memory_order_relaxed);
+    return true;
+  }
+}
+
 // GROUP BY of the scan described by `ap` (keys, values, slots, row mode; no in-kernel
 // predicate) through partitioning.  `gt` becomes a list of the groups; returns their number.
 uint64_t partitioned_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, AggParams ap, uint64_t selected, uint64_t scan_rows,
@@ -1116,6 +1198,12 @@ uint64_t partitioned_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, AggParam
                               GroupTable& gt) {
   const int words = part_record_words(ap, vals_nullable);
   if (words <= 0) fail(PRISM_GPU_EINTERNAL, "plan shape cannot be partitioned");
+  // one-word keys and COUNT(*) alone: the path without a histogram, unless it overflowed before
+  if (ctx->part_wc.load(std::memory_order_relaxed) != 0 && plan->wc_mode.load(std::memory_order_relaxed) >= 0 && wc_plan_fits(ap) &&
+      selected >= ctx->part_wc_min_rows.load(std::memory_order_relaxed) && selected < (1ull << 32) - wc_hot_slots()) {
+    uint64_t n = 0;
+    if (wc_group_by(ctx, plan, ap, selected, key_bytes, slot_ops, gt, &n)) return n;
+  }
   const uint32_t p_max = part_max_buckets(words);
   const uint32_t lds_entries = part_lds_entries(ap);
   const uint32_t lds_limit = lds_entries / 4 * 3;

@@ -273,6 +273,39 @@ uint32_t part_scan_workgroups(prism_gpu_ctx* ctx, const AggParams& p, uint32_t* 
 void launch_partitioned_group_by(prism_gpu_ctx* ctx, const AggParams& p, const PartParams& q, bool vals_nullable,
                                  uint64_t hist_bytes, uint64_t scatter_bytes, uint64_t agg_bytes, bool scatter_only = false);
 
+// ---- GROUP BY <one-word key> -> COUNT(*) without a histogram pass (kernels_wc.hip) ----------
+// Hot keys (found in a sample) are counted in LDS by the scatter pass itself; the other rows go
+// through per-bucket staging lines in LDS into fixed segments of the record array, one per
+// (workgroup, bucket); a workgroup per bucket then counts the keys in LDS and appends the
+// groups to the list.  flags[1] / flags[2] set: a segment or an LDS table overflowed, the
+// result is void and the caller takes the path with the histogram.
+struct WcParams {
+  uint32_t n_wg, tiles_per_wg;  // workgroups of the scatter pass and the scan tiles each takes
+  uint32_t cap_shift;           // a segment holds 2^cap_shift records
+  uint64_t* rec;                // [buckets][n_wg][2^cap_shift]
+  uint32_t* seg_count;          // [buckets][n_wg]
+  uint32_t* cm;                 // [wc_sample_counters()] counters of the sample, zero on entry
+  uint64_t* cand;               // [wc_max_candidates()]
+  uint32_t* n_cand;             // zero on entry
+  uint64_t* hot_keys;           // [wc_hot_slots()] the hot table (all ones: free entry)
+  unsigned long long* hot_count;  // [wc_hot_slots()] rows per hot key, zero on entry
+  uint32_t sample_tiles;        // scan tiles the sample takes
+  uint32_t hot_threshold;       // sample count from which a key is a candidate
+  uint32_t lds_entries;         // entries of the aggregation pass' LDS table (even)
+  uint64_t* list_keys;          // the list, laid out as PartParams' (one slot: the count)
+  int64_t* list_state;
+  uint64_t list_capacity;
+  unsigned long long* list_cursor;  // zero on entry
+  uint32_t* flags;              // [0] the list overflowed, [1] a segment overflowed, [2] an LDS table overflowed; zero on entry
+};
+bool wc_plan_fits(const AggParams& p);
+uint32_t wc_lds_entries(uint32_t n_wg);
+uint32_t wc_buckets();
+uint32_t wc_hot_slots();
+uint32_t wc_max_candidates();
+uint64_t wc_sample_counters();
+void launch_wc_group_by(prism_gpu_ctx* ctx, const AggParams& p, const WcParams& w, uint64_t key_bytes);
+
 // COUNT(DISTINCT x) GROUP BY k over two-word (x, k) pairs whose set is far too large for one
 // level of buckets: the records, already sorted into coarse buckets by a hash of k, are
 // sorted once more, inside every coarse bucket, by a hash of the whole pair; each fine bucket

@@ -1,0 +1,424 @@
+// GROUP BY <one-word key> -> COUNT(*) for group sets far beyond LDS, in two passes over the
+// rows and without a histogram: the shape prism-ql's `count by <column>` lowers to
+// (src/prism-ql/src/lower.rs:83-95) and ClickBench's GROUP BY "UserID".
+//
+// The general partitioned path (kernels_part.hip) reads the key column twice -- a histogram
+// to place every bucket's rows exactly, then the scatter -- and sorts each tile of rows by
+// bucket in LDS with four barriers per tile, its sixteen waves in step.  Here:
+//
+//   k_wc_sample    a sample of the scan (64 tiles) is counted into a table of 2^20 counters;
+//                  a key whose counter reaches the threshold becomes a candidate
+//   k_wc_build     the candidates, most frequent first, fill a small table of HOT keys
+//   k_wc_scatter   one pass over the rows.  A row whose key is hot is counted in LDS and goes
+//                  nowhere (with skewed keys -- a few ids in a large share of the rows -- that
+//                  is a third to a half of all rows, and it takes the heavy hitters out of the
+//                  buckets).  Every other row is appended to its bucket's staging line in LDS
+//                  (2048 buckets x 8 records); the lane that fills a line copies it out as 64
+//                  contiguous bytes.  No tile, no sort, no barrier: a wave takes a ticket per
+//                  row from the bucket's counter and waits only for that bucket's line.
+//                  Every (workgroup, bucket) pair owns a fixed segment of the record array,
+//                  sized from the expected rows with room to spare, so no offsets need
+//                  computing beforehand; a segment that overflows (rows of one cold key
+//                  clustered in one workgroup's share) voids the run and the caller falls back
+//                  to the histogram path.
+//   k_wc_agg       a workgroup per bucket: the bucket's segments are read (16 lanes a segment),
+//                  the keys counted in an LDS table of two-entry buckets with 32-bit counters
+//                  (12 bytes a group: 13 000 groups per bucket, 2.7e7 per query), the groups
+//                  appended to the result list
+//   k_wc_hot_emit  the hot keys' totals join the list
+//
+// Traffic per row: the key read once, the record written once and read once (24 bytes for an
+// 8-byte key, less the hot rows' share of the last two).
+#include <algorithm>
+
+#include "part_device.hpp"
+
+namespace prism {
+
+namespace {
+
+constexpr uint32_t kWcBlock = 1024;
+constexpr uint32_t kWcBucketBits = 11, kWcBuckets = 1u << kWcBucketBits;
+constexpr uint32_t kWcStage = 8;          // records of a staging line (64 bytes)
+constexpr uint32_t kWcHotSlots = 1024;    // hot table: 512 buckets of two entries
+constexpr uint32_t kWcCmBits = 20;        // counters of the sample
+constexpr uint32_t kWcMaxCand = 4096;
+constexpr unsigned long long kWcEmpty = ~0ull;
+constexpr int kWcMaxProbes = 128;
+constexpr size_t kWcLdsBytes = 160 * 1024 - 1024;
+
+typedef const __attribute__((address_space(1))) unsigned long long* WcWordPtr;
+
+__device__ __forceinline__ uint32_t wc_bucket(uint64_t key) { return bucket_hash32(key) >> (32 - kWcBucketBits); }
+__device__ __forceinline__ uint32_t wc_hot_bucket(uint64_t key) {
+  const uint32_t x = ((uint32_t)key * 0xC2B2AE35u) ^ ((uint32_t)(key >> 32) * 0x27D4EB2Fu);
+  return (x ^ (x >> 15)) * 0x9E3779B1u >> (32 - 9);  // kWcHotSlots / 2 = 2^9 buckets
+}
+__device__ __forceinline__ uint32_t wc_cm_index(uint64_t key) {
+  const uint32_t x = ((uint32_t)key ^ (uint32_t)(key >> 32)) * 0x9E3779B1u;
+  return ((x ^ (x >> 16)) * 0x85EBCA6Bu) >> (32 - kWcCmBits);
+}
+
+// ---- the hot keys -----------------------------------------------------------------------
+
+__global__ __launch_bounds__(kWcBlock) void k_wc_sample(AggParams p, WcParams w) {
+  const uint32_t tid = threadIdx.x;
+  const uint64_t tile = (uint64_t)blockIdx.x * p.sd.n_tiles / gridDim.x;
+  PartSegPos pos;
+  part_seg_init(p, pos, tile);
+  PartTile tl[1];
+  tl[0] = part_tile_next(p, pos, tile, p.sd.n_tiles);
+  uint64_t lo[4], hi[4];
+  uint32_t rowc[4], live;
+  part_load_keys<1, 4>(p, tl, tid, lo, hi, rowc, live);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (!((live >> r) & 1u)) continue;
+    const uint32_t c = atomicAdd(&w.cm[wc_cm_index(lo[r])], 1u) + 1u;
+    if (c == w.hot_threshold) {
+      const uint32_t i = atomicAdd(w.n_cand, 1u);
+      if (i < kWcMaxCand) w.cand[i] = lo[r];
+    }
+  }
+}
+
+// One workgroup: the candidates whose counters ended highest take their home bucket of the
+// hot table first.  A key that finds its bucket full is simply not hot.
+__global__ __launch_bounds__(kWcBlock) void k_wc_build(WcParams w) {
+  __shared__ unsigned long long t[kWcHotSlots];
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t i = tid; i < kWcHotSlots; i += kWcBlock) t[i] = kWcEmpty;
+  const uint32_t n = *w.n_cand < kWcMaxCand ? *w.n_cand : kWcMaxCand;
+  __syncthreads();
+  uint32_t upper = ~0u;
+  for (int pass = 0; pass < 4; ++pass) {
+    const uint32_t lower = w.hot_threshold << (2 * (3 - pass));  // 64, 16, 4, 1 times the threshold
+    for (uint32_t i = tid; i < n; i += kWcBlock) {
+      const unsigned long long key = w.cand[i];
+      const uint32_t c = w.cm[wc_cm_index(key)];
+      if (c < lower || c >= upper || key == kWcEmpty) continue;
+      const uint32_t b = wc_hot_bucket(key);
+      for (uint32_t e = 2 * b; e < 2 * b + 2; ++e) {
+        const unsigned long long old = atomicCAS(&t[e], kWcEmpty, key);
+        if (old == kWcEmpty || old == key) break;
+      }
+    }
+    upper = lower;
+    __syncthreads();
+  }
+  for (uint32_t i = tid; i < kWcHotSlots; i += kWcBlock) w.hot_keys[i] = t[i];
+}
+
+// ---- the scatter pass ---------------------------------------------------------------------
+//
+// Per bucket: `fill` hands out tickets (ticket t: place t % 8 of generation t / 8 of the
+// bucket's staging line), `prog` holds the records of the current generation already in
+// place (low half) and the generations copied out so far (high half, modulo 2^16).  The
+// holder of a ticket writes its record once its generation is the current one; the holder
+// of a generation's last ticket waits for all eight records, copies the line out and opens
+// the next generation.  All waiting is done in one loop that tries every pending step of
+// every lane in turn, so a lane never spins in front of a step that another lane of its own
+// wave has to take first.
+
+__device__ __forceinline__ uint32_t wc_prog_load(uint32_t* prog) {
+  return __hip_atomic_load(prog, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int NK>
+__global__ __launch_bounds__(kWcBlock) __attribute__((amdgpu_waves_per_eu(4))) void k_wc_scatter(AggParams p, WcParams w) {
+  constexpr bool AHEAD = NK > 0;
+  constexpr int NA = AHEAD ? NK : 1;
+  constexpr int R = 4;  // rows of a scan tile per thread: a workgroup takes one tile per step
+  extern __shared__ __align__(16) unsigned long long wc_lds[];
+  unsigned long long* stage = wc_lds;                                        // [kWcBuckets][kWcStage]
+  uint32_t* fill = (uint32_t*)(stage + (size_t)kWcBuckets * kWcStage);       // [kWcBuckets]
+  uint32_t* prog = fill + kWcBuckets;                                        // [kWcBuckets]
+  unsigned long long* hot_keys = (unsigned long long*)(prog + kWcBuckets);   // [kWcHotSlots]
+  uint32_t* hot_cnt = (uint32_t*)(hot_keys + kWcHotSlots);                   // [kWcHotSlots]
+  const uint32_t tid = threadIdx.x, wg = blockIdx.x;
+  for (uint32_t i = tid; i < kWcBuckets; i += kWcBlock) { fill[i] = 0; prog[i] = 0; }
+  for (uint32_t i = tid; i < kWcHotSlots; i += kWcBlock) { hot_keys[i] = w.hot_keys[i]; hot_cnt[i] = 0; }
+  __syncthreads();
+  const uint64_t t0 = (uint64_t)wg * w.tiles_per_wg;
+  const uint64_t t1 = t0 + w.tiles_per_wg < p.sd.n_tiles ? t0 + w.tiles_per_wg : p.sd.n_tiles;
+  const uint32_t cap = 1u << w.cap_shift;
+  unsigned long long raw[NA][R];
+  uint32_t live = 0, live_next = 0;
+  PartCursor<NA> cur;
+  PartSegPos pos;
+  if constexpr (AHEAD) {
+    if (t0 < t1) {
+      part_cursor_init<NA, 0>(p, cur, t0);
+      part_issue<NA, 0, R>(p, cur, t0, t1, tid, raw, live_next);
+    }
+  } else {
+    if (t0 < t1) part_seg_init(p, pos, t0);
+  }
+  for (uint64_t t = t0; t < t1; ++t) {
+    uint64_t key[R];
+    if constexpr (AHEAD) {
+      uint64_t rec[1][R];
+      part_finish<1, NA, 0, R>(p, raw, rec);
+#pragma unroll
+      for (int r = 0; r < R; ++r) key[r] = rec[0][r];
+      live = live_next;
+      if (t + 1 < t1) part_issue<NA, 0, R>(p, cur, t + 1, t1, tid, raw, live_next);
+    } else {
+      PartTile tl[1];
+      uint64_t hi_unused[R];
+      uint32_t rowc[R];
+      tl[0] = part_tile_next(p, pos, t, t1);
+      part_load_keys<1, R>(p, tl, tid, key, hi_unused, rowc, live);
+    }
+    // hot keys are counted where they are; the other rows take a ticket of their bucket
+    uint32_t bkt[R], tk[R], needw = 0, needf = 0;
+    ulonglong2 hc[R];
+    uint32_t hb[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      hb[r] = wc_hot_bucket(key[r]);
+      hc[r] = *(const ulonglong2*)&hot_keys[2 * hb[r]];
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      bkt[r] = wc_bucket(key[r]);
+      tk[r] = 0;
+      if (!((live >> r) & 1u)) continue;
+      if (hc[r].x == key[r] || hc[r].y == key[r]) {
+        atomicAdd(&hot_cnt[2 * hb[r] + (hc[r].x == key[r] ? 0u : 1u)], 1u);
+      } else {
+        tk[r] = atomicAdd(&fill[bkt[r]], 1u);
+        needw |= 1u << r;
+      }
+    }
+    for (;;) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t gen = tk[r] / kWcStage, place = tk[r] % kWcStage;
+        if ((needw >> r) & 1u) {
+          const uint32_t pr = wc_prog_load(&prog[bkt[r]]);
+          if ((pr >> 16) == (gen & 0xffffu)) {
+            __hip_atomic_store(&stage[(size_t)bkt[r] * kWcStage + place], (unsigned long long)key[r], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&prog[bkt[r]], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            needw &= ~(1u << r);
+            if (place == kWcStage - 1) needf |= 1u << r;
+          }
+        }
+        if ((needf >> r) & 1u) {
+          const uint32_t pr = wc_prog_load(&prog[bkt[r]]);
+          if ((pr & 0xffffu) == kWcStage) {
+            // the line is complete: out it goes, 64 contiguous bytes of the segment
+            const ulonglong2* s = (const ulonglong2*)&stage[(size_t)bkt[r] * kWcStage];
+            const ulonglong2 a = s[0], b = s[1], c = s[2], d = s[3];
+            const uint64_t off = (uint64_t)gen * kWcStage;
+            if (off + kWcStage <= cap) {
+              ulonglong2* dst = (ulonglong2*)(w.rec + ((((uint64_t)bkt[r] * w.n_wg + wg) << w.cap_shift) + off));
+              dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = d;
+            } else {
+              w.flags[1] = 1u;
+            }
+            // the records are in registers: the next generation may come (-8 records, +1 generation)
+            __hip_atomic_fetch_add(&prog[bkt[r]], 0x10000u - kWcStage, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            needf &= ~(1u << r);
+          }
+        }
+      }
+      if (__ballot((needw | needf) != 0u) == 0ull) break;
+    }
+  }
+  __syncthreads();
+  // what is left in the staging lines, and how many records every segment got
+  for (uint32_t b = tid; b < kWcBuckets; b += kWcBlock) {
+    const uint32_t n = fill[b], rem = n % kWcStage;
+    const uint64_t off = (uint64_t)(n / kWcStage) * kWcStage;
+    const bool fits = n <= cap;
+    if (!fits) w.flags[1] = 1u;
+    if (fits && rem) {
+      unsigned long long* dst = (unsigned long long*)w.rec + ((((uint64_t)b * w.n_wg + wg) << w.cap_shift) + off);
+      for (uint32_t j = 0; j < rem; ++j) dst[j] = stage[(size_t)b * kWcStage + j];
+    }
+    w.seg_count[(uint64_t)b * w.n_wg + wg] = fits ? n : cap;
+  }
+  for (uint32_t i = tid; i < kWcHotSlots; i += kWcBlock)
+    if (hot_cnt[i]) atomicAdd(&w.hot_count[i], (unsigned long long)hot_cnt[i]);
+}
+
+// ---- the aggregation pass -------------------------------------------------------------------
+
+// Entry of the key in the table of two-entry buckets (two home buckets, then the buckets
+// after the second), inserted when absent; -1: no room on its path.
+__device__ __forceinline__ int wc_entry(unsigned long long* keys, uint32_t nb, uint64_t key, bool& inserted) {
+  const uint32_t m1 = ((uint32_t)key ^ (uint32_t)(key >> 32)) * 0x9E3779B1u;
+  const uint32_t m2 = (m1 ^ (m1 >> 15)) * 0x85EBCA6Bu;
+  uint32_t b = __umulhi(m1, nb);
+  int step = 0;
+  while (step < kWcMaxProbes) {
+    asm volatile("" ::: "memory");  // the bucket is read afresh in every step
+    const ulonglong2 c = *(const ulonglong2*)&keys[2 * (size_t)b];
+    if (c.x == key) return (int)(2 * b);
+    if (c.y == key) return (int)(2 * b + 1);
+    if (c.x == kWcEmpty || c.y == kWcEmpty) {
+      const uint32_t e = 2 * b + (c.x == kWcEmpty ? 0u : 1u);
+      const unsigned long long old = atomicCAS(&keys[e], kWcEmpty, (unsigned long long)key);
+      if (old == kWcEmpty) { inserted = true; return (int)e; }
+      if (old == key) return (int)e;
+      continue;  // somebody else took the entry: look at the bucket again
+    }
+    b = step == 0 ? __umulhi(m2, nb) : (b + 1 == nb ? 0u : b + 1);
+    ++step;
+  }
+  return -1;
+}
+
+__global__ __launch_bounds__(kWcBlock) void k_wc_agg(AggParams p, WcParams w) {
+  extern __shared__ __align__(16) unsigned long long wc_lds[];
+  __shared__ uint32_t n_entries, wg_pos;
+  __shared__ unsigned long long out_base;
+  const uint32_t E = w.lds_entries, nb = E / 2, tid = threadIdx.x, lane = tid & 63u;
+  unsigned long long* keys = wc_lds;              // [E]
+  uint32_t* cnt = (uint32_t*)(keys + E);          // [E]
+  uint32_t* segcnt = cnt + E;                     // [n_wg]
+  const uint32_t sub = tid & 15u, seg_lane = tid >> 4;  // 16 lanes a segment, 64 segments a round
+  constexpr int U = 8;
+  for (uint32_t b = blockIdx.x; b < kWcBuckets; b += gridDim.x) {
+    for (uint32_t i = tid; i < E; i += kWcBlock) { keys[i] = kWcEmpty; cnt[i] = 0; }
+    for (uint32_t i = tid; i < w.n_wg; i += kWcBlock) segcnt[i] = w.seg_count[(uint64_t)b * w.n_wg + i];
+    if (tid == 0) { n_entries = 0; wg_pos = 0; }
+    __syncthreads();
+    const unsigned long long* region = (const unsigned long long*)w.rec + (((uint64_t)b * w.n_wg) << w.cap_shift);
+    bool lost = false;
+    for (uint32_t seg0 = 0; seg0 < w.n_wg; seg0 += kWcBlock / 16) {
+      const uint32_t seg = seg0 + seg_lane;
+      const uint32_t c = seg < w.n_wg ? segcnt[seg] : 0u;
+      const unsigned long long* s = region + ((uint64_t)(seg < w.n_wg ? seg : 0u) << w.cap_shift);
+      for (uint32_t i0 = 0; __ballot(i0 < c) != 0ull; i0 += 16 * U) {
+        uint64_t key[U];
+        bool in[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t j = i0 + (uint32_t)u * 16u + sub;
+          in[u] = j < c;
+          key[u] = __builtin_nontemporal_load((WcWordPtr)(uint64_t)(s + (in[u] ? j : 0u)));
+        }
+        // the first home bucket of all the step's rows is read before any is looked at
+        ulonglong2 c1[U];
+        uint32_t h1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          h1[u] = __umulhi(((uint32_t)key[u] ^ (uint32_t)(key[u] >> 32)) * 0x9E3779B1u, nb);
+          c1[u] = *(const ulonglong2*)&keys[2 * (size_t)h1[u]];
+        }
+        uint32_t n_new = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          int e = c1[u].x == key[u] ? (int)(2 * h1[u]) : (c1[u].y == key[u] ? (int)(2 * h1[u] + 1) : -1);
+          bool ins = false;
+          if (in[u] && e < 0) {
+            e = wc_entry(keys, nb, key[u], ins);
+            if (e < 0) lost = true;
+          }
+          const uint64_t m_ins = __ballot(ins);
+          n_new += (uint32_t)__popcll(m_ins);
+          if (in[u] && e >= 0) atomicAdd(&cnt[e], 1u);
+        }
+        if (n_new && lane == 0) atomicAdd(&n_entries, n_new);
+      }
+    }
+    if (lost) w.flags[2] = 1u;
+    __syncthreads();
+    const uint32_t n = n_entries;
+    if (tid == 0) out_base = atomicAdd(w.list_cursor, (unsigned long long)n);
+    __syncthreads();
+    const uint64_t first = out_base;
+    const bool fits = first + n <= w.list_capacity;
+    if (!fits && tid == 0) w.flags[0] = 1u;
+    for (uint32_t i0 = 0; i0 < E && fits; i0 += kWcBlock) {
+      const uint32_t i = i0 + tid;
+      const unsigned long long k = i < E ? keys[i] : kWcEmpty;
+      const bool occ = k != kWcEmpty;
+      const uint64_t m = __ballot(occ);
+      uint32_t wave_first = 0;
+      if (lane == 0 && m) wave_first = atomicAdd(&wg_pos, (uint32_t)__popcll(m));
+      wave_first = __shfl(wave_first, 0);
+      if (!occ) continue;
+      const uint64_t at = first + wave_first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      w.list_keys[at] = k;
+      w.list_state[at] = (long long)cnt[i];
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(kWcBlock) void k_wc_hot_emit(WcParams w) {
+  const uint32_t i = threadIdx.x, lane = i & 63u;
+  const unsigned long long k = i < kWcHotSlots ? w.hot_keys[i] : kWcEmpty;
+  const unsigned long long c = i < kWcHotSlots ? w.hot_count[i] : 0ull;
+  const bool occ = k != kWcEmpty && c != 0ull;
+  const uint64_t m = __ballot(occ);
+  unsigned long long wave_first = 0;
+  if (lane == 0 && m) wave_first = atomicAdd(w.list_cursor, (unsigned long long)__popcll(m));
+  wave_first = __shfl(wave_first, 0);
+  if (!occ) return;
+  const uint64_t at = wave_first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+  if (at < w.list_capacity) {
+    w.list_keys[at] = k;
+    w.list_state[at] = (long long)c;
+  } else {
+    w.flags[0] = 1u;
+  }
+}
+
+void wc_allow_lds(const void* k, size_t bytes) {
+  PRISM_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+}
+
+}  // namespace
+
+bool wc_plan_fits(const AggParams& p) {
+  if (p.key_words != 1 || p.keys_only || p.key_bits > 63 || p.n_keys < 1) return false;
+  if (p.n_slots != 1 || p.slots[0].op != kSlotAddOne) return false;
+  return p.row_mode == kRowsAll || p.row_mode == kRowsBitmap;
+}
+
+uint32_t wc_lds_entries(uint32_t n_wg) { return (uint32_t)((kWcLdsBytes - (size_t)n_wg * 4 - 256) / 12) & ~1u; }
+uint32_t wc_buckets() { return kWcBuckets; }
+uint32_t wc_hot_slots() { return kWcHotSlots; }
+uint32_t wc_max_candidates() { return kWcMaxCand; }
+uint64_t wc_sample_counters() { return 1ull << kWcCmBits; }
+
+void launch_wc_group_by(prism_gpu_ctx* ctx, const AggParams& p, const WcParams& w, uint64_t key_bytes) {
+  if (!wc_plan_fits(p)) fail(PRISM_GPU_EINTERNAL, "plan shape does not fit the histogram-free GROUP BY");
+  if (w.n_wg == 0 || (uint64_t)w.n_wg * w.tiles_per_wg < p.sd.n_tiles || w.cap_shift < 3 || w.cap_shift > 28 ||
+      w.lds_entries > wc_lds_entries(w.n_wg) || w.lds_entries < 64 || w.sample_tiles == 0 || w.sample_tiles > p.sd.n_tiles)
+    fail(PRISM_GPU_EINTERNAL, "bad work split for the histogram-free GROUP BY");
+  const uint64_t rows = p.sd.n_tiles * kTileRows;
+  {
+    KernelTimer timer(ctx, "wc_sample", (uint64_t)w.sample_tiles * kTileRows * key_bytes);
+    k_wc_sample<<<dim3(w.sample_tiles), dim3(kWcBlock), 0, ctx->stream>>>(p, w);
+    PRISM_HIP(hipGetLastError());
+    k_wc_build<<<dim3(1), dim3(kWcBlock), 0, ctx->stream>>>(w);
+    PRISM_HIP(hipGetLastError());
+  }
+  {
+    KernelTimer timer(ctx, "wc_scatter", rows * (key_bytes + 8));
+    const size_t lds = (size_t)kWcBuckets * kWcStage * 8 + (size_t)kWcBuckets * 8 + (size_t)kWcHotSlots * 12;
+    const int ahead = part_keys_ahead(p);
+    auto kernel = ahead == 1 ? k_wc_scatter<1> : ahead == 2 ? k_wc_scatter<2> : k_wc_scatter<0>;
+    wc_allow_lds((const void*)kernel, lds);
+    kernel<<<dim3(w.n_wg), dim3(kWcBlock), lds, ctx->stream>>>(p, w);
+    PRISM_HIP(hipGetLastError());
+  }
+  {
+    KernelTimer timer(ctx, "wc_agg", rows * 8);
+    const size_t lds = (size_t)w.lds_entries * 12 + (size_t)w.n_wg * 4;
+    wc_allow_lds((const void*)k_wc_agg, lds);
+    const uint32_t grid = std::min<uint32_t>(kWcBuckets, (uint32_t)ctx->n_cus);
+    k_wc_agg<<<dim3(grid), dim3(kWcBlock), lds, ctx->stream>>>(p, w);
+    PRISM_HIP(hipGetLastError());
+    k_wc_hot_emit<<<dim3(1), dim3(kWcBlock), 0, ctx->stream>>>(w);
+    PRISM_HIP(hipGetLastError());
+  }
+}
+
+}  // namespace prism

@@ -357,10 +357,11 @@ def test_streaming_kernel_hands_over_when_rows_scatter(oracle):
                 ctx.reset_stats()
                 first = plan.execute(table)
                 ran = _kernels(ctx)
-                assert "part_agg" in ran, "the streaming kernel did not hand the plan over"
+                # (COUNT(*) alone over this many rows: partitioned without a histogram pass)
+                assert "wc_agg" in ran, "the streaming kernel did not hand the plan over"
                 ctx.reset_stats()
                 second = plan.execute(table)
-                assert "part_agg" in _kernels(ctx)
+                assert "wc_agg" in _kernels(ctx) and "part_hist" not in _kernels(ctx)
             finally:
                 plan.close()
             same(first, want)
@@ -369,3 +370,126 @@ def test_streaming_kernel_hands_over_when_rows_scatter(oracle):
         st.close()
         table.close()
         ctx.close()
+
+
+# ---- GROUP BY key -> COUNT(*) without a histogram pass (kernels_wc.hip) ----------------------
+
+@pytest.fixture(scope="module")
+def wc_ctx():
+    from prism_amd.engine import Context
+
+    ctx = Context(0)
+    ctx.set_option("part_min_rows", 0)
+    ctx.set_option("part_force", 1)
+    ctx.set_option("part_wc_min_rows", 0)
+    yield ctx
+    ctx.close()
+
+
+def _same_groups(got, want, names):
+    import pyarrow.compute as pc
+
+    assert got.num_rows == want.num_rows
+    order = [(n, "ascending") for n in names]
+    assert got.take(pc.sort_indices(got, order)).equals(want.take(pc.sort_indices(want, order)))
+
+
+def test_histogram_free_count_by_key_small_tables(wc_ctx, oracle):
+    """Every shape the path takes, on tables of a few tiles: a nullable key (keys loaded with
+    their validity bits), two key columns in one word, a WHERE (selection bitmap), ORDER BY ..
+    LIMIT over the list, a one-word COUNT(DISTINCT) whose pairs are counted the same way."""
+    from prism_amd.engine import Plan, Table
+
+    for n, nulls, parts in [(1000, True, 1), (50_000, True, 3), (20_000, False, 2)]:
+        t = helpers.random_table(n, seed=n + 5, nulls=nulls)
+        g = Table(wc_ctx, t.schema)
+        g.append_table(t, parts)
+        try:
+            for q, n_keys in [(QueryPlan([count_star()], keys=["user"]), 1),
+                              (QueryPlan([count_star()], keys=["i16", "i32"]), 2),
+                              (QueryPlan([count_star()], keys=["user"], predicate=col("i32") > 0), 1),
+                              (QueryPlan([count_star()], keys=["user"], order_by=1, descending=True, limit=7), 1),
+                              (QueryPlan([count_star()], keys=[date_bin(60_000, "ts"), "service"]), 2),
+                              (QueryPlan([count_distinct("i16")], keys=["service"]), 1)]:
+                wc_ctx.reset_stats()
+                plan = Plan(wc_ctx, t.schema, q)
+                try:
+                    got = plan.execute(g)
+                    again = plan.execute(g)
+                finally:
+                    plan.close()
+                assert "wc_scatter" in _kernels(wc_ctx) and "part_hist" not in _kernels(wc_ctx), q
+                want = oracle.execute(t, q)
+                for r in (got, again):
+                    if q.limit is not None:
+                        assert_topk_match(r, want, q.order_by)
+                    else:
+                        assert_tables_match(r, want, n_keys)
+        finally:
+            g.close()
+
+
+def test_histogram_free_path_hot_keys_and_many_groups(wc_ctx, oracle):
+    """Log-uniform ids: the frequent ids are found in the sample and counted in LDS (they would
+    overflow any segment: one id alone holds 1/20 of the rows), the rest goes through the
+    staging lines; 2e6 groups in 6e6 rows."""
+    wl = workloads.c3(id_bits=20)
+    rows, parts = 6_000_000, 6
+    table = workloads.build_gpu_table(wc_ctx, wl, 0, rows, rows, parts)
+    st = oracle.SynthTable(wl.schema, wl.make_cols(), wl.seed, 0, rows, rows, n_parts=parts, threads=8)
+    try:
+        from prism_amd.engine import Plan
+
+        for q in [QueryPlan([count_star()], keys=["UserID"]), wl.query,
+                  QueryPlan([count_star()], keys=["UserID"], predicate=col("UserID") > (1 << 61))]:
+            want, _ = st.execute(q, threads=8)
+            wc_ctx.reset_stats()
+            plan = Plan(wc_ctx, wl.schema, q)
+            try:
+                runs = [plan.execute(table), plan.execute(table)]
+            finally:
+                plan.close()
+            ran = _kernels(wc_ctx)
+            assert "wc_agg" in ran and "part_hist" not in ran and "part_agg" not in ran
+            for got in runs:
+                if q.limit is not None:
+                    assert_topk_match(got, want, q.order_by)
+                else:
+                    _same_groups(got, want, ["UserID"])
+    finally:
+        st.close()
+        table.close()
+
+
+def test_histogram_free_path_falls_back_when_a_segment_overflows(wc_ctx, oracle):
+    """Rows sorted by key: every key's rows lie in one workgroup's share, so with few keys
+    per bucket some (workgroup, bucket) segment takes far more rows than it holds.  The run
+    is given up, the histogram path produces the result, and the plan remembers."""
+    import numpy as np
+    import pyarrow as pa
+    from prism_amd.engine import Plan, Table
+
+    n = 3_000_000
+    # 500 rows a key, sorted: six times more keys than the hot table takes, each a few segments' worth
+    keys = np.repeat(np.arange(6000, dtype=np.int64) * 7_777_777_777 + 13, n // 6000)
+    t = pa.table({"k": pa.array(keys)})
+    g = Table(wc_ctx, t.schema)
+    g.append_table(t, 3)
+    try:
+        q = QueryPlan([count_star()], keys=["k"])
+        plan = Plan(wc_ctx, t.schema, q)
+        try:
+            wc_ctx.reset_stats()
+            got = plan.execute(g)
+            ran = _kernels(wc_ctx)
+            assert "wc_scatter" in ran and "part_agg" in ran  # tried, given up, done the other way
+            wc_ctx.reset_stats()
+            again = plan.execute(g)
+            assert "wc_scatter" not in _kernels(wc_ctx)
+        finally:
+            plan.close()
+        want = oracle.execute(t, q)
+        assert_tables_match(got, want, 1)
+        assert_tables_match(again, want, 1)
+    finally:
+        g.close()
