@@ -261,6 +261,9 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3", "C4", "C4G", "C5"])
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the workload's)")
+    ap.add_argument("--id-bits", type=int, default=0,
+                    help="C3: ranks of the id generator are drawn from [1, 2^id_bits) (default 24: 6e6 groups in 1e8 rows; "
+                         "26: 1.76e7 groups, ClickBench's UserID cardinality)")
     ap.add_argument("--partitions", type=int, default=0, help="partitions per GPU")
     ap.add_argument("--cpu-sample-partitions", type=int, default=8,
                     help="leading partitions of rank 0 the CPU baseline and the parity check run on")
@@ -322,6 +325,10 @@ def main() -> int:
     from prism_amd.engine import Comm, Context, Plan, PrismGpuError
 
     wl = workloads.WORKLOADS[args.workload]()
+    if args.workload == "C3" and args.id_bits:
+        import dataclasses
+
+        wl = dataclasses.replace(workloads.c3(id_bits=args.id_bits), name="C3_17M" if args.id_bits == 26 else "C3")
     rows = args.rows or wl.default_rows
     parts = args.partitions or wl.default_partitions
     total_rows = rows * world

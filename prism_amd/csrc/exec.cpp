@@ -1130,13 +1130,15 @@ bool wc_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggParams& ap, 
   w.sample_tiles = (uint32_t)std::min<uint64_t>(64, ap.sd.n_tiles);
   // a candidate: a key seen this often in the sample (1/32768 of it, at least 4 times)
   w.hot_threshold = (uint32_t)std::max<uint64_t>(4, ((uint64_t)w.sample_tiles * kTileRows) >> 15);
+  if (const char* dbg = std::getenv("PRISM_WC_DEBUG_MODE")) w.debug = (uint32_t)std::atoi(dbg);
   const uint64_t n_cm = wc_sample_counters();
   Scratch rec(ctx, ((uint64_t)P * w.n_wg << w.cap_shift) * 8 + 256), seg_count(ctx, (uint64_t)P * w.n_wg * 4),
-      cm(ctx, n_cm * 4), cand(ctx, (uint64_t)wc_max_candidates() * 8), hot(ctx, (uint64_t)wc_hot_slots() * 16), d_small(ctx, 256);
+      cm(ctx, n_cm * 12), cand(ctx, (uint64_t)wc_max_candidates() * 4), hot(ctx, (uint64_t)wc_hot_slots() * 16), d_small(ctx, 256);
   w.rec = rec.as<uint64_t>();
   w.seg_count = seg_count.as<uint32_t>();
-  w.cm = cm.as<uint32_t>();
-  w.cand = cand.as<uint64_t>();
+  w.s_keys = cm.as<uint64_t>();
+  w.s_cnt = (uint32_t*)(cm.as<uint64_t>() + n_cm);
+  w.cand = cand.as<uint32_t>();
   w.hot_keys = hot.as<uint64_t>();
   w.hot_count = (unsigned long long*)(hot.as<uint64_t>() + wc_hot_slots());
   // one small block: [0] the list cursor (8 bytes), [8] the candidates, [16] three flags
@@ -1158,7 +1160,8 @@ bool wc_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggParams& ap, 
     list.overflow = Scratch(ctx, 256);
     PRISM_HIP(hipMemsetAsync(list.overflow.p, 0, 4, ctx->stream));
     PRISM_HIP(hipMemsetAsync(d_small.p, 0, 64, ctx->stream));
-    PRISM_HIP(hipMemsetAsync(cm.p, 0, n_cm * 4, ctx->stream));
+    PRISM_HIP(hipMemsetAsync(w.s_keys, 0xff, n_cm * 8, ctx->stream));
+    PRISM_HIP(hipMemsetAsync(w.s_cnt, 0, n_cm * 4, ctx->stream));
     PRISM_HIP(hipMemsetAsync(w.hot_count, 0, (size_t)wc_hot_slots() * 8, ctx->stream));
     w.list_keys = list.keys.as<uint64_t>();
     w.list_state = list.state.as<int64_t>();
@@ -1171,6 +1174,10 @@ bool wc_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggParams& ap, 
     HostTimer ht_wait(ctx, "host:part_wait");
     PRISM_HIP(hipMemcpyAsync(&h, d_small.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     PRISM_HIP(hipStreamSynchronize(ctx->stream));
+    if (std::getenv("PRISM_WC_DEBUG"))
+      std::fprintf(stderr, "[wc] n_wg %u tiles/wg %u cap 2^%u entries %u sample %u thr %u: groups %llu cand %u flags %u %u %u\n", w.n_wg,
+                   w.tiles_per_wg, w.cap_shift, w.lds_entries, w.sample_tiles, w.hot_threshold, h.cursor, h.n_cand, h.flags[0],
+                   h.flags[1], h.flags[2]);
     if (h.flags[1] || h.flags[2]) {
       plan->wc_mode.store(-1, std::memory_order_relaxed);
       return false;

@@ -284,8 +284,9 @@ struct WcParams {
   uint32_t cap_shift;           // a segment holds 2^cap_shift records
   uint64_t* rec;                // [buckets][n_wg][2^cap_shift]
   uint32_t* seg_count;          // [buckets][n_wg]
-  uint32_t* cm;                 // [wc_sample_counters()] counters of the sample, zero on entry
-  uint64_t* cand;               // [wc_max_candidates()]
+  uint64_t* s_keys;             // [wc_sample_counters()] the sample's table: keys (all ones on entry)
+  uint32_t* s_cnt;              // [wc_sample_counters()] and their counts (zero on entry)
+  uint32_t* cand;               // [wc_max_candidates()] entries of the sample's table whose count reached the threshold
   uint32_t* n_cand;             // zero on entry
   uint64_t* hot_keys;           // [wc_hot_slots()] the hot table (all ones: free entry)
   unsigned long long* hot_count;  // [wc_hot_slots()] rows per hot key, zero on entry
@@ -297,6 +298,7 @@ struct WcParams {
   uint64_t list_capacity;
   unsigned long long* list_cursor;  // zero on entry
   uint32_t* flags;              // [0] the list overflowed, [1] a segment overflowed, [2] an LDS table overflowed; zero on entry
+  uint32_t debug;               // experiments: bit 0 no hot look-up, bit 1 no tickets / staging, bit 2 no copy-out
 };
 bool wc_plan_fits(const AggParams& p);
 uint32_t wc_lds_entries(uint32_t n_wg);

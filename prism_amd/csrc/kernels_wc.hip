@@ -6,8 +6,8 @@
 // to place every bucket's rows exactly, then the scatter -- and sorts each tile of rows by
 // bucket in LDS with four barriers per tile, its sixteen waves in step.  Here:
 //
-//   k_wc_sample    a sample of the scan (64 tiles) is counted into a table of 2^20 counters;
-//                  a key whose counter reaches the threshold becomes a candidate
+//   k_wc_sample    a sample of the scan (64 tiles) is counted into a hash table of 2^20 keys;
+//                  a key whose count reaches the threshold becomes a candidate
 //   k_wc_build     the candidates, most frequent first, fill a small table of HOT keys
 //   k_wc_scatter   one pass over the rows.  A row whose key is hot is counted in LDS and goes
 //                  nowhere (with skewed keys -- a few ids in a large share of the rows -- that
@@ -49,11 +49,14 @@ constexpr size_t kWcLdsBytes = 160 * 1024 - 1024;
 
 typedef const __attribute__((address_space(1))) unsigned long long* WcWordPtr;
 
-__device__ __forceinline__ uint32_t wc_bucket(uint64_t key) { return bucket_hash32(key) >> (32 - kWcBucketBits); }
-__device__ __forceinline__ uint32_t wc_hot_bucket(uint64_t key) {
-  const uint32_t x = ((uint32_t)key * 0xC2B2AE35u) ^ ((uint32_t)(key >> 32) * 0x27D4EB2Fu);
-  return (x ^ (x >> 15)) * 0x9E3779B1u >> (32 - 9);  // kWcHotSlots / 2 = 2^9 buckets
-}
+// One 32-bit mix of the key serves the scatter pass twice: its top bits are the bucket, and
+// the two home buckets of the key in the hot table (kWcHotSlots / 2 = 2^9 buckets of two
+// entries) come from its lower bits.  A key takes the first free entry of its first home
+// bucket, else of its second: with one home bucket three of the hundred most frequent keys
+// were likely to share one, and the one turned away overflowed its segments.  A look-up reads
+// the second bucket only when the first is full and holds another two keys.
+__device__ __forceinline__ uint32_t wc_hot_b1(uint32_t mix) { return (mix >> 3) & (kWcHotSlots / 2 - 1); }
+__device__ __forceinline__ uint32_t wc_hot_b2(uint32_t mix) { return (mix * 0x9E3779B1u) >> (32 - 9); }
 __device__ __forceinline__ uint32_t wc_cm_index(uint64_t key) {
   const uint32_t x = ((uint32_t)key ^ (uint32_t)(key >> 32)) * 0x9E3779B1u;
   return ((x ^ (x >> 16)) * 0x85EBCA6Bu) >> (32 - kWcCmBits);
@@ -61,8 +64,15 @@ __device__ __forceinline__ uint32_t wc_cm_index(uint64_t key) {
 
 // ---- the hot keys -----------------------------------------------------------------------
 
+// (The workgroup counts its tile in an LDS table first and adds every key's count to the
+// global counter once: a frequent key is a twentieth of the sample, and ten thousand updates of
+// one address from all over the chip are carried out one after the other -- 0.14 ms.)
 __global__ __launch_bounds__(kWcBlock) void k_wc_sample(AggParams p, WcParams w) {
+  constexpr uint32_t S = 8192;  // a tile has 4096 rows: half load at most
+  __shared__ unsigned long long skey[S];
+  __shared__ uint32_t scnt[S];
   const uint32_t tid = threadIdx.x;
+  for (uint32_t i = tid; i < S; i += kWcBlock) { skey[i] = kWcEmpty; scnt[i] = 0; }
   const uint64_t tile = (uint64_t)blockIdx.x * p.sd.n_tiles / gridDim.x;
   PartSegPos pos;
   part_seg_init(p, pos, tile);
@@ -71,19 +81,54 @@ __global__ __launch_bounds__(kWcBlock) void k_wc_sample(AggParams p, WcParams w)
   uint64_t lo[4], hi[4];
   uint32_t rowc[4], live;
   part_load_keys<1, 4>(p, tl, tid, lo, hi, rowc, live);
+  __syncthreads();
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    if (!((live >> r) & 1u)) continue;
-    const uint32_t c = atomicAdd(&w.cm[wc_cm_index(lo[r])], 1u) + 1u;
-    if (c == w.hot_threshold) {
-      const uint32_t i = atomicAdd(w.n_cand, 1u);
-      if (i < kWcMaxCand) w.cand[i] = lo[r];
+    if (!((live >> r) & 1u) || lo[r] == kWcEmpty) continue;
+    uint32_t e = wc_cm_index(lo[r]) & (S - 1);
+    for (;;) {
+      unsigned long long k = __hip_atomic_load(&skey[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (k == kWcEmpty) {
+        const unsigned long long old = atomicCAS(&skey[e], kWcEmpty, (unsigned long long)lo[r]);
+        k = old == kWcEmpty ? lo[r] : old;
+      }
+      if (k == lo[r]) { atomicAdd(&scnt[e], 1u); break; }
+      e = (e + 1) & (S - 1);
+    }
+  }
+  __syncthreads();
+  // The workgroup's counts join the sample's table in HBM, keyed by the whole key: the add that
+  // takes a key's count across the threshold makes it a candidate, exactly once.  (Counters
+  // shared by whatever keys hash alike would do for the counting, but then the add that
+  // crosses the threshold may be a rare key's, and the frequent key beside it never becomes a
+  // candidate: one run in three lost a key that way and overflowed its segments.)
+  const uint32_t G = 1u << kWcCmBits;
+  for (uint32_t i = tid; i < S; i += kWcBlock) {
+    const unsigned long long k = skey[i];
+    if (k == kWcEmpty) continue;
+    const uint32_t n = scnt[i];
+    uint32_t e = wc_cm_index(k);
+    for (uint32_t probes = 0; probes < 1024; ++probes) {
+      unsigned long long g = __hip_atomic_load(&w.s_keys[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (g == kWcEmpty) {
+        const unsigned long long old = atomicCAS((unsigned long long*)&w.s_keys[e], kWcEmpty, k);
+        g = old == kWcEmpty ? k : old;
+      }
+      if (g == k) {
+        const uint32_t before = atomicAdd(&w.s_cnt[e], n);
+        if (before < w.hot_threshold && before + n >= w.hot_threshold) {
+          const uint32_t j = atomicAdd(w.n_cand, 1u);
+          if (j < kWcMaxCand) w.cand[j] = e;
+        }
+        break;
+      }
+      e = (e + 1) & (G - 1);
     }
   }
 }
 
-// One workgroup: the candidates whose counters ended highest take their home bucket of the
-// hot table first.  A key that finds its bucket full is simply not hot.
+// One workgroup: the candidates whose counters ended highest take their places in the hot
+// table first.  A key that finds both its buckets full is simply not hot.
 __global__ __launch_bounds__(kWcBlock) void k_wc_build(WcParams w) {
   __shared__ unsigned long long t[kWcHotSlots];
   const uint32_t tid = threadIdx.x;
@@ -94,12 +139,13 @@ __global__ __launch_bounds__(kWcBlock) void k_wc_build(WcParams w) {
   for (int pass = 0; pass < 4; ++pass) {
     const uint32_t lower = w.hot_threshold << (2 * (3 - pass));  // 64, 16, 4, 1 times the threshold
     for (uint32_t i = tid; i < n; i += kWcBlock) {
-      const unsigned long long key = w.cand[i];
-      const uint32_t c = w.cm[wc_cm_index(key)];
+      const unsigned long long key = w.s_keys[w.cand[i]];
+      const uint32_t c = w.s_cnt[w.cand[i]];
       if (c < lower || c >= upper || key == kWcEmpty) continue;
-      const uint32_t b = wc_hot_bucket(key);
-      for (uint32_t e = 2 * b; e < 2 * b + 2; ++e) {
-        const unsigned long long old = atomicCAS(&t[e], kWcEmpty, key);
+      const uint32_t mix = bucket_hash32(key), b1 = wc_hot_b1(mix), b2 = wc_hot_b2(mix);
+      const uint32_t order[4] = {2 * b1, 2 * b1 + 1, 2 * b2, 2 * b2 + 1};
+      for (int j = 0; j < 4; ++j) {
+        const unsigned long long old = atomicCAS(&t[order[j]], kWcEmpty, key);
         if (old == kWcEmpty || old == key) break;
       }
     }
@@ -114,19 +160,23 @@ __global__ __launch_bounds__(kWcBlock) void k_wc_build(WcParams w) {
 // Per bucket: `fill` hands out tickets (ticket t: place t % 8 of generation t / 8 of the
 // bucket's staging line), `prog` holds the records of the current generation already in
 // place (low half) and the generations copied out so far (high half, modulo 2^16).  The
-// holder of a ticket writes its record once its generation is the current one; the holder
-// of a generation's last ticket waits for all eight records, copies the line out and opens
-// the next generation.  All waiting is done in one loop that tries every pending step of
-// every lane in turn, so a lane never spins in front of a step that another lane of its own
-// wave has to take first.
+// holder of a ticket writes its record once its generation is the current one; whoever
+// writes a generation's eighth record copies the line out and opens the next generation.
+// The only wait is for a line that still holds the generation before, and it is done in one
+// loop that tries every pending row of every lane in turn, so a lane never spins in front of
+// a step that another lane of its own wave has to take first.
 
-__device__ __forceinline__ uint32_t wc_prog_load(uint32_t* prog) {
-  return __hip_atomic_load(prog, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
+// NK: key columns requested a tile ahead (no validity bitmaps); 0: keys loaded where they are
+// used, with their validity bits; kWcPlain8: ONE 8-byte key column, no NULLs, no selection
+// bitmap, not a date_bin -- the key is (value - bias) << bit_pos, and the loop carries none of
+// the scalar branches on widths and key kinds that the general loaders take per row (they were
+// a third of the wave's issue cycles).
+constexpr int kWcPlain8 = 9;
 
 template <int NK>
 __global__ __launch_bounds__(kWcBlock) __attribute__((amdgpu_waves_per_eu(4))) void k_wc_scatter(AggParams p, WcParams w) {
-  constexpr bool AHEAD = NK > 0;
+  constexpr bool PLAIN = NK == kWcPlain8;
+  constexpr bool AHEAD = NK > 0 && !PLAIN;
   constexpr int NA = AHEAD ? NK : 1;
   constexpr int R = 4;  // rows of a scan tile per thread: a workgroup takes one tile per step
   extern __shared__ __align__(16) unsigned long long wc_lds[];
@@ -146,7 +196,42 @@ __global__ __launch_bounds__(kWcBlock) __attribute__((amdgpu_waves_per_eu(4))) v
   uint32_t live = 0, live_next = 0;
   PartCursor<NA> cur;
   PartSegPos pos;
-  if constexpr (AHEAD) {
+  // kWcPlain8: the four rows of the lane in tile `t` -- two pairs of neighbouring rows, 16 bytes
+  // a load (which rows a lane takes is of no consequence here) -- requested two tiles before they
+  // are used: with 8-byte loads one tile ahead a CU had 32 KiB in flight and the pass read at
+  // 3.5 TB/s with everything else switched off.
+  typedef unsigned long long __attribute__((ext_vector_type(2))) wc_u64x2;
+  wc_u64x2 pre[2][2];      // [tile parity][pair]
+  uint32_t pre_live[2] = {0, 0};
+  auto plain_issue = [&](uint64_t t, int slot) {
+    if constexpr (!PLAIN) return;
+    else {
+    while (t >= cur.next_base) part_cursor_load<1, 0>(p, cur, cur.seg + 1);
+    const uint64_t first = (t - cur.base) * kTileRows, left = cur.rows - first;
+    const uint32_t n = left > kTileRows ? kTileRows : (uint32_t)left, row0 = (uint32_t)first;
+    uint32_t lv = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const uint32_t in_tile = (uint32_t)h * 2u * kWcBlock + 2u * tid;  // the pair's first row
+      lv |= (in_tile < n ? 1u : 0u) << (2 * h);
+      lv |= (in_tile + 1 < n ? 1u : 0u) << (2 * h + 1);
+      // (a pair beyond the tile's rows reads the tile's first pair; one that straddles its end reads
+      // eight bytes into the column's padding)
+      pre[slot][h] = __builtin_nontemporal_load(
+          (const __attribute__((address_space(1))) wc_u64x2*)(cur.col[0] + (row0 + (in_tile < n ? in_tile : 0u)) * 8u));
+    }
+    pre_live[slot] = lv;
+    }
+  };
+  const uint64_t plain_bias = (uint64_t)p.keys[0].bias;
+  const int plain_shift = p.keys[0].bit_pos;
+  if constexpr (PLAIN) {
+    if (t0 < t1) {
+      part_cursor_init<1, 0>(p, cur, t0);
+      plain_issue(t0, 0);
+      if (t0 + 1 < t1) plain_issue(t0 + 1, 1);
+    }
+  } else if constexpr (AHEAD) {
     if (t0 < t1) {
       part_cursor_init<NA, 0>(p, cur, t0);
       part_issue<NA, 0, R>(p, cur, t0, t1, tid, raw, live_next);
@@ -156,7 +241,21 @@ __global__ __launch_bounds__(kWcBlock) __attribute__((amdgpu_waves_per_eu(4))) v
   }
   for (uint64_t t = t0; t < t1; ++t) {
     uint64_t key[R];
-    if constexpr (AHEAD) {
+    if constexpr (PLAIN) {
+      // (the two slots are taken in turn: the loop is unrolled by hand so that they stay registers)
+      const int slot = (int)((t - t0) & 1u);
+      if (slot == 0) {
+        key[0] = pre[0][0].x; key[1] = pre[0][0].y; key[2] = pre[0][1].x; key[3] = pre[0][1].y;
+        live = pre_live[0];
+        if (t + 2 < t1) plain_issue(t + 2, 0);
+      } else {
+        key[0] = pre[1][0].x; key[1] = pre[1][0].y; key[2] = pre[1][1].x; key[3] = pre[1][1].y;
+        live = pre_live[1];
+        if (t + 2 < t1) plain_issue(t + 2, 1);
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) key[r] = (key[r] - plain_bias) << plain_shift;
+    } else if constexpr (AHEAD) {
       uint64_t rec[1][R];
       part_finish<1, NA, 0, R>(p, raw, rec);
 #pragma unroll
@@ -171,60 +270,94 @@ __global__ __launch_bounds__(kWcBlock) __attribute__((amdgpu_waves_per_eu(4))) v
       part_load_keys<1, R>(p, tl, tid, key, hi_unused, rowc, live);
     }
     // hot keys are counted where they are; the other rows take a ticket of their bucket
-    uint32_t bkt[R], tk[R], needw = 0, needf = 0;
-    ulonglong2 hc[R];
-    uint32_t hb[R];
+    uint32_t mix[R], bkt[R], tk[R], needw = 0;
+    ulonglong2 hc1[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      hb[r] = wc_hot_bucket(key[r]);
-      hc[r] = *(const ulonglong2*)&hot_keys[2 * hb[r]];
+      mix[r] = bucket_hash32(key[r]);
+      bkt[r] = mix[r] >> (32 - kWcBucketBits);
+      hc1[r] = *(const ulonglong2*)&hot_keys[2 * wc_hot_b1(mix[r])];
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      bkt[r] = wc_bucket(key[r]);
       tk[r] = 0;
       if (!((live >> r) & 1u)) continue;
-      if (hc[r].x == key[r] || hc[r].y == key[r]) {
-        atomicAdd(&hot_cnt[2 * hb[r] + (hc[r].x == key[r] ? 0u : 1u)], 1u);
-      } else {
+      int hot = -1;
+      hot = hc1[r].y == key[r] ? (int)(2 * wc_hot_b1(mix[r]) + 1) : hot;
+      hot = hc1[r].x == key[r] ? (int)(2 * wc_hot_b1(mix[r])) : hot;
+      if (w.debug & 1u) hot = -1;
+      if (hot < 0 && hc1[r].y != kWcEmpty && !(w.debug & 1u)) {  // the first home bucket is full of other keys: the key may sit in its second
+        const uint32_t b2 = wc_hot_b2(mix[r]);
+        const ulonglong2 hc2 = *(const ulonglong2*)&hot_keys[2 * b2];
+        hot = hc2.y == key[r] ? (int)(2 * b2 + 1) : hot;
+        hot = hc2.x == key[r] ? (int)(2 * b2) : hot;
+      }
+      if (hot >= 0) {
+        atomicAdd(&hot_cnt[hot], 1u);
+      } else if (!(w.debug & 2u)) {
         tk[r] = atomicAdd(&fill[bkt[r]], 1u);
         needw |= 1u << r;
       }
     }
+    // Each round takes the pending rows of the lane through the same steps together -- the four
+    // look-ups of `prog`, then the stores, then the four additions -- so that their LDS round
+    // trips overlap instead of adding up row after row.  (LDS carries out a wave's
+    // instructions in the order they were issued; the compiler is kept from reordering them,
+    // and nothing has to wait for a store before the addition that follows it.)
     for (;;) {
+      uint32_t pr[R], before[R], ok = 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) pr[r] = __hip_atomic_load(&prog[bkt[r]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const uint32_t gen = tk[r] / kWcStage, place = tk[r] % kWcStage;
-        if ((needw >> r) & 1u) {
-          const uint32_t pr = wc_prog_load(&prog[bkt[r]]);
-          if ((pr >> 16) == (gen & 0xffffu)) {
-            __hip_atomic_store(&stage[(size_t)bkt[r] * kWcStage + place], (unsigned long long)key[r], __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(&prog[bkt[r]], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            needw &= ~(1u << r);
-            if (place == kWcStage - 1) needf |= 1u << r;
-          }
+        if (((needw >> r) & 1u) && (pr[r] >> 16) == (gen & 0xffffu)) {  // (else the line still holds the generation before)
+          ok |= 1u << r;
+          __hip_atomic_store(&stage[(size_t)bkt[r] * kWcStage + place], (unsigned long long)key[r], __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        if ((needf >> r) & 1u) {
-          const uint32_t pr = wc_prog_load(&prog[bkt[r]]);
-          if ((pr & 0xffffu) == kWcStage) {
-            // the line is complete: out it goes, 64 contiguous bytes of the segment
-            const ulonglong2* s = (const ulonglong2*)&stage[(size_t)bkt[r] * kWcStage];
-            const ulonglong2 a = s[0], b = s[1], c = s[2], d = s[3];
-            const uint64_t off = (uint64_t)gen * kWcStage;
-            if (off + kWcStage <= cap) {
-              ulonglong2* dst = (ulonglong2*)(w.rec + ((((uint64_t)bkt[r] * w.n_wg + wg) << w.cap_shift) + off));
-              dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = d;
-            } else {
-              w.flags[1] = 1u;
-            }
-            // the records are in registers: the next generation may come (-8 records, +1 generation)
-            __hip_atomic_fetch_add(&prog[bkt[r]], 0x10000u - kWcStage, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            needf &= ~(1u << r);
+      }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        before[r] = 0;
+        if ((ok >> r) & 1u) before[r] = __hip_atomic_fetch_add(&prog[bkt[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      needw &= ~ok;
+      // The rows that put the eighth record of a line in place copy the line out, 64 contiguous
+      // bytes of the segment (nobody waits for anybody: whoever writes last, copies).  A lane
+      // seldom has two such rows in a round, so the copy-out is issued once per lane, for its
+      // first such row, and again only while some lane has another: a store instruction costs the
+      // address unit the same sixteen cycles whether four of its lanes are active or sixty-four,
+      // and one copy-out per ROW of the round made this a third of the pass.
+      uint32_t fl = 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (((ok >> r) & 1u) && (before[r] & 0xffffu) == kWcStage - 1) fl |= 1u << r;
+      while (__ballot(fl != 0u) != 0ull) {
+        if (fl != 0u) {
+          const int r = __ffs((int)fl) - 1;
+          fl &= fl - 1u;
+          const uint32_t fb = r == 0 ? bkt[0] : r == 1 ? bkt[1] : r == 2 ? bkt[2] : bkt[3];
+          const uint32_t ft = r == 0 ? tk[0] : r == 1 ? tk[1] : r == 2 ? tk[2] : tk[3];
+          const ulonglong2* s = (const ulonglong2*)&stage[(size_t)fb * kWcStage];
+          asm volatile("" ::: "memory");
+          const ulonglong2 a = s[0], b = s[1], c = s[2], d = s[3];
+          asm volatile("" ::: "memory");
+          // the records are on their way to registers: the next generation may come (-8 records, +1 generation)
+          __hip_atomic_fetch_add(&prog[fb], 0x10000u - kWcStage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const uint64_t off = (uint64_t)(ft / kWcStage) * kWcStage;
+          if (w.debug & 4u) {
+            if (a.x == 12345ull && b.x == c.x && d.y == 7ull) w.flags[3] = 1u;
+          } else if (off + kWcStage <= cap) {
+            ulonglong2* dst = (ulonglong2*)(w.rec + ((((uint64_t)fb * w.n_wg + wg) << w.cap_shift) + off));
+            dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = d;
+          } else {
+            w.flags[1] = 1u;
           }
         }
       }
-      if (__ballot((needw | needf) != 0u) == 0ull) break;
+      if (__ballot(needw != 0u) == 0ull) break;
     }
   }
   __syncthreads();
@@ -292,16 +425,31 @@ __global__ __launch_bounds__(kWcBlock) void k_wc_agg(AggParams p, WcParams w) {
       const uint32_t seg = seg0 + seg_lane;
       const uint32_t c = seg < w.n_wg ? segcnt[seg] : 0u;
       const unsigned long long* s = region + ((uint64_t)(seg < w.n_wg ? seg : 0u) << w.cap_shift);
-      for (uint32_t i0 = 0; __ballot(i0 < c) != 0ull; i0 += 16 * U) {
+      uint32_t cmax = c;  // the longest of the wave's four segments: the wave's trip count
+#pragma unroll
+      for (int off = 32; off >= 16; off >>= 1) { const uint32_t o = __shfl_xor(cmax, off, 64); cmax = o > cmax ? o : cmax; }
+      cmax = __builtin_amdgcn_readfirstlane(cmax);
+      // the keys of the next step are requested before those of this step are looked up
+      uint64_t next[U];
+      auto request = [&](uint32_t i0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t j = i0 + (uint32_t)u * 16u + sub;
+          next[u] = __builtin_nontemporal_load((WcWordPtr)(uint64_t)(s + (j < c ? j : 0u)));
+        }
+      };
+      if (cmax) request(0);
+      for (uint32_t i0 = 0; i0 < cmax; i0 += 16 * U) {
         uint64_t key[U];
         bool in[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const uint32_t j = i0 + (uint32_t)u * 16u + sub;
-          in[u] = j < c;
-          key[u] = __builtin_nontemporal_load((WcWordPtr)(uint64_t)(s + (in[u] ? j : 0u)));
+          key[u] = next[u];
+          in[u] = i0 + (uint32_t)u * 16u + sub < c;
         }
-        // the first home bucket of all the step's rows is read before any is looked at
+        if (i0 + 16 * U < cmax) request(i0 + 16 * U);
+        // the first home bucket of all the step's rows is read before any is looked at, and the
+        // claims of the new keys among them go out together: the LDS round trips overlap
         ulonglong2 c1[U];
         uint32_t h1[U];
 #pragma unroll
@@ -309,18 +457,31 @@ __global__ __launch_bounds__(kWcBlock) void k_wc_agg(AggParams p, WcParams w) {
           h1[u] = __umulhi(((uint32_t)key[u] ^ (uint32_t)(key[u] >> 32)) * 0x9E3779B1u, nb);
           c1[u] = *(const ulonglong2*)&keys[2 * (size_t)h1[u]];
         }
+        int e[U];
+        unsigned long long old[U];
+        bool claim[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          e[u] = c1[u].x == key[u] ? (int)(2 * h1[u]) : (c1[u].y == key[u] ? (int)(2 * h1[u] + 1) : -1);
+          // a new key, as a rule, and a free entry in its first home bucket: one attempt to claim it
+          // (the entry was free when the bucket was read and entries only fill up: if the claim
+          // succeeds or meets the same key, the entry is the key's)
+          claim[u] = in[u] && e[u] < 0 && c1[u].y == kWcEmpty;
+          old[u] = 0;
+          if (claim[u])
+            old[u] = atomicCAS(&keys[2 * h1[u] + (c1[u].x == kWcEmpty ? 0u : 1u)], kWcEmpty, (unsigned long long)key[u]);
+        }
         uint32_t n_new = 0;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          int e = c1[u].x == key[u] ? (int)(2 * h1[u]) : (c1[u].y == key[u] ? (int)(2 * h1[u] + 1) : -1);
-          bool ins = false;
-          if (in[u] && e < 0) {
-            e = wc_entry(keys, nb, key[u], ins);
-            if (e < 0) lost = true;
+          bool ins = claim[u] && old[u] == kWcEmpty;
+          if (claim[u] && (old[u] == kWcEmpty || old[u] == key[u])) e[u] = (int)(2 * h1[u] + (c1[u].x == kWcEmpty ? 0u : 1u));
+          if (in[u] && e[u] < 0) {
+            e[u] = wc_entry(keys, nb, key[u], ins);
+            if (e[u] < 0) lost = true;
           }
-          const uint64_t m_ins = __ballot(ins);
-          n_new += (uint32_t)__popcll(m_ins);
-          if (in[u] && e >= 0) atomicAdd(&cnt[e], 1u);
+          n_new += (uint32_t)__popcll(__ballot(ins));
+          if (in[u] && e[u] >= 0) atomicAdd(&cnt[e[u]], 1u);
         }
         if (n_new && lane == 0) atomicAdd(&n_entries, n_new);
       }
@@ -404,7 +565,8 @@ void launch_wc_group_by(prism_gpu_ctx* ctx, const AggParams& p, const WcParams& 
     KernelTimer timer(ctx, "wc_scatter", rows * (key_bytes + 8));
     const size_t lds = (size_t)kWcBuckets * kWcStage * 8 + (size_t)kWcBuckets * 8 + (size_t)kWcHotSlots * 12;
     const int ahead = part_keys_ahead(p);
-    auto kernel = ahead == 1 ? k_wc_scatter<1> : ahead == 2 ? k_wc_scatter<2> : k_wc_scatter<0>;
+    const bool plain8 = ahead == 1 && p.n_keys == 1 && p.keys[0].width == 8 && !p.keys[0].date_bin && p.row_mode == kRowsAll;
+    auto kernel = plain8 ? k_wc_scatter<kWcPlain8> : ahead == 1 ? k_wc_scatter<1> : ahead == 2 ? k_wc_scatter<2> : k_wc_scatter<0>;
     wc_allow_lds((const void*)kernel, lds);
     kernel<<<dim3(w.n_wg), dim3(kWcBlock), lds, ctx->stream>>>(p, w);
     PRISM_HIP(hipGetLastError());
