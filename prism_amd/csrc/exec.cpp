@@ -1122,29 +1122,35 @@ bool wc_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggParams& ap, 
   w.n_wg = (uint32_t)std::max<uint64_t>(1, ceil_div(ap.sd.n_tiles, per));
   const uint32_t P = wc_buckets();
   // a segment: the rows a (workgroup, bucket) pair expects, half as many again, and a margin
-  // for small scans whose counts vary more
+  // for small scans whose counts vary more.  (Sizing the segments for the rows the hot keys left
+  // on the plan's last run -- half the size on skewed data -- was tried: keys just below the hot
+  // table's reach then overflow their segments, and every run paid for a second attempt.)
   const uint64_t mean = ceil_div(selected, (uint64_t)w.n_wg * P);
-  uint64_t cap = pow2_ceil(std::max<uint64_t>(64, mean + mean / 2 + 64));
+  const uint64_t cap = pow2_ceil(std::max<uint64_t>(64, mean + mean / 2 + 64));
   while ((1ull << w.cap_shift) < cap) ++w.cap_shift;
+  const uint32_t full_shift = w.cap_shift;
   w.lds_entries = wc_lds_entries(w.n_wg);
-  w.sample_tiles = (uint32_t)std::min<uint64_t>(64, ap.sd.n_tiles);
+  w.sample_tiles = (uint32_t)std::min<uint64_t>(32, ap.sd.n_tiles);
   // a candidate: a key seen this often in the sample (1/32768 of it, at least 4 times)
   w.hot_threshold = (uint32_t)std::max<uint64_t>(4, ((uint64_t)w.sample_tiles * kTileRows) >> 15);
-  if (const char* dbg = std::getenv("PRISM_WC_DEBUG_MODE")) w.debug = (uint32_t)std::atoi(dbg);
   const uint64_t n_cm = wc_sample_counters();
-  Scratch rec(ctx, ((uint64_t)P * w.n_wg << w.cap_shift) * 8 + 256), seg_count(ctx, (uint64_t)P * w.n_wg * 4),
-      cm(ctx, n_cm * 12), cand(ctx, (uint64_t)wc_max_candidates() * 4), hot(ctx, (uint64_t)wc_hot_slots() * 16), d_small(ctx, 256);
+  Scratch rec(ctx, ((uint64_t)P * w.n_wg << full_shift) * 8 + 256), seg_count(ctx, (uint64_t)P * w.n_wg * 4),
+      cm(ctx, n_cm * 12 + (uint64_t)wc_hot_slots() * 8 + 256), cand(ctx, (uint64_t)wc_max_candidates() * 4), hot(ctx, (uint64_t)wc_hot_slots() * 8);
   w.rec = rec.as<uint64_t>();
   w.seg_count = seg_count.as<uint32_t>();
   w.s_keys = cm.as<uint64_t>();
   w.s_cnt = (uint32_t*)(cm.as<uint64_t>() + n_cm);
   w.cand = cand.as<uint32_t>();
   w.hot_keys = hot.as<uint64_t>();
-  w.hot_count = (unsigned long long*)(hot.as<uint64_t>() + wc_hot_slots());
-  // one small block: [0] the list cursor (8 bytes), [8] the candidates, [16] three flags
-  w.list_cursor = d_small.as<unsigned long long>();
-  w.n_cand = (uint32_t*)(d_small.as<uint8_t>() + 8);
-  w.flags = (uint32_t*)(d_small.as<uint8_t>() + 16);
+  // what starts at zero lies in one block behind the sample's keys and is cleared in one go: the
+  // sample's counts, the hot keys' rows, and a small block -- [0] the list cursor (8 bytes),
+  // [8] the candidates, [16] four flags, [32] the hot keys' rows in total
+  w.hot_count = (unsigned long long*)(w.s_cnt + n_cm);
+  uint8_t* const d_small = (uint8_t*)(w.hot_count + wc_hot_slots());
+  w.list_cursor = (unsigned long long*)d_small;
+  w.n_cand = (uint32_t*)(d_small + 8);
+  w.flags = (uint32_t*)(d_small + 16);
+  w.hot_rows = (unsigned long long*)(d_small + 32);
   uint64_t groups_est = plan->part_groups.load(std::memory_order_relaxed);
   if (!groups_est) groups_est = plan->groups_hint;
   uint64_t list_cap = groups_est ? groups_est + groups_est / 16 + 1024 : std::min<uint64_t>(selected, 1ull << 25);
@@ -1159,10 +1165,8 @@ bool wc_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggParams& ap, 
     list.state = Scratch(ctx, (list_cap + 1) * 8);
     list.overflow = Scratch(ctx, 256);
     PRISM_HIP(hipMemsetAsync(list.overflow.p, 0, 4, ctx->stream));
-    PRISM_HIP(hipMemsetAsync(d_small.p, 0, 64, ctx->stream));
     PRISM_HIP(hipMemsetAsync(w.s_keys, 0xff, n_cm * 8, ctx->stream));
-    PRISM_HIP(hipMemsetAsync(w.s_cnt, 0, n_cm * 4, ctx->stream));
-    PRISM_HIP(hipMemsetAsync(w.hot_count, 0, (size_t)wc_hot_slots() * 8, ctx->stream));
+    PRISM_HIP(hipMemsetAsync(w.s_cnt, 0, n_cm * 4 + (size_t)wc_hot_slots() * 8 + 64, ctx->stream));
     w.list_keys = list.keys.as<uint64_t>();
     w.list_state = list.state.as<int64_t>();
     w.list_capacity = list_cap;
@@ -1170,14 +1174,15 @@ bool wc_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggParams& ap, 
       KernelTimer timer(ctx, "group_by", selected * key_bytes);
       launch_wc_group_by(ctx, ap, w, key_bytes);
     }
-    struct { unsigned long long cursor; uint32_t n_cand, pad; uint32_t flags[4]; } h{};
+    struct { unsigned long long cursor; uint32_t n_cand, pad; uint32_t flags[4]; unsigned long long hot_rows; } h{};
     HostTimer ht_wait(ctx, "host:part_wait");
-    PRISM_HIP(hipMemcpyAsync(&h, d_small.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    PRISM_HIP(hipMemcpyAsync(&h, d_small, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     PRISM_HIP(hipStreamSynchronize(ctx->stream));
     if (std::getenv("PRISM_WC_DEBUG"))
       std::fprintf(stderr, "[wc] n_wg %u tiles/wg %u cap 2^%u entries %u sample %u thr %u: groups %llu cand %u flags %u %u %u\n", w.n_wg,
                    w.tiles_per_wg, w.cap_shift, w.lds_entries, w.sample_tiles, w.hot_threshold, h.cursor, h.n_cand, h.flags[0],
                    h.flags[1], h.flags[2]);
+    if (std::getenv("PRISM_WC_DEBUG")) std::fprintf(stderr, "[wc] hot rows %llu of %llu\n", h.hot_rows, (unsigned long long)selected);
     if (h.flags[1] || h.flags[2]) {
       plan->wc_mode.store(-1, std::memory_order_relaxed);
       return false;

@@ -290,6 +290,7 @@ struct WcParams {
   uint32_t* n_cand;             // zero on entry
   uint64_t* hot_keys;           // [wc_hot_slots()] the hot table (all ones: free entry)
   unsigned long long* hot_count;  // [wc_hot_slots()] rows per hot key, zero on entry
+  unsigned long long* hot_rows;   // their sum, zero on entry
   uint32_t sample_tiles;        // scan tiles the sample takes
   uint32_t hot_threshold;       // sample count from which a key is a candidate
   uint32_t lds_entries;         // entries of the aggregation pass' LDS table (even)
@@ -298,7 +299,6 @@ struct WcParams {
   uint64_t list_capacity;
   unsigned long long* list_cursor;  // zero on entry
   uint32_t* flags;              // [0] the list overflowed, [1] a segment overflowed, [2] an LDS table overflowed; zero on entry
-  uint32_t debug;               // experiments: bit 0 no hot look-up, bit 1 no tickets / staging, bit 2 no copy-out
 };
 bool wc_plan_fits(const AggParams& p);
 uint32_t wc_lds_entries(uint32_t n_wg);

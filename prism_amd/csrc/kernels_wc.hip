@@ -6,7 +6,7 @@
 // to place every bucket's rows exactly, then the scatter -- and sorts each tile of rows by
 // bucket in LDS with four barriers per tile, its sixteen waves in step.  Here:
 //
-//   k_wc_sample    a sample of the scan (64 tiles) is counted into a hash table of 2^20 keys;
+//   k_wc_sample    a sample of the scan (32 tiles) is counted into a hash table of 2^19 keys;
 //                  a key whose count reaches the threshold becomes a candidate
 //   k_wc_build     the candidates, most frequent first, fill a small table of HOT keys
 //   k_wc_scatter   one pass over the rows.  A row whose key is hot is counted in LDS and goes
@@ -25,7 +25,7 @@
 //                  the keys counted in an LDS table of two-entry buckets with 32-bit counters
 //                  (12 bytes a group: 13 000 groups per bucket, 2.7e7 per query), the groups
 //                  appended to the result list
-//   k_wc_hot_emit  the hot keys' totals join the list
+//                  appended to the result list; the hot keys' totals join the list at the end
 //
 // Traffic per row: the key read once, the record written once and read once (24 bytes for an
 // 8-byte key, less the hot rows' share of the last two).
@@ -41,7 +41,7 @@ constexpr uint32_t kWcBlock = 1024;
 constexpr uint32_t kWcBucketBits = 11, kWcBuckets = 1u << kWcBucketBits;
 constexpr uint32_t kWcStage = 8;          // records of a staging line (64 bytes)
 constexpr uint32_t kWcHotSlots = 1024;    // hot table: 512 buckets of two entries
-constexpr uint32_t kWcCmBits = 20;        // counters of the sample
+constexpr uint32_t kWcCmBits = 19;        // entries of the sample's table (32 tiles: a quarter full at most)
 constexpr uint32_t kWcMaxCand = 4096;
 constexpr unsigned long long kWcEmpty = ~0ull;
 constexpr int kWcMaxProbes = 128;
@@ -103,26 +103,39 @@ __global__ __launch_bounds__(kWcBlock) void k_wc_sample(AggParams p, WcParams w)
   // crosses the threshold may be a rare key's, and the frequent key beside it never becomes a
   // candidate: one run in three lost a key that way and overflowed its segments.)
   const uint32_t G = 1u << kWcCmBits;
-  for (uint32_t i = tid; i < S; i += kWcBlock) {
-    const unsigned long long k = skey[i];
-    if (k == kWcEmpty) continue;
-    const uint32_t n = scnt[i];
-    uint32_t e = wc_cm_index(k);
-    for (uint32_t probes = 0; probes < 1024; ++probes) {
-      unsigned long long g = __hip_atomic_load(&w.s_keys[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (g == kWcEmpty) {
-        const unsigned long long old = atomicCAS((unsigned long long*)&w.s_keys[e], kWcEmpty, k);
-        g = old == kWcEmpty ? k : old;
-      }
-      if (g == k) {
-        const uint32_t before = atomicAdd(&w.s_cnt[e], n);
-        if (before < w.hot_threshold && before + n >= w.hot_threshold) {
-          const uint32_t j = atomicAdd(w.n_cand, 1u);
-          if (j < kWcMaxCand) w.cand[j] = e;
-        }
-        break;
-      }
-      e = (e + 1) & (G - 1);
+  // (a thread's eight entries are taken through the steps together -- the claims, then the
+  // additions -- so that it waits for the memory side twice, not sixteen times)
+  constexpr int PER = S / kWcBlock;
+  unsigned long long k[PER], g[PER];
+  uint32_t n[PER], e[PER], before[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    k[j] = skey[tid + (uint32_t)j * kWcBlock];
+    n[j] = scnt[tid + (uint32_t)j * kWcBlock];
+    e[j] = wc_cm_index(k[j]);
+    g[j] = 0;
+    if (k[j] != kWcEmpty) g[j] = atomicCAS((unsigned long long*)&w.s_keys[e[j]], kWcEmpty, k[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    if (k[j] == kWcEmpty) continue;
+    // not the key's entry: on along the probe path (rare at a quarter load)
+    for (uint32_t probes = 0; g[j] != kWcEmpty && g[j] != k[j] && probes < 1024; ++probes) {
+      e[j] = (e[j] + 1) & (G - 1);
+      g[j] = atomicCAS((unsigned long long*)&w.s_keys[e[j]], kWcEmpty, k[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    before[j] = 0;
+    if (k[j] != kWcEmpty && (g[j] == kWcEmpty || g[j] == k[j])) before[j] = atomicAdd(&w.s_cnt[e[j]], n[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    if (k[j] == kWcEmpty || !(g[j] == kWcEmpty || g[j] == k[j])) continue;
+    if (before[j] < w.hot_threshold && before[j] + n[j] >= w.hot_threshold) {
+      const uint32_t c = atomicAdd(w.n_cand, 1u);
+      if (c < kWcMaxCand) w.cand[c] = e[j];
     }
   }
 }
@@ -134,19 +147,29 @@ __global__ __launch_bounds__(kWcBlock) void k_wc_build(WcParams w) {
   const uint32_t tid = threadIdx.x;
   for (uint32_t i = tid; i < kWcHotSlots; i += kWcBlock) t[i] = kWcEmpty;
   const uint32_t n = *w.n_cand < kWcMaxCand ? *w.n_cand : kWcMaxCand;
+  // a thread's candidates (at most four), fetched once for all the passes
+  constexpr int PER = kWcMaxCand / kWcBlock;
+  unsigned long long key[PER];
+  uint32_t cnt[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const uint32_t i = tid + (uint32_t)j * kWcBlock;
+    const uint32_t at = i < n ? w.cand[i] : 0u;
+    key[j] = i < n ? w.s_keys[at] : kWcEmpty;
+    cnt[j] = i < n ? w.s_cnt[at] : 0u;
+  }
   __syncthreads();
   uint32_t upper = ~0u;
   for (int pass = 0; pass < 4; ++pass) {
     const uint32_t lower = w.hot_threshold << (2 * (3 - pass));  // 64, 16, 4, 1 times the threshold
-    for (uint32_t i = tid; i < n; i += kWcBlock) {
-      const unsigned long long key = w.s_keys[w.cand[i]];
-      const uint32_t c = w.s_cnt[w.cand[i]];
-      if (c < lower || c >= upper || key == kWcEmpty) continue;
-      const uint32_t mix = bucket_hash32(key), b1 = wc_hot_b1(mix), b2 = wc_hot_b2(mix);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      if (cnt[j] < lower || cnt[j] >= upper || key[j] == kWcEmpty) continue;
+      const uint32_t mix = bucket_hash32(key[j]), b1 = wc_hot_b1(mix), b2 = wc_hot_b2(mix);
       const uint32_t order[4] = {2 * b1, 2 * b1 + 1, 2 * b2, 2 * b2 + 1};
-      for (int j = 0; j < 4; ++j) {
-        const unsigned long long old = atomicCAS(&t[order[j]], kWcEmpty, key);
-        if (old == kWcEmpty || old == key) break;
+      for (int o = 0; o < 4; ++o) {
+        const unsigned long long old = atomicCAS(&t[order[o]], kWcEmpty, key[j]);
+        if (old == kWcEmpty || old == key[j]) break;
       }
     }
     upper = lower;
@@ -285,8 +308,7 @@ __global__ __launch_bounds__(kWcBlock) __attribute__((amdgpu_waves_per_eu(4))) v
       int hot = -1;
       hot = hc1[r].y == key[r] ? (int)(2 * wc_hot_b1(mix[r]) + 1) : hot;
       hot = hc1[r].x == key[r] ? (int)(2 * wc_hot_b1(mix[r])) : hot;
-      if (w.debug & 1u) hot = -1;
-      if (hot < 0 && hc1[r].y != kWcEmpty && !(w.debug & 1u)) {  // the first home bucket is full of other keys: the key may sit in its second
+      if (hot < 0 && hc1[r].y != kWcEmpty) {  // the first home bucket is full of other keys: the key may sit in its second
         const uint32_t b2 = wc_hot_b2(mix[r]);
         const ulonglong2 hc2 = *(const ulonglong2*)&hot_keys[2 * b2];
         hot = hc2.y == key[r] ? (int)(2 * b2 + 1) : hot;
@@ -294,7 +316,7 @@ __global__ __launch_bounds__(kWcBlock) __attribute__((amdgpu_waves_per_eu(4))) v
       }
       if (hot >= 0) {
         atomicAdd(&hot_cnt[hot], 1u);
-      } else if (!(w.debug & 2u)) {
+      } else {
         tk[r] = atomicAdd(&fill[bkt[r]], 1u);
         needw |= 1u << r;
       }
@@ -347,9 +369,7 @@ __global__ __launch_bounds__(kWcBlock) __attribute__((amdgpu_waves_per_eu(4))) v
           // the records are on their way to registers: the next generation may come (-8 records, +1 generation)
           __hip_atomic_fetch_add(&prog[fb], 0x10000u - kWcStage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           const uint64_t off = (uint64_t)(ft / kWcStage) * kWcStage;
-          if (w.debug & 4u) {
-            if (a.x == 12345ull && b.x == c.x && d.y == 7ull) w.flags[3] = 1u;
-          } else if (off + kWcStage <= cap) {
+          if (off + kWcStage <= cap) {
             ulonglong2* dst = (ulonglong2*)(w.rec + ((((uint64_t)fb * w.n_wg + wg) << w.cap_shift) + off));
             dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = d;
           } else {
@@ -404,6 +424,31 @@ __device__ __forceinline__ int wc_entry(unsigned long long* keys, uint32_t nb, u
   return -1;
 }
 
+// The hot keys' totals join the list (one workgroup; run by the aggregation pass' first
+// workgroup once its buckets are done: the list has no order, and a launch of its own for a
+// thousand entries cost more than the work).
+__device__ __forceinline__ void wc_hot_emit(const WcParams& w) {
+  const uint32_t i = threadIdx.x, lane = i & 63u;
+  const unsigned long long k = i < kWcHotSlots ? w.hot_keys[i] : kWcEmpty;
+  const unsigned long long c = i < kWcHotSlots ? w.hot_count[i] : 0ull;
+  const bool occ = k != kWcEmpty && c != 0ull;
+  // (the rows the hot keys took: the caller sizes the next run's segments for the rest)
+  const unsigned long long wave_rows = wave_sum_u64(occ ? c : 0ull);
+  if (lane == 0 && wave_rows) atomicAdd(w.hot_rows, wave_rows);
+  const uint64_t m = __ballot(occ);
+  unsigned long long wave_first = 0;
+  if (lane == 0 && m) wave_first = atomicAdd(w.list_cursor, (unsigned long long)__popcll(m));
+  wave_first = __shfl(wave_first, 0);
+  if (!occ) return;
+  const uint64_t at = wave_first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+  if (at < w.list_capacity) {
+    w.list_keys[at] = k;
+    w.list_state[at] = (long long)c;
+  } else {
+    w.flags[0] = 1u;
+  }
+}
+
 __global__ __launch_bounds__(kWcBlock) void k_wc_agg(AggParams p, WcParams w) {
   extern __shared__ __align__(16) unsigned long long wc_lds[];
   __shared__ uint32_t n_entries, wg_pos;
@@ -412,8 +457,13 @@ __global__ __launch_bounds__(kWcBlock) void k_wc_agg(AggParams p, WcParams w) {
   unsigned long long* keys = wc_lds;              // [E]
   uint32_t* cnt = (uint32_t*)(keys + E);          // [E]
   uint32_t* segcnt = cnt + E;                     // [n_wg]
-  const uint32_t sub = tid & 15u, seg_lane = tid >> 4;  // 16 lanes a segment, 64 segments a round
-  constexpr int U = 8;
+  // 32 lanes a segment and five rows a lane: a step covers 160 records of each of the wave's two
+  // segments -- a segment of the usual 100 to 130 records in one step with a quarter of the
+  // lanes idle (16 lanes x 8 rows covered 128, and most waves went round a second time for the
+  // one segment of their four that held a few more)
+  constexpr uint32_t LPS = 32;
+  const uint32_t sub = tid & (LPS - 1), seg_lane = tid / LPS;
+  constexpr int U = 5;
   for (uint32_t b = blockIdx.x; b < kWcBuckets; b += gridDim.x) {
     for (uint32_t i = tid; i < E; i += kWcBlock) { keys[i] = kWcEmpty; cnt[i] = 0; }
     for (uint32_t i = tid; i < w.n_wg; i += kWcBlock) segcnt[i] = w.seg_count[(uint64_t)b * w.n_wg + i];
@@ -421,33 +471,32 @@ __global__ __launch_bounds__(kWcBlock) void k_wc_agg(AggParams p, WcParams w) {
     __syncthreads();
     const unsigned long long* region = (const unsigned long long*)w.rec + (((uint64_t)b * w.n_wg) << w.cap_shift);
     bool lost = false;
-    for (uint32_t seg0 = 0; seg0 < w.n_wg; seg0 += kWcBlock / 16) {
+    for (uint32_t seg0 = 0; seg0 < w.n_wg; seg0 += kWcBlock / LPS) {
       const uint32_t seg = seg0 + seg_lane;
       const uint32_t c = seg < w.n_wg ? segcnt[seg] : 0u;
       const unsigned long long* s = region + ((uint64_t)(seg < w.n_wg ? seg : 0u) << w.cap_shift);
-      uint32_t cmax = c;  // the longest of the wave's four segments: the wave's trip count
-#pragma unroll
-      for (int off = 32; off >= 16; off >>= 1) { const uint32_t o = __shfl_xor(cmax, off, 64); cmax = o > cmax ? o : cmax; }
+      uint32_t cmax = c;  // the longer of the wave's two segments: the wave's trip count
+      { const uint32_t o = __shfl_xor(cmax, 32, 64); cmax = o > cmax ? o : cmax; }
       cmax = __builtin_amdgcn_readfirstlane(cmax);
       // the keys of the next step are requested before those of this step are looked up
       uint64_t next[U];
       auto request = [&](uint32_t i0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const uint32_t j = i0 + (uint32_t)u * 16u + sub;
+          const uint32_t j = i0 + (uint32_t)u * LPS + sub;
           next[u] = __builtin_nontemporal_load((WcWordPtr)(uint64_t)(s + (j < c ? j : 0u)));
         }
       };
       if (cmax) request(0);
-      for (uint32_t i0 = 0; i0 < cmax; i0 += 16 * U) {
+      for (uint32_t i0 = 0; i0 < cmax; i0 += LPS * U) {
         uint64_t key[U];
         bool in[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           key[u] = next[u];
-          in[u] = i0 + (uint32_t)u * 16u + sub < c;
+          in[u] = i0 + (uint32_t)u * LPS + sub < c;
         }
-        if (i0 + 16 * U < cmax) request(i0 + 16 * U);
+        if (i0 + LPS * U < cmax) request(i0 + LPS * U);
         // the first home bucket of all the step's rows is read before any is looked at, and the
         // claims of the new keys among them go out together: the LDS round trips overlap
         ulonglong2 c1[U];
@@ -509,25 +558,7 @@ __global__ __launch_bounds__(kWcBlock) void k_wc_agg(AggParams p, WcParams w) {
     }
     __syncthreads();
   }
-}
-
-__global__ __launch_bounds__(kWcBlock) void k_wc_hot_emit(WcParams w) {
-  const uint32_t i = threadIdx.x, lane = i & 63u;
-  const unsigned long long k = i < kWcHotSlots ? w.hot_keys[i] : kWcEmpty;
-  const unsigned long long c = i < kWcHotSlots ? w.hot_count[i] : 0ull;
-  const bool occ = k != kWcEmpty && c != 0ull;
-  const uint64_t m = __ballot(occ);
-  unsigned long long wave_first = 0;
-  if (lane == 0 && m) wave_first = atomicAdd(w.list_cursor, (unsigned long long)__popcll(m));
-  wave_first = __shfl(wave_first, 0);
-  if (!occ) return;
-  const uint64_t at = wave_first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-  if (at < w.list_capacity) {
-    w.list_keys[at] = k;
-    w.list_state[at] = (long long)c;
-  } else {
-    w.flags[0] = 1u;
-  }
+  if (blockIdx.x == 0) wc_hot_emit(w);
 }
 
 void wc_allow_lds(const void* k, size_t bytes) {
@@ -577,8 +608,6 @@ void launch_wc_group_by(prism_gpu_ctx* ctx, const AggParams& p, const WcParams& 
     wc_allow_lds((const void*)k_wc_agg, lds);
     const uint32_t grid = std::min<uint32_t>(kWcBuckets, (uint32_t)ctx->n_cus);
     k_wc_agg<<<dim3(grid), dim3(kWcBlock), lds, ctx->stream>>>(p, w);
-    PRISM_HIP(hipGetLastError());
-    k_wc_hot_emit<<<dim3(1), dim3(kWcBlock), 0, ctx->stream>>>(w);
     PRISM_HIP(hipGetLastError());
   }
 }
