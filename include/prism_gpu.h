@@ -208,6 +208,9 @@ void prism_gpu_ctx_free(prism_gpu_ctx* ctx);
  *                    histogram pass; 1 (default): without one (hot keys counted in LDS, fixed
  *                    segments per workgroup and bucket), falling back when a segment overflows
  *   "part_wc_min_rows" fewer selected rows never take that path (default 8388608)
+ *   "part2_fixed"    0: the second partition level of COUNT(DISTINCT) always counts the rows of its
+ *                    fine buckets first; 1 (default): fine buckets get regions of fixed size, and the counting
+ *                    pass only runs when one overflows
  *   "part2_compact"  0: COUNT(DISTINCT) partitioned twice always keeps two-word records at the
  *                    second level; 1 (default): one-word records when the pairs allow it
  *   "contains_windows" 0: LIKE '%needle%' over a column without a dictionary always uses the

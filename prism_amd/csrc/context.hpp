@@ -70,6 +70,7 @@ struct prism_gpu_ctx {
   std::atomic<int> part_half_blocks{1};              // 0: the scatter pass of a partitioned GROUP BY always runs one 1024-thread workgroup per CU
   std::atomic<int> part_wc{1};                       // 0: GROUP BY key -> COUNT(*) never takes the histogram-free path
   std::atomic<uint64_t> part_wc_min_rows{1ull << 23};  // fewer selected rows: the path with the histogram
+  std::atomic<int> part2_fixed{1};                   // 0: the second partition level of COUNT(DISTINCT) always runs its histogram pass
   std::atomic<int> part2_compact{1};                 // 0: the second partition level of COUNT(DISTINCT) always keeps two-word records
   std::atomic<int> contains_windows{1};              // 0: substring search always by the byte-wise prefilter
   std::atomic<int> sharded_fail_phase{0};            // tests: prism_gpu_execute_sharded fails on purpose in this local phase (1..5) on this context's rank

@@ -142,6 +142,7 @@ struct prism_gpu_plan {
   // COUNT(DISTINCT) partitioned twice: distinct pairs per 1024 rows of the last run (0: not run yet);
   // rows that repeat a pair need no entry of the LDS sets, so fine buckets may hold more rows
   std::atomic<uint32_t> distinct_pairs_per_1024{0};
+  std::atomic<int> part2_fixed{0};  // -1: a fine bucket of this plan's data outgrew its fixed region: the second level keeps its histogram
 };
 
 // One streaming partition (ExecutionPlan::execute(partition) on a thread of its own).  It

@@ -1512,7 +1512,6 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggPar
       d_items(ctx, (size_t)q1.max_items * sizeof(PartItem)), d_small(ctx, 256);
   for (int w = 0; w < 2; ++w) {
     rec[w] = Scratch(ctx, selected * 8 + 256);
-    if (w == 0 || !compact) rec2[w] = Scratch(ctx, selected * 8 + 256);
     q1.rec[w] = rec[w].as<uint64_t>();
   }
   q1.hist = d_hist.as<uint32_t>();
@@ -1529,42 +1528,64 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggPar
   launch_partitioned_group_by(ctx, ap, q1, false, selected * key_bytes, selected * (key_bytes + 16), 0, true);
 
   const uint32_t n_fine = 1u << (p1 + p2);
-  Scratch d_fine(ctx, (size_t)n_fine * 12 + 64);
-  PRISM_HIP(hipMemsetAsync(d_fine.p, 0, (size_t)n_fine * 4, ctx->stream));
-  distinct_outer_alloc(ctx, layout, selected, outer);
-  Part2Params q2;
-  std::memset(&q2, 0, sizeof(q2));
-  q2.in_lo = rec[0].as<uint64_t>();
-  q2.in_hi = rec[1].as<uint64_t>();
-  q2.out_lo = rec2[0].as<uint64_t>();
-  q2.out_hi = compact ? nullptr : rec2[1].as<uint64_t>();
-  q2.compact = compact ? 1 : 0;
-  q2.lo_bits = lo_bits;
-  q2.hi_bits = hi_bits;
-  q2.coarse_base = q1.bucket_base;
-  q2.p1_bits = (uint32_t)p1;
-  q2.p2_bits = (uint32_t)p2;
-  q2.n_rows = selected;
-  q2.slice_rows = 1u << 16;
-  q2.fine_count = d_fine.as<uint32_t>();
-  q2.fine_cursor = d_fine.as<uint32_t>() + n_fine;
-  q2.fine_base = d_fine.as<uint32_t>() + 2 * (size_t)n_fine;
-  q2.lds_entries = set_entries;
-  q2.x_null_bit = layout.fields[0].null_bit;
-  q2.dense = outer.dense ? 1 : 0;
-  q2.capacity = outer.capacity;
-  q2.g_keys = outer.keys.as<uint64_t>();
-  q2.g_state = outer.state.as<int64_t>();
-  q2.overflow = outer.overflow.as<uint32_t>();
-  q2.queue = (uint32_t*)(d_small.as<uint8_t>() + 32);
-  q2.flags = (uint32_t*)(d_small.as<uint8_t>() + 40);
-  q2.pairs = compact ? (unsigned long long*)(d_small.as<uint8_t>() + 64) : nullptr;  // [64, 128) of the block
-  launch_distinct_second_level(ctx, q2);
+  // The fine buckets get regions of fixed size (no histogram pass over the records) unless
+  // this plan's data overflowed one before, or the padded array would pass 2^32 records.
+  const uint64_t fixed_capacity = part2_fixed_capacity(selected, n_fine);
+  bool fixed = ctx->part2_fixed.load(std::memory_order_relaxed) != 0 && plan->part2_fixed.load(std::memory_order_relaxed) >= 0 &&
+               fixed_capacity < (1ull << 32);
+  for (int w = 0; w < 2; ++w)
+    if (w == 0 || !compact) rec2[w] = Scratch(ctx, (fixed ? fixed_capacity : selected) * 8 + 256);
+  Scratch d_fine(ctx, (size_t)n_fine * 16 + 64);
   struct { uint32_t flags[2]; uint64_t pad[2]; unsigned long long pairs[8]; } h{};
   static_assert(sizeof(h) == 88, "layout of the small block from offset 40 on");
-  PRISM_HIP(hipMemcpyAsync(&h, q2.flags, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-  PRISM_HIP(hipStreamSynchronize(ctx->stream));
-  collect_timings(ctx);
+  for (;;) {
+    PRISM_HIP(hipMemsetAsync(d_fine.p, 0, (size_t)n_fine * 4, ctx->stream));
+    PRISM_HIP(hipMemsetAsync(d_small.as<uint8_t>() + 32, 0, 224, ctx->stream));
+    distinct_outer_alloc(ctx, layout, selected, outer);
+    Part2Params q2;
+    std::memset(&q2, 0, sizeof(q2));
+    q2.in_lo = rec[0].as<uint64_t>();
+    q2.in_hi = rec[1].as<uint64_t>();
+    q2.out_lo = rec2[0].as<uint64_t>();
+    q2.out_hi = compact ? nullptr : rec2[1].as<uint64_t>();
+    q2.out_capacity = fixed ? fixed_capacity : selected;
+    q2.compact = compact ? 1 : 0;
+    q2.lo_bits = lo_bits;
+    q2.hi_bits = hi_bits;
+    q2.coarse_base = q1.bucket_base;
+    q2.p1_bits = (uint32_t)p1;
+    q2.p2_bits = (uint32_t)p2;
+    q2.n_rows = selected;
+    q2.slice_rows = 1u << 16;
+    q2.fine_count = d_fine.as<uint32_t>();
+    q2.fine_cursor = d_fine.as<uint32_t>() + n_fine;
+    q2.fine_base = d_fine.as<uint32_t>() + 2 * (size_t)n_fine;
+    q2.fine_limit = fixed ? d_fine.as<uint32_t>() + 3 * (size_t)n_fine + 1 : nullptr;
+    q2.lds_entries = set_entries;
+    q2.x_null_bit = layout.fields[0].null_bit;
+    q2.dense = outer.dense ? 1 : 0;
+    q2.capacity = outer.capacity;
+    q2.g_keys = outer.keys.as<uint64_t>();
+    q2.g_state = outer.state.as<int64_t>();
+    q2.overflow = outer.overflow.as<uint32_t>();
+    q2.queue = (uint32_t*)(d_small.as<uint8_t>() + 32);
+    q2.flags = (uint32_t*)(d_small.as<uint8_t>() + 40);
+    q2.pairs = compact ? (unsigned long long*)(d_small.as<uint8_t>() + 64) : nullptr;  // [64, 128) of the block
+    launch_distinct_second_level(ctx, q2);
+    PRISM_HIP(hipMemcpyAsync(&h, q2.flags, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    PRISM_HIP(hipStreamSynchronize(ctx->stream));
+    collect_timings(ctx);
+    if (std::getenv("PRISM_WC_DEBUG"))
+      std::fprintf(stderr, "[part2] p1 %d p2 %d compact %d fixed %d rows %llu: flags %u %u\n", p1, p2, (int)compact, (int)fixed,
+                   (unsigned long long)selected, h.flags[0], h.flags[1]);
+    if (fixed && h.flags[1] != 0) {
+      // a fine bucket outgrew its region (few distinct values that repeat a lot): exact places from now on
+      plan->part2_fixed.store(-1, std::memory_order_relaxed);
+      fixed = false;
+      continue;
+    }
+    break;
+  }
   if (h.flags[0] != 0 || table_overflowed(ctx, outer)) {
     outer = GroupTable();
     return false;

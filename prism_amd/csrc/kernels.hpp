@@ -325,6 +325,10 @@ struct Part2Params {
   uint32_t* fine_count;         // [n_fine], zero on entry
   uint32_t* fine_base;          // [n_fine + 1]
   uint32_t* fine_cursor;        // [n_fine]
+  uint32_t* fine_limit;         // [n_fine] or null.  Set: no histogram pass; fine bucket f owns the fixed region
+                                // [fine_base[f], fine_limit[f]) (laid out by the library from the coarse buckets' sizes) and holds
+                                // the records up to fine_cursor[f]; a bucket that outgrows its region sets flags[1]
+  uint64_t out_capacity;        // records out_lo / out_hi hold
   uint32_t lds_entries;         // entries of the pair table in LDS (a fine bucket may hold half as many rows)
   int32_t x_null_bit;           // bit of the low word that marks a NULL x, -1: none
   int32_t dense;                // the outer table
@@ -333,7 +337,7 @@ struct Part2Params {
   int64_t* g_state;
   uint32_t* overflow;
   uint32_t* queue;              // next fine bucket of the last pass (zero on entry)
-  uint32_t* flags;              // [0]: a fine bucket did not fit LDS (the result is void)
+  uint32_t* flags;              // [0]: a fine bucket did not fit LDS (the result is void), [1]: a fixed region overflowed (the same)
   // compact: both bucket numbers are top bits of bijections (coarse: of the high word's
   // hi_bits bits, sub: of the low word's lo_bits bits), and a record sorted into its fine
   // bucket is ONE word, the bits the bucket does not imply: (high rest << (lo_bits - p2_bits))
@@ -343,6 +347,8 @@ struct Part2Params {
   unsigned long long* pairs;    // [8] (one-word records): distinct pairs counted, as eight partial sums; may be null
 };
 uint32_t part2_lds_entries(bool compact);
+// Records the output arrays must hold when the fine buckets get regions of fixed size.
+uint64_t part2_fixed_capacity(uint64_t n_rows, uint32_t n_fine);
 void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q);
 
 // Second level of COUNT(DISTINCT x) GROUP BY k: every occupied entry of the

@@ -124,6 +124,28 @@ __global__ __launch_bounds__(1024) void k_part2_scan(Part2Params q, uint32_t n_f
   if (threadIdx.x == 0) q.fine_base[n_fine] = carry;
 }
 
+// The second level without its histogram: every fine bucket gets a region of fixed size --
+// twice its even share of the coarse bucket's rows, plus a margin (one frequent pair can be
+// half a fine bucket's rows) -- instead of its exact place.  The bucket numbers are top bits of mixed words, so the fine buckets of a
+// coarse bucket are close to even unless few distinct values repeat a lot; a bucket that
+// outgrows its region sets flags[1], its surplus rows are dropped, and the caller runs the
+// level again with the histogram.  Saves a pass over the records (16 bytes a row).
+constexpr uint32_t kP2Margin = 48;
+__global__ __launch_bounds__(256) void k_part2_layout(Part2Params q, uint32_t n_fine) {
+  const uint32_t f = blockIdx.x * 256 + threadIdx.x;
+  if (f > n_fine) return;
+  const uint32_t n_sub = 1u << q.p2_bits;
+  auto coarse_start = [&](uint32_t c) { return 2 * q.coarse_base[c] + (uint64_t)c * kP2Margin * n_sub; };
+  if (f == n_fine) { q.fine_base[f] = (uint32_t)coarse_start(1u << q.p1_bits); return; }
+  const uint32_t c = f >> q.p2_bits, sub = f & (n_sub - 1);
+  const uint64_t rows = q.coarse_base[c + 1] - q.coarse_base[c];
+  const uint64_t cap = (((2 * rows) >> q.p2_bits) + kP2Margin) & ~15ull;
+  const uint32_t at = (uint32_t)(coarse_start(c) + sub * cap);
+  q.fine_base[f] = at;
+  q.fine_cursor[f] = at;
+  q.fine_limit[f] = (uint32_t)(at + cap);
+}
+
 // Exclusive scan of n (<= 2 * kP2Block, even) LDS counters in place; a[n] receives the total.
 __device__ __forceinline__ void p2_block_scan(uint32_t* a, uint32_t n, uint32_t* wave_tot) {
   const uint32_t t = threadIdx.x, i0 = 2 * t;
@@ -193,8 +215,10 @@ __global__ __launch_bounds__(kP2Block) void k_part2_scatter(Part2Params q) {
         where[r] = li | (atomicAdd(&cnt[li], 1u) << 12);
       } else {
         // beyond the coarse buckets the counters cover: a place of its own
-        const uint32_t g = atomicAdd(&q.fine_cursor[((uint64_t)c << q.p2_bits) | s], 1u);
-        if (g < q.n_rows) {
+        const uint64_t ff = ((uint64_t)c << q.p2_bits) | s;
+        const uint32_t g = atomicAdd(&q.fine_cursor[ff], 1u);
+        if (q.fine_limit && g >= q.fine_limit[ff]) q.flags[1] = 1u;
+        else if (g < q.out_capacity) {
           if (q.compact) {
             const int lo_rest = q.lo_bits - (int)q.p2_bits, hi_rest = q.hi_bits - (int)q.p1_bits;
             q.out_lo[g] = ((hi[r] & ((1ull << hi_rest) - 1ull)) << lo_rest) | (lo[r] & ((1ull << lo_rest) - 1ull));
@@ -209,7 +233,14 @@ __global__ __launch_bounds__(kP2Block) void k_part2_scatter(Part2Params q) {
     for (uint32_t i = threadIdx.x; i < kP2Counters; i += kP2Block) {
       const uint32_t c = c0 + i / n_sub;
       lstart[i] = i < n_cnt ? cnt[i] : 0u;
-      base[i] = (i < n_cnt && cnt[i] && c < n_coarse) ? atomicAdd(&q.fine_cursor[((uint64_t)c << q.p2_bits) | (i % n_sub)], cnt[i]) : 0u;
+      uint32_t at = 0u;
+      if (i < n_cnt && cnt[i] && c < n_coarse) {
+        const uint64_t ff = ((uint64_t)c << q.p2_bits) | (i % n_sub);
+        at = atomicAdd(&q.fine_cursor[ff], cnt[i]);
+        // (regions of fixed size: a run that does not fit its bucket's region is dropped as a whole)
+        if (q.fine_limit && (uint64_t)at + cnt[i] > q.fine_limit[ff]) { q.flags[1] = 1u; at = ~0u; }
+      }
+      base[i] = at;
     }
     __syncthreads();
     p2_block_scan(lstart, kP2Counters, wave_tot);
@@ -229,14 +260,14 @@ __global__ __launch_bounds__(kP2Block) void k_part2_scatter(Part2Params q) {
         const uint64_t tl = s_lo[i], th = s_hi[i];  // (staged mixed)
         const uint32_t li = ((uint32_t)(th >> hi_rest) - c0) * n_sub + (uint32_t)(tl >> lo_rest);
         const uint32_t g = base[li] + (i - lstart[li]);
-        if (g < q.n_rows) q.out_lo[g] = ((th & ((1ull << hi_rest) - 1ull)) << lo_rest) | (tl & ((1ull << lo_rest) - 1ull));
+        if (base[li] != ~0u && g < q.out_capacity) q.out_lo[g] = ((th & ((1ull << hi_rest) - 1ull)) << lo_rest) | (tl & ((1ull << lo_rest) - 1ull));
       }
     } else {
       for (uint32_t i = threadIdx.x; i < n_live; i += kP2Block) {
         const unsigned long long w0 = s_lo[i], w1 = s_hi[i];
         const uint32_t li = (coarse_of(q, w1) - c0) * n_sub + sub_of(q, w0, w1);
         const uint32_t g = base[li] + (i - lstart[li]);
-        if (g < q.n_rows) {
+        if (base[li] != ~0u && g < q.out_capacity) {
           q.out_lo[g] = w0;
           q.out_hi[g] = w1;
         }
@@ -244,6 +275,14 @@ __global__ __launch_bounds__(kP2Block) void k_part2_scatter(Part2Params q) {
     }
     __syncthreads();
   }
+}
+
+// One past the last record of fine bucket f: where the next bucket starts, or (regions of fixed
+// size) as far as the scatter pass' cursor got.
+__device__ __forceinline__ uint32_t p2_bucket_end(const Part2Params& q, uint32_t f) {
+  if (!q.fine_limit) return q.fine_base[f + 1];
+  const uint32_t end = q.fine_cursor[f], lim = q.fine_limit[f];
+  return end < lim ? end : lim;
 }
 
 // Puts the pair into the LDS set unless it is there: 1 = it was new, 0 = it was there, -1 = the
@@ -288,7 +327,7 @@ __global__ __launch_bounds__(kP2AggBlock) void k_part2_agg(Part2Params q, uint32
   // out would put a device-scope atomic and a barrier in front of every one of them
   for (uint32_t f = blockIdx.x; f < n_fine; f += gridDim.x) {
     __syncthreads();
-    const uint32_t b0 = q.fine_base[f], b1 = q.fine_base[f + 1];
+    const uint32_t b0 = q.fine_base[f], b1 = p2_bucket_end(q, f);
     if (b1 == b0) continue;
     // A fine bucket of more rows than the set is sure to take (the coarse bucket of a very
     // frequent group) is worked off in several passes over its rows, each taking the pairs of
@@ -388,7 +427,7 @@ __global__ __launch_bounds__(kP2AggBlock) void k_part2_agg_compact(Part2Params q
   for (uint32_t i = tid; i < kP2Groups; i += kP2AggBlock) gcnt[i] = 0;
   for (uint32_t f = blockIdx.x; f < n_fine; f += gridDim.x) {
     __syncthreads();
-    const uint32_t b0 = q.fine_base[f], b1 = q.fine_base[f + 1];
+    const uint32_t b0 = q.fine_base[f], b1 = p2_bucket_end(q, f);
     if (b1 == b0) continue;
     const uint32_t n = b1 - b0;
     constexpr uint32_t kBatch = 8;  // a thread's first rows, requested together and kept for all the passes
@@ -508,6 +547,8 @@ __global__ __launch_bounds__(kP2AggBlock) void k_part2_agg_compact(Part2Params q
 
 }  // namespace
 
+uint64_t part2_fixed_capacity(uint64_t n_rows, uint32_t n_fine) { return 2 * n_rows + (uint64_t)kP2Margin * n_fine + 64; }
+
 uint32_t part2_lds_entries(bool compact) {
   // a workgroup's share of the LDS next to its static arrays (group counters), in 16-byte
   // pairs or (compact form) 8-byte records
@@ -523,8 +564,14 @@ void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q) {
   if (q.compact && (q.hi_bits < (int)q.p1_bits || q.hi_bits - (int)q.p1_bits > 9 || q.lo_bits < (int)q.p2_bits || q.lo_bits > 63 ||
                     q.lo_bits - (int)q.p2_bits + q.hi_bits - (int)q.p1_bits > 63 || q.x_null_bit >= 0))
     fail(PRISM_GPU_EINTERNAL, "bad shape for one-word records");
+  if (q.fine_limit ? (q.out_capacity < part2_fixed_capacity(q.n_rows, n_fine) || q.out_capacity >= (1ull << 32)) : q.out_capacity < q.n_rows)
+    fail(PRISM_GPU_EINTERNAL, "the second partition level's output array is too short");
   const uint32_t slices = (uint32_t)ceil_div(q.n_rows, q.slice_rows);
-  {
+  if (q.fine_limit) {
+    KernelTimer timer(ctx, "part2_layout", 0);
+    k_part2_layout<<<dim3((uint32_t)ceil_div(n_fine + 1, 256)), dim3(256), 0, ctx->stream>>>(q, n_fine);
+    PRISM_HIP(hipGetLastError());
+  } else {
     KernelTimer timer(ctx, "part2_hist", q.n_rows * 16);
     k_part2_hist<<<dim3(slices), dim3(kP2Block), 0, ctx->stream>>>(q);
     PRISM_HIP(hipGetLastError());

@@ -205,14 +205,20 @@ def test_count_distinct_partitioned_twice(part_ctx, oracle):
     # records of one word at the second level (the bits their fine bucket does not imply:
     # 63-bit ids without NULLs next to a 12-bit group key allow it), then of two words
     rows = 1_500_000
-    for compact, record_bytes in ((1, 8), (0, 16)):
+    # (and both ways of placing the fine buckets: regions of fixed size, the default, and exact
+    # places from a histogram pass over the records)
+    for compact, record_bytes, fixed in ((1, 8, 1), (0, 16, 1), (1, 8, 0), (0, 16, 0)):
         part_ctx.set_option("part2_compact", compact)
+        part_ctx.set_option("part2_fixed", fixed)
         part_ctx.reset_stats()
         _synth_both(part_ctx, oracle, wl, rows, 4, [(wl.query, 2)])
-        assert {"part2_hist", "part2_scatter", "part2_agg"} <= _kernels(part_ctx)
+        ran = _kernels(part_ctx)
+        assert {"part2_layout" if fixed else "part2_hist", "part2_scatter", "part2_agg"} <= ran
+        assert ("part2_hist" in ran) == (not fixed)
         agg = part_ctx.stats()["kernels"]["part2_agg"]
         assert agg["algorithmic_bytes"] == agg["launches"] * rows * record_bytes
     part_ctx.set_option("part2_compact", 1)
+    part_ctx.set_option("part2_fixed", 1)
 
     rng = np.random.default_rng(21)
     n = 300_000
@@ -267,7 +273,11 @@ def test_count_distinct_of_one_dominant_group(part_ctx, oracle):
                 part_ctx.reset_stats()
                 got = plan.execute(g)
                 agg = part_ctx.stats()["kernels"]["part2_agg"]
-                assert agg["launches"] == 1 and agg["algorithmic_bytes"] == n * 8  # one-word records
+                # one-word records.  (300 values that repeat a lot make very uneven fine buckets: the
+                # regions of fixed size overflow, and the level runs again with its histogram)
+                assert agg["launches"] == (2 if distinct_values == 300 else 1)
+                assert agg["algorithmic_bytes"] == agg["launches"] * n * 8
+                assert ("part2_hist" in _kernels(part_ctx)) == (distinct_values == 300)
                 # (the plan has learnt what share of the rows are distinct pairs: with few of
                 # them the second run makes its fine buckets up to four times as large)
                 again = plan.execute(g)
