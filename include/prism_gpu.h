@@ -216,6 +216,9 @@ void prism_gpu_ctx_free(prism_gpu_ctx* ctx);
  *   "contains_windows" 0: LIKE '%needle%' over a column without a dictionary always uses the
  *                    byte-wise prefilter; 1 (default): needles of 4 bytes and more are found by
  *                    comparing 4-byte windows with the needle's leading words
+ *   "shard_distinct" 0: prism_gpu_execute_sharded always builds a COUNT(DISTINCT)'s set of pairs as a
+ *                    hash table in HBM before the exchange; 1 (default): over 2^24 rows and more the
+ *                    pairs are partitioned twice, as on one GPU, and the buckets' distinct records travel
  *   "sharded_fail_phase" tests only: this context's rank fails on purpose in the given local
  *                    phase (1..5) of prism_gpu_execute_sharded (default 0: never)
  * Unknown names are PRISM_GPU_EINVAL. */

@@ -315,6 +315,69 @@ void maybe_fail(prism_gpu_ctx* ctx, int phase) {
     fail(PRISM_GPU_EINTERNAL, "failure injected in phase " + std::to_string(phase) + " of the sharded execution");
 }
 
+// The exchange of a sharded COUNT(DISTINCT) (every rank holds the distinct records of its
+// fine buckets: state_shard): fine bucket (c, sub) belongs to rank c % world; the records are
+// laid out owner by owner, the buckets' counts and the records travel in one all-to-all each,
+// and the owner counts the union of the runs it received per group.  Returns the owner's state
+// (pairs counted per group), or null when this rank failed on the way (`status` says how; the
+// caller's next agreement makes that everybody's error).
+prism_gpu_state* exchange_distinct_shard(prism_gpu_comm* c, LocalStatus& status, prism_gpu_state* local, prism_gpu_ctx* ctx) {
+  const int world = c->world, rank = c->rank;
+  DistinctShard* sh = state_shard(local);
+  if (!sh) fail(PRISM_GPU_EINTERNAL, "no distinct records to exchange");
+  const uint32_t n_fine = sh->n_fine, n_sub = 1u << sh->p2, n_coarse = 1u << sh->p1;
+  auto n_own_of = [&](int o) { return (uint64_t)(n_coarse / (uint32_t)world + ((uint32_t)o < n_coarse % (uint32_t)world ? 1u : 0u)) * n_sub; };
+  std::vector<uint64_t> block_start(world + 1, 0), cnt_send(world), cnt_recv(world);
+  for (int o = 0; o < world; ++o) block_start[o + 1] = block_start[o] + n_own_of(o);
+  const uint64_t n_own = n_own_of(rank);
+  for (int o = 0; o < world; ++o) { cnt_send[o] = n_own_of(o); cnt_recv[o] = n_own; }
+  Scratch counts64, offsets, send;
+  std::vector<uint64_t> send_counts(world, 0);
+  uint64_t send_total = 0;
+  status.run([&] {
+    counts64 = Scratch(ctx, (size_t)n_fine * 8 + 8);
+    offsets = Scratch(ctx, ((size_t)n_fine + 1) * 8);
+    launch_shard_counts(ctx, sh->fine_count, counts64.as<unsigned long long>(), n_fine, (uint32_t)sh->p1, (uint32_t)sh->p2, (uint32_t)world);
+    launch_scan_u64(ctx, counts64.as<unsigned long long>(), offsets.as<unsigned long long>(), n_fine);
+    std::vector<uint64_t> edge(world + 1, 0);
+    for (int o = 0; o <= world; ++o)
+      PRISM_HIP(hipMemcpyAsync(&edge[o], offsets.as<uint64_t>() + block_start[o], 8, hipMemcpyDeviceToHost, ctx->stream));
+    PRISM_HIP(hipStreamSynchronize(ctx->stream));
+    for (int o = 0; o < world; ++o) send_counts[o] = edge[o + 1] - edge[o];
+    send_total = edge[world];
+    send = Scratch(ctx, std::max<uint64_t>(1, send_total) * 8);
+    launch_shard_gather(ctx, sh->records.as<unsigned long long>(), sh->fine_base, sh->fine_count, offsets.as<unsigned long long>(),
+                        send.as<unsigned long long>(), n_fine, (uint32_t)sh->p1, (uint32_t)sh->p2, (uint32_t)world);
+    PRISM_HIP(hipStreamSynchronize(ctx->stream));
+    collect_timings(ctx);
+  });
+  // who sends how many records to whom
+  std::vector<uint64_t> recv_counts(world, 0), roff(world + 1, 0);
+  {
+    const std::vector<int64_t> all = agree(c, status, (const int64_t*)send_counts.data(), (size_t)world, "while it dealt its distinct records to their owners");
+    for (int s = 0; s < world; ++s) recv_counts[s] = (uint64_t)all[(size_t)s * (world + 1) + 1 + rank];
+  }
+  for (int s = 0; s < world; ++s) roff[s + 1] = roff[s] + recv_counts[s];
+  const uint64_t recv_total = roff[world];
+  Scratch recv_cnt64, recv;
+  status.run([&] {
+    if (recv_total >= (1ull << 32)) fail(PRISM_GPU_EUNSUPPORTED, "more than 2^32 distinct records meet on one rank");
+    recv_cnt64 = Scratch(ctx, (size_t)world * std::max<uint64_t>(1, n_own) * 8);
+    recv = Scratch(ctx, std::max<uint64_t>(1, recv_total) * 8);
+    maybe_fail(ctx, 3);
+  });
+  agree(c, status, nullptr, 0, "before the all-to-all of its distinct records");
+  alltoallv_columns(c, 1, counts64.as<uint64_t>(), n_fine, cnt_send, recv_cnt64.as<uint64_t>(), (uint64_t)world * n_own, cnt_recv);
+  alltoallv_columns(c, 1, send.as<uint64_t>(), send_total, send_counts, recv.as<uint64_t>(), recv_total, recv_counts);
+  PRISM_HIP(hipStreamSynchronize(ctx->stream));
+  send.reset();
+  prism_gpu_state* merged = nullptr;
+  status.run([&] {
+    merged = distinct_shard_merge(local, recv.as<uint64_t>(), recv_total, recv_cnt64.as<uint64_t>(), roff.data(), (uint32_t)n_own, world, rank);
+  });
+  return merged;
+}
+
 int execute_sharded_impl(prism_gpu_comm* c, prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids,
                          size_t n_partitions, int root, ArrowArray* out) {
   prism_gpu_ctx* ctx = c->ctx;
@@ -328,7 +391,7 @@ int execute_sharded_impl(prism_gpu_comm* c, prism_gpu_plan* plan, prism_gpu_tabl
   for (const KeyPlan& k : plan->keys)
     if (plan->fields[k.column].is_string) coded.push_back(k.column);
   if (plan->distinct_plan && plan->distinct_col >= 0 && plan->fields[plan->distinct_col].is_string) coded.push_back(plan->distinct_col);
-  const size_t vec_n = n_cols * 3 + coded.size();
+  const size_t vec_n = n_cols * 3 + coded.size() + 1;  // (the last word: the rows this rank scans)
   std::vector<prism_gpu_col_stats> mine(n_cols), agreed(n_cols);
   std::vector<int64_t> vec(vec_n, 0);
   LocalStatus status;
@@ -345,8 +408,19 @@ int execute_sharded_impl(prism_gpu_comm* c, prism_gpu_plan* plan, prism_gpu_tabl
       table_dictionary_digest(table, coded[i], &digest, &n_values);
       vec[n_cols * 3 + i] = (int64_t)digest;
     }
+    {
+      std::lock_guard<std::mutex> g(table->mu);
+      uint64_t rows = 0;
+      for (const Chunk& ch : table->chunks) {
+        bool in = partition_ids == nullptr || n_partitions == 0;
+        for (size_t k = 0; k < n_partitions && !in; ++k) in = partition_ids[k] == ch.partition_id;
+        if (in) rows += ch.rows;
+      }
+      vec[vec_n - 1] = (int64_t)rows;
+    }
     maybe_fail(ctx, 1);
   });
+  uint64_t max_rows = 0;
   {
     const std::vector<int64_t> all = agree(c, status, vec.data(), vec_n, "while it collected its column statistics");
     const size_t stride = vec_n + 1;
@@ -360,6 +434,7 @@ int execute_sharded_impl(prism_gpu_comm* c, prism_gpu_plan* plan, prism_gpu_tabl
         agreed[i].nulls += (uint64_t)v[2];
       }
     }
+    for (int r = 0; r < world; ++r) max_rows = std::max<uint64_t>(max_rows, (uint64_t)all[(size_t)r * stride + vec_n]);
     // (every rank sees the same digests, so every rank takes this exit or none does)
     for (size_t i = 0; i < coded.size(); ++i)
       for (int r = 1; r < world; ++r)
@@ -369,19 +444,55 @@ int execute_sharded_impl(prism_gpu_comm* c, prism_gpu_plan* plan, prism_gpu_tabl
   }
 
   // ---- 2. this rank's share ----
-  StateGuard local;
-  status.run([&] {
-    local.st = aggregate_state(plan, table, partition_ids, n_partitions, agreed.data());
-    maybe_fail(ctx, 2);
-  });
-  const auto t0 = std::chrono::steady_clock::now();
+  auto t0 = std::chrono::steady_clock::now();
   auto done = [&](int has) {
     std::lock_guard<std::mutex> g(c->mu);
     c->stats.exchange_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return has;
   };
+  if (world == 1 && plan->distinct_plan) {
+    // one rank: nothing to exchange, and the pairs need no set in HBM
+    execute_plan(plan, table, partition_ids, n_partitions, false, out);
+    t0 = std::chrono::steady_clock::now();
+    return done(1);
+  }
+  StateGuard local;
+  // COUNT(DISTINCT) over many rows: the pairs are partitioned twice on every rank, as on one GPU,
+  // and what travels are the DISTINCT records of the fine buckets, each bucket to the rank that
+  // owns it; the owner counts the union of what it received.  Whether a rank can do its part
+  // depends on the plan, the agreed statistics and the largest scan of any rank -- facts all
+  // ranks share -- but it is only known by trying, so the ranks say how it went and take the
+  // other way together (the set of pairs as a hash table in HBM) if any of them could not.
+  StateGuard shard_work;
+  bool shard_done = false;
+  if (plan->distinct_plan && ctx->shard_distinct.load(std::memory_order_relaxed) != 0 &&
+      max_rows >= (ctx->part_force.load(std::memory_order_relaxed) != 0 ? 1ull : (1ull << 24))) {
+    LocalStatus tried;
+    DistinctShardRequest req{max_rows};
+    tried.run([&] { local.st = aggregate_state(plan, table, partition_ids, n_partitions, agreed.data(), &req); });
+    const int64_t ok = tried.code == 0 ? 1 : 0;
+    const std::vector<int64_t> all = agree(c, status, &ok, 1, "while it collected its column statistics");
+    bool all_ok = true;
+    for (int r = 0; r < world; ++r) all_ok = all_ok && all[(size_t)r * 2 + 1] == 1;
+    if (all_ok) {
+      t0 = std::chrono::steady_clock::now();
+      status.run([&] { maybe_fail(ctx, 2); });
+      shard_work.st = exchange_distinct_shard(c, status, local.st, ctx);
+      shard_done = true;
+    } else {
+      state_free(local.st);
+      local.st = nullptr;
+    }
+  }
+  if (!shard_done) {
+    status.run([&] {
+      local.st = aggregate_state(plan, table, partition_ids, n_partitions, agreed.data());
+      maybe_fail(ctx, 2);
+    });
+    t0 = std::chrono::steady_clock::now();
+  }
   StateView v;
-  status.run([&] { v = state_view(local.st); });
+  if (!shard_done) status.run([&] { v = state_view(local.st); });
   if (world == 1) {
     if (status.code) fail(status.code, status.msg);
     state_finish(local.st, out);
@@ -397,7 +508,7 @@ int execute_sharded_impl(prism_gpu_comm* c, prism_gpu_plan* plan, prism_gpu_tabl
   const int width = status.code ? 0 : 1 + (two ? 1 : 0) + v.n_slots;
   const uint64_t n = status.code ? 0 : v.entries;
   uint64_t* send_keys = nullptr;
-  if (!status.code && !v.dense) {
+  if (!shard_done && !status.code && !v.dense) {
     // ---- 3b. large key space: rows to their owners, merge there, the owners' groups to root ----
     // Rows travel in compact column form: keys, high words (two-word keys), one column per slot.
     status.run([&] {
@@ -425,66 +536,75 @@ int execute_sharded_impl(prism_gpu_comm* c, prism_gpu_plan* plan, prism_gpu_tabl
       PRISM_HIP(hipStreamSynchronize(ctx->stream));
     });
   }
-  // who sends how much to whom (all zero from a rank with a dense state); the status of phase 2
-  std::vector<int64_t> counts_all;
-  {
-    const std::vector<int64_t> all = agree(c, status, (const int64_t*)send_counts.data(), (size_t)world, "while it aggregated its partitions");
-    counts_all.resize((size_t)world * world);
-    for (int s = 0; s < world; ++s)
-      std::memcpy(counts_all.data() + (size_t)s * world, all.data() + (size_t)s * (world + 1) + 1, 8 * (size_t)world);
-  }
-  if (v.dense) {
-    for (int s = 0; s < v.n_slots;) {
-      int e = s + 1;
-      const bool f64 = v.slot_ops[s] == kSlotAddF64;
-      while (e < v.n_slots && reduce_of(v.slot_ops[e]) == reduce_of(v.slot_ops[s]) && (v.slot_ops[e] == kSlotAddF64) == f64) ++e;
-      // slot arrays lie dense_stride apart, one spare entry between two: a run of slots is one array
-      const size_t cnt = (size_t)(e - s) * v.dense_stride - (v.dense_stride - v.entries);
-      reduce_device(c, v.dense_state + (uint64_t)s * v.dense_stride, cnt, f64 ? PRISM_REDUCE_F64 : PRISM_REDUCE_I64, reduce_of(v.slot_ops[s]), root);
-      s = e;
-    }
-    PRISM_HIP(hipStreamSynchronize(ctx->stream));
-    if (rank != root) return done(0);
-    state_finish(local.st, out);
-    return done(1);
-  }
-
-  std::vector<uint64_t> recv_counts(world);
-  uint64_t recv_total = 0;
-  for (int s = 0; s < world; ++s) recv_total += recv_counts[s] = (uint64_t)counts_all[(size_t)s * world + rank];
-  // (the receive block is allocated before the collective: a rank that cannot have it must not
-  // leave the others inside the all-to-all, so the allocation's outcome is agreed first)
-  Scratch recv;
-  status.run([&] {
-    recv = Scratch(ctx, std::max<uint64_t>(1, recv_total) * 8 * (uint64_t)width);
-    maybe_fail(ctx, 3);
-  });
-  agree(c, status, nullptr, 0, "before the all-to-all of its group rows");
-  alltoallv_columns(c, width, send_keys, n, send_counts, recv.as<uint64_t>(), recv_total, recv_counts);
-  PRISM_HIP(hipStreamSynchronize(ctx->stream));
-  collect_timings(ctx);
-  send.reset();
-
-  // the owner's table: same key packing, no rows of its own
   StateGuard owned, outer;
   const uint32_t no_partition = 0xFFFFFFFFu;
   prism_gpu_state* work = nullptr;
   StateView w;
-  status.run([&] {
-    owned.st = aggregate_state(plan, table, &no_partition, 1, agreed.data());
-    const uint64_t* rk = recv.as<uint64_t>();
-    state_merge_rows(owned.st, rk, two ? rk + recv_total : nullptr, (const int64_t*)(rk + (two ? 2 : 1) * recv_total), recv_total);
-    recv.reset();
-    // COUNT(DISTINCT): the owner holds every pair of its groups, so it can count them; what goes
-    // on to the root are (group, count) rows of groups no other rank has
-    work = owned.st;
-    if (v.distinct == 1) {
-      outer.st = state_distinct_outer(owned.st);
-      work = outer.st;
+  const bool pairs = shard_done || v.distinct == 1;  // what reaches the root are (group, count) rows of a COUNT(DISTINCT)
+  if (shard_done) {
+    work = shard_work.st;
+    status.run([&] {
+      w = state_view(work);
+      maybe_fail(ctx, 4);
+    });
+  } else {
+    // who sends how much to whom (all zero from a rank with a dense state); the status of phase 2
+    std::vector<int64_t> counts_all;
+    {
+      const std::vector<int64_t> all = agree(c, status, (const int64_t*)send_counts.data(), (size_t)world, "while it aggregated its partitions");
+      counts_all.resize((size_t)world * world);
+      for (int s = 0; s < world; ++s)
+        std::memcpy(counts_all.data() + (size_t)s * world, all.data() + (size_t)s * (world + 1) + 1, 8 * (size_t)world);
     }
-    w = state_view(work);
-    maybe_fail(ctx, 4);
-  });
+    if (v.dense) {
+      for (int s = 0; s < v.n_slots;) {
+        int e = s + 1;
+        const bool f64 = v.slot_ops[s] == kSlotAddF64;
+        while (e < v.n_slots && reduce_of(v.slot_ops[e]) == reduce_of(v.slot_ops[s]) && (v.slot_ops[e] == kSlotAddF64) == f64) ++e;
+        // slot arrays lie dense_stride apart, one spare entry between two: a run of slots is one array
+        const size_t cnt = (size_t)(e - s) * v.dense_stride - (v.dense_stride - v.entries);
+        reduce_device(c, v.dense_state + (uint64_t)s * v.dense_stride, cnt, f64 ? PRISM_REDUCE_F64 : PRISM_REDUCE_I64, reduce_of(v.slot_ops[s]), root);
+        s = e;
+      }
+      PRISM_HIP(hipStreamSynchronize(ctx->stream));
+      if (rank != root) return done(0);
+      state_finish(local.st, out);
+      return done(1);
+    }
+
+    std::vector<uint64_t> recv_counts(world);
+    uint64_t recv_total = 0;
+    for (int s = 0; s < world; ++s) recv_total += recv_counts[s] = (uint64_t)counts_all[(size_t)s * world + rank];
+    // (the receive block is allocated before the collective: a rank that cannot have it must not
+    // leave the others inside the all-to-all, so the allocation's outcome is agreed first)
+    Scratch recv;
+    status.run([&] {
+      recv = Scratch(ctx, std::max<uint64_t>(1, recv_total) * 8 * (uint64_t)width);
+      maybe_fail(ctx, 3);
+    });
+    agree(c, status, nullptr, 0, "before the all-to-all of its group rows");
+    alltoallv_columns(c, width, send_keys, n, send_counts, recv.as<uint64_t>(), recv_total, recv_counts);
+    PRISM_HIP(hipStreamSynchronize(ctx->stream));
+    collect_timings(ctx);
+    send.reset();
+
+    // the owner's table: same key packing, no rows of its own
+    status.run([&] {
+      owned.st = aggregate_state(plan, table, &no_partition, 1, agreed.data());
+      const uint64_t* rk = recv.as<uint64_t>();
+      state_merge_rows(owned.st, rk, two ? rk + recv_total : nullptr, (const int64_t*)(rk + (two ? 2 : 1) * recv_total), recv_total);
+      recv.reset();
+      // COUNT(DISTINCT): the owner holds every pair of its groups, so it can count them; what goes
+      // on to the root are (group, count) rows of groups no other rank has
+      work = owned.st;
+      if (v.distinct == 1) {
+        outer.st = state_distinct_outer(owned.st);
+        work = outer.st;
+      }
+      w = state_view(work);
+      maybe_fail(ctx, 4);
+    });
+  }
   // the owner's groups that can still make the result
   Scratch lead_keys, lead_hi, lead_state;
   int64_t n_lead_i = 0;
@@ -528,7 +648,7 @@ int execute_sharded_impl(prism_gpu_comm* c, prism_gpu_plan* plan, prism_gpu_tabl
   if (rank != root) return done(0);
   // (no collective follows: what fails from here on fails on the root alone, and the others are done)
   StateGuard empty_inner, final_state;
-  if (v.distinct == 1) {
+  if (pairs) {
     empty_inner.st = aggregate_state(plan, table, &no_partition, 1, agreed.data());
     final_state.st = state_distinct_outer(empty_inner.st);
   } else {

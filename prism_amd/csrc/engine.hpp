@@ -187,11 +187,34 @@ std::unique_ptr<prism_gpu_part> part_open(prism_gpu_plan* plan, uint32_t partiti
 void part_push(prism_gpu_part* part, ArrowArray* batch);
 void part_finish(prism_gpu_part* part, ArrowArray* out);
 
+// COUNT(DISTINCT x) GROUP BY k over two-word pairs, sharded over several GPUs: a rank's own
+// part ends with the DISTINCT records of every fine bucket (one word each: the bits the bucket
+// does not imply), which are dealt to the buckets' owners.  The numbers of buckets follow from
+// `sizing_rows`, which the ranks agree on, so that every rank cuts the same buckets.
+struct DistinctShardRequest {
+  uint64_t sizing_rows;
+};
+struct DistinctShard {
+  int p1 = 0, p2 = 0, lo_bits = 0, hi_bits = 0;
+  uint32_t n_fine = 0, lds_entries = 0;
+  Scratch records;  // fine bucket f: records[fine_base[f] .. + fine_count[f])
+  Scratch fine;     // the block fine_count / fine_base point into
+  uint32_t* fine_count = nullptr;
+  uint32_t* fine_base = nullptr;
+};
+
 // Device-resident aggregate state (prism_gpu_aggregate and friends).
 void scan_stats(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions,
                 prism_gpu_col_stats* out);
 prism_gpu_state* aggregate_state(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids,
-                                 size_t n_partitions, const prism_gpu_col_stats* stats);
+                                 size_t n_partitions, const prism_gpu_col_stats* stats, const DistinctShardRequest* shard = nullptr);
+// The shard a state holds (null: the state is a table).
+DistinctShard* state_shard(prism_gpu_state* st);
+// The owner's part: `records` holds, for each of `world` ranks, the distinct records of this
+// rank's n_own fine buckets in order (rank s's start at recv_start[s], host array), counts64 their
+// numbers ([world][n_own], device).  Returns a state that counts the pairs per group.
+prism_gpu_state* distinct_shard_merge(prism_gpu_state* local, const uint64_t* records, uint64_t n_records, const uint64_t* counts64,
+                                      const uint64_t* recv_start, uint32_t n_own, int world, int rank);
 void state_describe(prism_gpu_state* st, prism_gpu_state_info* out);
 void state_export(prism_gpu_state* st, void* device_dst, size_t bytes);
 void state_import(prism_gpu_state* st, const void* device_src, size_t bytes);

@@ -1439,16 +1439,22 @@ uint64_t distinct_emit_outer(prism_gpu_ctx* ctx, const prism_gpu_plan* plan, con
 // bucket into fine buckets by a hash of the pair, and the fine buckets are deduplicated in
 // LDS and counted per group into `outer`.  False: a fine bucket did not fit (very uneven
 // data) or the outer table overflowed; nothing usable was produced.
+// With `shard` (a query sharded over several GPUs) the last pass writes every fine bucket's
+// distinct records instead of counting them, the bucket numbers follow from req->sizing_rows
+// (the same on every rank) and from nothing this rank has learnt, and `outer` stays empty.
 bool partitioned_distinct(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggParams& ap, uint64_t selected, uint64_t key_bytes,
-                          const KeyLayout& layout, GroupTable& outer) {
+                          const KeyLayout& layout, GroupTable& outer, const DistinctShardRequest* req = nullptr,
+                          DistinctShard* shard = nullptr) {
   const int words = part_record_words(ap, false);
-  if (words != 2 || selected == 0 || selected >= (1ull << 32)) return false;
+  if (words != 2 || selected >= (1ull << 32) || (selected == 0 && !shard)) return false;
+  const uint64_t sizing = shard ? std::max<uint64_t>(1, req->sizing_rows) : selected;
+  if (sizing >= (1ull << 32) || selected > sizing) return false;
   // coarse buckets of about half a million rows, fine buckets of about a quarter of the LDS set
   // (at most 1024 of them while the scatter pass can run two half-size workgroups per CU: the
   // counters of 2048 buckets next to two tiles do not fit the LDS)
   const int p1_most = ctx->part_half_blocks.load(std::memory_order_relaxed) != 0 && part_scatter_halves(words, 1024) ? 10 : 11;
   int p1 = 6;
-  while (p1 < p1_most && (selected >> p1) > (1ull << 19)) ++p1;
+  while (p1 < p1_most && (sizing >> p1) > (1ull << 19)) ++p1;
   if ((1u << p1) > part_max_buckets(words)) return false;
   // (a fine bucket of up to half the set's entries is taken in one go; larger ones, in the
   // coarse buckets of very frequent groups, in several passes)
@@ -1458,13 +1464,13 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggPar
   // many rows; the last pass falls back to several passes per bucket should a bucket's pairs
   // crowd its set all the same, and the share is learnt anew on every run).  Fewer, larger
   // fine buckets mean longer runs out of the second scatter pass and less work per bucket.
-  const uint32_t seen = plan->distinct_pairs_per_1024.load(std::memory_order_relaxed);
+  const uint32_t seen = shard ? 0u : plan->distinct_pairs_per_1024.load(std::memory_order_relaxed);
   const uint64_t rows_per_entry_x8 = seen ? std::min<uint64_t>(32, std::max<uint64_t>(8, 8 * 1024 / (uint64_t)seen)) : 8;
   auto fine_bits = [&](int coarse_bits, uint32_t entries) {
     const uint64_t fine_rows = (uint64_t)entries * 3 / 8 * rows_per_entry_x8 / 8;
     int b = 0;
-    while (b < 10 && (selected >> (coarse_bits + b)) > fine_rows) ++b;
-    return (selected >> (coarse_bits + b)) > fine_rows ? -1 : b;
+    while (b < 10 && (sizing >> (coarse_bits + b)) > fine_rows) ++b;
+    return (sizing >> (coarse_bits + b)) > fine_rows ? -1 : b;
   };
   // One-word records at the second level: when both bucket numbers are taken from bijections
   // of the words, a record in its fine bucket needs only the bits the bucket does not imply;
@@ -1487,13 +1493,30 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggPar
     }
     if (c2 >= 0 && excess() > 0) c2 += excess();
     compact = c2 >= 0 && c2 <= 10 && c2 <= lo_bits && c1 <= hi_bits && hi_bits - c1 <= 9 && excess() <= 0 &&
-              ((c1 == p1 && c2 == fine_bits(c1, part2_lds_entries(true))) || (selected >> (c1 + c2)) >= 128);
+              ((c1 == p1 && c2 == fine_bits(c1, part2_lds_entries(true))) || (sizing >> (c1 + c2)) >= 128);
     if (compact) { p1 = c1; p2 = c2; }
   }
+  if (shard && !compact) return false;  // (distinct records travel in the one-word form only)
   if (!compact) p2 = fine_bits(p1, part2_lds_entries(false));
   if (p2 < 0) return false;  // more rows than 2^21 fine buckets take
   const uint32_t P1 = 1u << p1;
   const uint32_t set_entries = part2_lds_entries(compact);
+  if (shard && selected == 0) {
+    // a rank with nothing to scan still takes part in the exchange: every bucket empty
+    const uint32_t nf = 1u << (p1 + p2);
+    shard->p1 = p1;
+    shard->p2 = p2;
+    shard->lo_bits = lo_bits;
+    shard->hi_bits = hi_bits;
+    shard->n_fine = nf;
+    shard->lds_entries = set_entries;
+    shard->fine = Scratch(ctx, (size_t)nf * 16 + 64);
+    PRISM_HIP(hipMemsetAsync(shard->fine.p, 0, (size_t)nf * 16 + 64, ctx->stream));
+    shard->fine_count = shard->fine.as<uint32_t>();
+    shard->fine_base = shard->fine.as<uint32_t>() + 2 * (size_t)nf;
+    shard->records = Scratch(ctx, 256);
+    return true;
+  }
 
   PartParams q1;
   std::memset(&q1, 0, sizeof(q1));
@@ -1505,13 +1528,13 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggPar
   q1.max_items = P1 + 4;
   q1.lds_entries = part_lds_entries(ap);
   q1.lds_limit = q1.lds_entries / 4 * 3;
-  q1.rec_capacity = selected;
+  q1.rec_capacity = std::max<uint64_t>(1, selected);
   q1.by_hi = 1;
   q1.hi_bits = compact ? hi_bits : 0;
   Scratch rec[2], rec2[2], d_hist(ctx, (size_t)q1.n_wg * P1 * 4), d_totals(ctx, (size_t)P1 * 4), d_base(ctx, (size_t)(P1 + 1) * 8),
       d_items(ctx, (size_t)q1.max_items * sizeof(PartItem)), d_small(ctx, 256);
   for (int w = 0; w < 2; ++w) {
-    rec[w] = Scratch(ctx, selected * 8 + 256);
+    rec[w] = Scratch(ctx, std::max<uint64_t>(1, selected) * 8 + 256);
     q1.rec[w] = rec[w].as<uint64_t>();
   }
   q1.hist = d_hist.as<uint32_t>();
@@ -1531,7 +1554,7 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggPar
   // The fine buckets get regions of fixed size (no histogram pass over the records) unless
   // this plan's data overflowed one before, or the padded array would pass 2^32 records.
   const uint64_t fixed_capacity = part2_fixed_capacity(selected, n_fine);
-  bool fixed = ctx->part2_fixed.load(std::memory_order_relaxed) != 0 && plan->part2_fixed.load(std::memory_order_relaxed) >= 0 &&
+  bool fixed = !shard && ctx->part2_fixed.load(std::memory_order_relaxed) != 0 && plan->part2_fixed.load(std::memory_order_relaxed) >= 0 &&
                fixed_capacity < (1ull << 32);
   for (int w = 0; w < 2; ++w)
     if (w == 0 || !compact) rec2[w] = Scratch(ctx, (fixed ? fixed_capacity : selected) * 8 + 256);
@@ -1541,9 +1564,10 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggPar
   for (;;) {
     PRISM_HIP(hipMemsetAsync(d_fine.p, 0, (size_t)n_fine * 4, ctx->stream));
     PRISM_HIP(hipMemsetAsync(d_small.as<uint8_t>() + 32, 0, 224, ctx->stream));
-    distinct_outer_alloc(ctx, layout, selected, outer);
+    if (!shard) distinct_outer_alloc(ctx, layout, selected, outer);
     Part2Params q2;
     std::memset(&q2, 0, sizeof(q2));
+    q2.emit_out = shard ? rec[0].as<uint64_t>() : nullptr;  // (the first level's records are done with once the second has scattered them)
     q2.in_lo = rec[0].as<uint64_t>();
     q2.in_hi = rec[1].as<uint64_t>();
     q2.out_lo = rec2[0].as<uint64_t>();
@@ -1563,11 +1587,13 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggPar
     q2.fine_limit = fixed ? d_fine.as<uint32_t>() + 3 * (size_t)n_fine + 1 : nullptr;
     q2.lds_entries = set_entries;
     q2.x_null_bit = layout.fields[0].null_bit;
-    q2.dense = outer.dense ? 1 : 0;
-    q2.capacity = outer.capacity;
-    q2.g_keys = outer.keys.as<uint64_t>();
-    q2.g_state = outer.state.as<int64_t>();
-    q2.overflow = outer.overflow.as<uint32_t>();
+    if (!shard) {
+      q2.dense = outer.dense ? 1 : 0;
+      q2.capacity = outer.capacity;
+      q2.g_keys = outer.keys.as<uint64_t>();
+      q2.g_state = outer.state.as<int64_t>();
+      q2.overflow = outer.overflow.as<uint32_t>();
+    }
     q2.queue = (uint32_t*)(d_small.as<uint8_t>() + 32);
     q2.flags = (uint32_t*)(d_small.as<uint8_t>() + 40);
     q2.pairs = compact ? (unsigned long long*)(d_small.as<uint8_t>() + 64) : nullptr;  // [64, 128) of the block
@@ -1586,9 +1612,22 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggPar
     }
     break;
   }
-  if (h.flags[0] != 0 || table_overflowed(ctx, outer)) {
+  if (h.flags[0] != 0 || (!shard && table_overflowed(ctx, outer))) {
     outer = GroupTable();
     return false;
+  }
+  if (shard) {
+    shard->p1 = p1;
+    shard->p2 = p2;
+    shard->lo_bits = lo_bits;
+    shard->hi_bits = hi_bits;
+    shard->n_fine = n_fine;
+    shard->lds_entries = set_entries;
+    shard->fine_count = d_fine.as<uint32_t>();
+    shard->fine_base = d_fine.as<uint32_t>() + 2 * (size_t)n_fine;
+    shard->records = std::move(rec[0]);
+    shard->fine = std::move(d_fine);
+    return true;
   }
   if (compact) {
     unsigned long long pairs = 0;
@@ -1617,8 +1656,10 @@ struct prism_gpu_state {
   prism::Scratch c_keys, c_keys_hi, c_state;
   // COUNT(DISTINCT): 1 = the table is the set of (x, group) pairs, 2 = the table counts the
   // pairs per group (slot 0: pairs folded in, slot 1: the distinct count)
+  // 3 = no table: the distinct records of every fine bucket (`shard`), for the exchange of a sharded query
   int distinct = 0;
   uint64_t selected = 0;  // rows that went into the set (sizes the outer table)
+  std::unique_ptr<prism::DistinctShard> shard;
 };
 
 namespace prism {
@@ -1757,7 +1798,8 @@ bool try_fuse_predicate(const prism_gpu_plan* plan, const prism_gpu_table* table
 
 void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions,
                   bool merge_input, ArrowArray* out, const prism_gpu_col_stats* stats_override, prism_gpu_state** capture,
-                  bool emit_partial = false, prism_gpu_ctx* ctx_override = nullptr, std::vector<OutColumn>* cols_out = nullptr);
+                  bool emit_partial = false, prism_gpu_ctx* ctx_override = nullptr, std::vector<OutColumn>* cols_out = nullptr,
+                  const DistinctShardRequest* shard_req = nullptr);
 void execute_mixed(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions, ArrowArray* out);
 }
 
@@ -1782,7 +1824,7 @@ namespace {
 // statistics so that every rank of a multi-GPU query packs keys the same way.
 void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions,
                   bool merge_input, ArrowArray* out, const prism_gpu_col_stats* stats_override, prism_gpu_state** capture,
-                  bool emit_partial, prism_gpu_ctx* ctx_override, std::vector<OutColumn>* cols_out) {
+                  bool emit_partial, prism_gpu_ctx* ctx_override, std::vector<OutColumn>* cols_out, const DistinctShardRequest* shard_req) {
   if (plan->mixed) fail(PRISM_GPU_EUNSUPPORTED, "COUNT(DISTINCT) next to other aggregates runs through prism_gpu_execute only");
   // (ctx_override: a child context of the plan's, for partitions that stream concurrently)
   prism_gpu_ctx* ctx = ctx_override ? ctx_override : plan->ctx;
@@ -1891,7 +1933,8 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
   bool fused = false;
   // A plan that partitions its rows evaluates the predicate as a bitmap (the partitioning
   // kernels take a selection, not a predicate).
-  const bool prefers_part = !plan->keys.empty() && (plan->part_mode.load(std::memory_order_relaxed) == 1 || part_forced(ctx));
+  // (a sharded COUNT(DISTINCT) partitions its pairs: its WHERE is wanted as a bitmap)
+  const bool prefers_part = !plan->keys.empty() && (plan->part_mode.load(std::memory_order_relaxed) == 1 || part_forced(ctx) || shard_req != nullptr);
   if (has_pred && !count_only && !plan->distinct_plan && layout.words == 1 && !prefers_part)
     fused = try_fuse_predicate(plan, table, ss, keys, layout, ap, false);
   if (has_pred && !count_only && !fused) {
@@ -2149,6 +2192,21 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       outer_ready = partitioned_distinct(ctx, plan, ap, selected, key_bytes, layout, outer_q);
       if (!outer_ready) plan->part_mode.store(-1, std::memory_order_relaxed);  // uneven data: the one-table way from now on
     }
+    // The rank's part of a sharded COUNT(DISTINCT): the same two partition levels, ending with the
+    // distinct records of every fine bucket instead of counts (the ranks decided together that
+    // the plan takes this way: distinct_shard_possible).
+    std::unique_ptr<DistinctShard> shard;
+    if (shard_req && capture) {
+      if (!(plan->distinct_plan && layout.words == 2 && !partial && ap.n_pred == 0 && ap.row_mode != kRowsSelvec))
+        fail(PRISM_GPU_EINTERNAL, "the plan cannot produce the distinct records of a sharded COUNT(DISTINCT)");
+      for (const Chunk* ch : ss.chunks)
+        if (ch->rows >= (1ull << 29)) fail(PRISM_GPU_EUNSUPPORTED, "a sharded COUNT(DISTINCT) takes chunks of fewer than 2^29 rows");
+      shard = std::make_unique<DistinctShard>();
+      KernelTimer timer(ctx, "group_by", ss.rows * value_bytes);
+      if (!partitioned_distinct(ctx, plan, ap, selected, key_bytes, layout, outer_q, shard_req, shard.get()))
+        fail(PRISM_GPU_EINTERNAL, "the distinct pairs of this rank's partitions do not fit the fine buckets");
+      outer_ready = true;
+    }
     if (use_part && !outer_ready) {
       partitioned_group_by(ctx, plan, ap, selected, ss.rows, key_bytes, value_bytes, vals_nullable, slot_ops, gt);
       dense = false;
@@ -2179,7 +2237,7 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
         PRISM_HIP(hipStreamSynchronize(ctx->stream));
         collect_timings(ctx);
         execute_impl(plan, table, partition_ids, n_partitions, merge_input, out, stats_override, capture, emit_partial, ctx_override,
-                     cols_out);
+                     cols_out, shard_req);
         return;
       }
       if (dense || flag == 0u) break;
@@ -2201,7 +2259,8 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       st->gt = std::move(gt);
       st->slot_ops = slot_ops;
       if (fused) selected = fused_count();
-      st->distinct = plan->distinct_plan ? 1 : 0;
+      st->distinct = shard ? 3 : plan->distinct_plan ? 1 : 0;
+      st->shard = std::move(shard);
       st->selected = selected;
       {
         std::lock_guard<std::mutex> g(ctx->mu);
@@ -2540,10 +2599,68 @@ void scan_stats(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* pa
 }
 
 prism_gpu_state* aggregate_state(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids,
-                                 size_t n_partitions, const prism_gpu_col_stats* stats) {
+                                 size_t n_partitions, const prism_gpu_col_stats* stats, const DistinctShardRequest* shard) {
   prism_gpu_state* st = nullptr;
-  execute_impl(plan, table, partition_ids, n_partitions, false, nullptr, stats, &st);
+  execute_impl(plan, table, partition_ids, n_partitions, false, nullptr, stats, &st, false, nullptr, nullptr, shard);
   return st;
+}
+
+DistinctShard* state_shard(prism_gpu_state* st) { return st->shard.get(); }
+
+prism_gpu_state* distinct_shard_merge(prism_gpu_state* local, const uint64_t* records, uint64_t n_records, const uint64_t* counts64,
+                                      const uint64_t* recv_start, uint32_t n_own, int world, int rank) {
+  prism_gpu_plan* plan = local->plan;
+  prism_gpu_ctx* ctx = plan->ctx;
+  bind(ctx);
+  const DistinctShard* sh = local->shard.get();
+  if (!sh) fail(PRISM_GPU_EINTERNAL, "not the distinct records of a sharded COUNT(DISTINCT)");
+  if (n_records >= (1ull << 32)) fail(PRISM_GPU_EUNSUPPORTED, "more than 2^32 distinct records meet on one rank");
+  auto st = std::make_unique<prism_gpu_state>();
+  st->plan = plan;
+  st->table = local->table;
+  st->keys = local->keys;
+  st->layout = local->layout;  // (the pairs' layout: the outer rows are unpacked relative to it)
+  st->low = local->low;
+  st->slot_ops = {kSlotAddOne, kSlotAddOne};
+  st->distinct = 2;
+  st->selected = std::max<uint64_t>(1, n_records);
+  distinct_outer_alloc(ctx, st->layout, st->selected, st->gt);
+  Scratch runs(ctx, (size_t)world * std::max<uint32_t>(1, n_own) * 8), d_start(ctx, (size_t)world * 8 + 64);
+  uint32_t* const seg_base = runs.as<uint32_t>();
+  uint32_t* const seg_cnt = seg_base + (size_t)world * n_own;
+  PRISM_HIP(hipMemcpyAsync(d_start.p, recv_start, (size_t)world * 8, hipMemcpyHostToDevice, ctx->stream));
+  uint32_t* const flags = (uint32_t*)(d_start.as<uint8_t>() + (size_t)world * 8);
+  PRISM_HIP(hipMemsetAsync(flags, 0, 64, ctx->stream));
+  if (n_own) launch_shard_runs(ctx, (const unsigned long long*)counts64, d_start.as<unsigned long long>(), seg_base, seg_cnt, n_own, (uint32_t)world);
+  Part2Params q;
+  std::memset(&q, 0, sizeof(q));
+  q.out_lo = const_cast<uint64_t*>(records);
+  q.compact = 1;
+  q.lo_bits = sh->lo_bits;
+  q.hi_bits = sh->hi_bits;
+  q.p1_bits = (uint32_t)sh->p1;
+  q.p2_bits = (uint32_t)sh->p2;
+  q.n_rows = n_records;
+  q.lds_entries = sh->lds_entries;
+  q.x_null_bit = -1;
+  q.dense = st->gt.dense ? 1 : 0;
+  q.capacity = st->gt.capacity;
+  q.g_keys = st->gt.keys.as<uint64_t>();
+  q.g_state = st->gt.state.as<int64_t>();
+  q.overflow = st->gt.overflow.as<uint32_t>();
+  q.flags = flags;
+  q.n_src = (uint32_t)world;
+  q.world = (uint32_t)world;
+  q.rank = (uint32_t)rank;
+  q.seg_base = seg_base;
+  q.seg_cnt = seg_cnt;
+  launch_distinct_merge(ctx, q, n_own);
+  uint32_t h_flags[2] = {0, 0};
+  PRISM_HIP(hipMemcpyAsync(h_flags, flags, 8, hipMemcpyDeviceToHost, ctx->stream));
+  PRISM_HIP(hipStreamSynchronize(ctx->stream));
+  collect_timings(ctx);
+  if (h_flags[0] != 0 || table_overflowed(ctx, st->gt)) fail(PRISM_GPU_EINTERNAL, "the distinct records of a fine bucket did not fit its owner's set");
+  return st.release();
 }
 
 void state_describe(prism_gpu_state* st, prism_gpu_state_info* out) {

@@ -345,11 +345,35 @@ struct Part2Params {
   // p2_bits <= lo_bits, lo_bits - p2_bits + hi_bits - p1_bits <= 63 and no NULL bit in x.
   int32_t compact, lo_bits, hi_bits;
   unsigned long long* pairs;    // [8] (one-word records): distinct pairs counted, as eight partial sums; may be null
+  // A query sharded over several GPUs (one-word records only).  emit_out set: the last pass writes
+  // every fine bucket's DISTINCT records to emit_out[fine_base[f] ..] and their number to
+  // fine_count[f] instead of counting them per group.  launch_distinct_merge: bucket j of this
+  // rank's n_own buckets is the union of n_src runs of out_lo, run s at seg_base[s * n_own + j]
+  // with seg_cnt[s * n_own + j] records; it is fine bucket ((j >> p2_bits) * world + rank, j & (2^p2_bits - 1)).
+  uint64_t* emit_out;
+  uint32_t n_src, world, rank;
+  const uint32_t* seg_base;
+  const uint32_t* seg_cnt;
 };
 uint32_t part2_lds_entries(bool compact);
 // Records the output arrays must hold when the fine buckets get regions of fixed size.
 uint64_t part2_fixed_capacity(uint64_t n_rows, uint32_t n_fine);
 void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q);
+// The exchange of a sharded COUNT(DISTINCT): fine bucket (c, sub) belongs to rank c % world.
+// counts64: the buckets' distinct-record counts in owner-major order (owner by owner, inside an
+// owner's block by j = (c / world) * n_sub + sub), one 64-bit word each; launch_scan_u64 turns them
+// into places in the send buffer (offsets[n] = the total); launch_shard_gather copies the records
+// there; launch_shard_runs turns what an owner received (counts of n_own buckets from each of
+// `world` ranks, rank s's records starting at recv_start[s]) into the runs launch_distinct_merge reads.
+void launch_shard_counts(prism_gpu_ctx* ctx, const uint32_t* fine_count, unsigned long long* counts64, uint32_t n_fine, uint32_t p1_bits,
+                         uint32_t p2_bits, uint32_t world);
+void launch_scan_u64(prism_gpu_ctx* ctx, const unsigned long long* counts, unsigned long long* offsets, uint32_t n);
+void launch_shard_gather(prism_gpu_ctx* ctx, const unsigned long long* records, const uint32_t* fine_base, const uint32_t* fine_count,
+                         const unsigned long long* send_offsets, unsigned long long* send, uint32_t n_fine, uint32_t p1_bits,
+                         uint32_t p2_bits, uint32_t world);
+void launch_shard_runs(prism_gpu_ctx* ctx, const unsigned long long* recv_counts64, const unsigned long long* recv_start, uint32_t* seg_base,
+                       uint32_t* seg_cnt, uint32_t n_own, uint32_t world);
+void launch_distinct_merge(prism_gpu_ctx* ctx, const Part2Params& q, uint32_t n_own);
 
 // Second level of COUNT(DISTINCT x) GROUP BY k: every occupied entry of the
 // (k, x) set adds 1 (when its x field is not NULL) to group k of table `q`.

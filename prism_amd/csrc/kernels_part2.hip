@@ -415,27 +415,59 @@ __global__ __launch_bounds__(kP2AggBlock) void k_part2_agg(Part2Params q, uint32
 // the group counters are indexed directly, and the set is a plain one-word table (one CAS to
 // claim an entry, nothing to publish).  The groups' keys are rebuilt from (coarse bucket, high
 // rest) through the inverse of the bijection when the counts leave for the outer table.
+//
+// MODE kP2Count: as described.  kP2Emit (the rank's own part of a query sharded over several
+// GPUs): a record seen for the first time is written to q.emit_out instead -- the bucket's
+// distinct records, at the bucket's place -- and q.fine_count[f] receives their number; nothing
+// is counted.  kP2Merge (the owner's part): bucket j of this rank's share of the fine buckets
+// is the union of one run of records per sending rank (q.seg_base / q.seg_cnt, in q.out_lo),
+// each run distinct in itself; counted like kP2Count.
+enum P2AggMode { kP2Count = 0, kP2Emit = 1, kP2Merge = 2 };
+
+template <int MODE>
 __global__ __launch_bounds__(kP2AggBlock) void k_part2_agg_compact(Part2Params q, uint32_t n_fine) {
   extern __shared__ __align__(16) unsigned long long p2_lds[];
   __shared__ uint32_t gcnt[kP2Groups];
   __shared__ uint32_t crowded;  // a row of the bucket found no room on its probe path
-  const uint32_t S = q.lds_entries, tid = threadIdx.x;
+  __shared__ uint32_t emit_n;   // kP2Emit: distinct records of the bucket written so far
+  const uint32_t S = q.lds_entries, tid = threadIdx.x, lane = tid & 63u;
   const int lo_rest = q.lo_bits - (int)q.p2_bits, hi_rest = q.hi_bits - (int)q.p1_bits;
   const uint32_t n_groups = 1u << hi_rest;  // <= kP2Groups
   unsigned long long* keys = p2_lds;
   unsigned long long my_pairs = 0;  // distinct pairs this thread handed to the outer table
   for (uint32_t i = tid; i < kP2Groups; i += kP2AggBlock) gcnt[i] = 0;
+  if (tid == 0) emit_n = 0;
+  constexpr uint32_t kBatch = 8;  // rows a thread requests together
+  const uint32_t n_src = MODE == kP2Merge ? q.n_src : 1u;
   for (uint32_t f = blockIdx.x; f < n_fine; f += gridDim.x) {
     __syncthreads();
-    const uint32_t b0 = q.fine_base[f], b1 = p2_bucket_end(q, f);
-    if (b1 == b0) continue;
-    const uint32_t n = b1 - b0;
-    constexpr uint32_t kBatch = 8;  // a thread's first rows, requested together and kept for all the passes
+    // the bucket's runs of records: one, or (kP2Merge) one per sending rank
+    auto run_of = [&](uint32_t src, uint32_t& r0, uint32_t& r1) {
+      if (MODE == kP2Merge) {
+        r0 = q.seg_base[(uint64_t)src * n_fine + f];
+        r1 = r0 + q.seg_cnt[(uint64_t)src * n_fine + f];
+      } else {
+        r0 = q.fine_base[f];
+        r1 = p2_bucket_end(q, f);
+      }
+    };
+    uint32_t n = 0;
+    for (uint32_t src = 0; src < n_src; ++src) {
+      uint32_t r0, r1;
+      run_of(src, r0, r1);
+      n += r1 - r0;
+    }
+    if (n == 0) {
+      if (MODE == kP2Emit && tid == 0) q.fine_count[f] = 0;
+      continue;
+    }
+    uint32_t b0, b1;  // the first run: its leading rows stay in registers for all the passes
+    run_of(0, b0, b1);
     uint64_t b[kBatch];
 #pragma unroll
     for (uint32_t j = 0; j < kBatch; ++j) {
       const uint32_t i = b0 + tid + j * kP2AggBlock, ic = i < b1 ? i : b0;
-      b[j] = __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.out_lo + ic));
+      b[j] = b1 > b0 ? __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.out_lo + ic)) : 0ull;
     }
     // A bucket of more rows than the set is sure to take (n > S / 2) is first tried in one go
     // all the same: what makes a bucket large is, as a rule, one very frequent pair, and rows
@@ -461,62 +493,95 @@ __global__ __launch_bounds__(kP2AggBlock) void k_part2_agg_compact(Part2Params q
       // overlap, made the pass slower, 7.5 -> 10.7 ms: rows that repeat a frequent pair then
       // all see its entry still free and fight over it.)
       const uint32_t nb = Sb >> 1;
-      auto take = [&](uint64_t rec, uint32_t pass) {
+      // true: the record was seen for the first time
+      auto take = [&](uint64_t rec, uint32_t pass) -> bool {
         uint32_t h = ((uint32_t)rec ^ (uint32_t)(rec >> 32) * 0x85EBCA6Bu);
         h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
-        if (passes > 1 && (uint32_t)(hash64(rec * 0xD6E8FEB86659FD93ull) >> 33) % passes != pass) return;
+        if (passes > 1 && (uint32_t)(hash64(rec * 0xD6E8FEB86659FD93ull) >> 33) % passes != pass) return false;
         uint32_t bkt = __umulhi(h, nb);
         for (uint32_t probes = 0; probes < probe_limit; ++probes) {
           asm volatile("" ::: "memory");  // the bucket is read afresh in every step
           const ulonglong2 c = *(const ulonglong2*)&keys[2 * (size_t)bkt];
-          if (c.x == rec || c.y == rec) return;
+          if (c.x == rec || c.y == rec) return false;
           if (c.x == kP2Empty || c.y == kP2Empty) {
             const uint32_t e = 2 * bkt + (c.x == kP2Empty ? 0u : 1u);
             const unsigned long long old = atomicCAS(&keys[e], kP2Empty, (unsigned long long)rec);
             if (old == kP2Empty) {  // seen for the first time: counts for its group
-              atomicAdd(&gcnt[(uint32_t)(rec >> lo_rest)], 1u);
-              return;
+              if (MODE != kP2Emit) atomicAdd(&gcnt[(uint32_t)(rec >> lo_rest)], 1u);
+              return true;
             }
-            if (old == rec) return;
+            if (old == rec) return false;
             continue;  // another record took the entry: look at the bucket again
           }
           bkt = bkt + 1 == nb ? 0u : bkt + 1;
         }
         if (passes == 1) crowded = 1u;
         else q.flags[0] = 1u;  // a class far larger than its share: the result is void
+        return false;
       };
-      auto take_batch = [&](const uint64_t (&r)[kBatch], uint32_t first, uint32_t pass) {
+      // (every thread of the workgroup makes the same calls: the ballot below needs whole waves)
+      auto take_batch = [&](const uint64_t (&r)[kBatch], uint32_t first, uint32_t end, uint32_t pass) {
 #pragma unroll
-        for (uint32_t j = 0; j < kBatch; ++j)
-          if (first + tid + j * kP2AggBlock < b1) take(r[j], pass);
+        for (uint32_t j = 0; j < kBatch; ++j) {
+          bool fresh = false;
+          if (first + tid + j * kP2AggBlock < end) fresh = take(r[j], pass);
+          if (MODE == kP2Emit) {
+            // the wave's new records take consecutive places behind the bucket's earlier ones
+            const uint64_t m = __ballot(fresh);
+            if (m) {
+              uint32_t at = 0;
+              if (lane == (uint32_t)(__ffsll((long long)m) - 1)) at = atomicAdd(&emit_n, (uint32_t)__popcll(m));
+              at = __shfl(at, __ffsll((long long)m) - 1);
+              if (fresh) q.emit_out[(uint64_t)b0 + at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r[j];
+            }
+          }
+        }
       };
       for (uint32_t pass = 0; pass < passes; ++pass) {
         if (pass) __syncthreads();
         for (uint32_t i = tid; i < Sb; i += kP2AggBlock) keys[i] = kP2Empty;
         if (tid == 0) crowded = 0;
         __syncthreads();
-        take_batch(b, b0, pass);
-        // (what lies beyond the first rows is fetched once per pass, again a batch at a time so
-        // that a thread waits for memory once per batch)
-        for (uint32_t base = b0 + kBatch * kP2AggBlock; base < b1; base += kBatch * kP2AggBlock) {
-          uint64_t more[kBatch];
-#pragma unroll
-          for (uint32_t j = 0; j < kBatch; ++j) {
-            const uint32_t i = base + tid + j * kP2AggBlock, ic = i < b1 ? i : b0;
-            more[j] = __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.out_lo + ic));
+        for (uint32_t src = 0; src < n_src; ++src) {
+          uint32_t r0, r1;
+          run_of(src, r0, r1);
+          uint32_t base = r0;
+          if (src == 0) {
+            take_batch(b, r0, r1, pass);
+            base = r0 + kBatch * kP2AggBlock;
           }
-          take_batch(more, base, pass);
+          // (what lies beyond the first rows is fetched once per pass, again a batch at a time so
+          // that a thread waits for memory once per batch)
+          for (; base < r1; base += kBatch * kP2AggBlock) {
+            uint64_t more[kBatch];
+#pragma unroll
+            for (uint32_t j = 0; j < kBatch; ++j) {
+              const uint32_t i = base + tid + j * kP2AggBlock, ic = i < r1 ? i : r0;
+              more[j] = __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.out_lo + ic));
+            }
+            take_batch(more, base, r1, pass);
+          }
         }
       }
       __syncthreads();
       if (passes > 1 || !crowded) break;
       for (uint32_t i = tid; i < n_groups; i += kP2AggBlock) gcnt[i] = 0;
+      if (tid == 0) emit_n = 0;
       const uint32_t per_pass = S / 5 * 2;
       passes = (n + per_pass - 1) / per_pass;
       if (passes < 2) passes = 2;
       __syncthreads();
     }
-    const uint64_t coarse = f >> q.p2_bits;
+    if (MODE == kP2Emit) {
+      if (tid == 0) {
+        q.fine_count[f] = emit_n;
+        my_pairs += emit_n;
+        emit_n = 0;
+      }
+      continue;
+    }
+    // (kP2Merge: bucket f of this rank's share is fine bucket (c * world + rank, sub) of the query)
+    const uint64_t coarse = MODE == kP2Merge ? (uint64_t)(f >> q.p2_bits) * q.world + q.rank : (uint64_t)(f >> q.p2_bits);
     for (uint32_t i = tid; i < n_groups; i += kP2AggBlock) {
       const uint32_t c = gcnt[i];
       if (c == 0) continue;
@@ -542,6 +607,101 @@ __global__ __launch_bounds__(kP2AggBlock) void k_part2_agg_compact(Part2Params q
     if ((tid & 63u) == 0 && w) atomicAdd(&wg_pairs, w);
     __syncthreads();
     if (tid == 0 && wg_pairs) atomicAdd(&q.pairs[blockIdx.x & 7u], wg_pairs);
+  }
+}
+
+// ---- a COUNT(DISTINCT) sharded over several GPUs: the exchange of the distinct records ----
+// Fine bucket (c, sub) of the query belongs to rank c % world.  In a rank's send buffer the
+// buckets lie owner by owner, and inside an owner's block in the order of the owner's own
+// numbering j = (c / world) * n_sub + sub, so that what an owner receives from a rank is its
+// buckets in order.
+__device__ __forceinline__ uint32_t p2_owner_major(uint32_t f, uint32_t p1_bits, uint32_t p2_bits, uint32_t world) {
+  const uint32_t n_sub = 1u << p2_bits, n_coarse = 1u << p1_bits;
+  const uint32_t c = f >> p2_bits, sub = f & (n_sub - 1), owner = c % world;
+  // coarse buckets of the owners before this one: owner o has ceil((n_coarse - o) / world)
+  const uint32_t before = owner * (n_coarse / world) + (owner < n_coarse % world ? owner : n_coarse % world);
+  return (before + c / world) * n_sub + sub;
+}
+
+// counts in owner-major order (a 64-bit word each: they travel through the all-to-all of words)
+__global__ __launch_bounds__(256) void k_shard_counts(const uint32_t* fine_count, unsigned long long* counts64, uint32_t n_fine,
+                                                       uint32_t p1_bits, uint32_t p2_bits, uint32_t world) {
+  const uint32_t f = blockIdx.x * 256 + threadIdx.x;
+  if (f < n_fine) counts64[p2_owner_major(f, p1_bits, p2_bits, world)] = fine_count[f];
+}
+
+// exclusive scan of n 64-bit counts (one workgroup); offsets[n] receives the total
+__global__ __launch_bounds__(1024) void k_scan_u64(const unsigned long long* counts, unsigned long long* offsets, uint32_t n) {
+  __shared__ unsigned long long wave_tot[16];
+  __shared__ unsigned long long carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < n; base += 1024) {
+    const uint32_t i = base + threadIdx.x;
+    const unsigned long long v = i < n ? counts[i] : 0ull;
+    unsigned long long incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned long long o = __shfl_up(incl, off, 64);
+      if ((int)(threadIdx.x & 63) >= off) incl += o;
+    }
+    if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    unsigned long long before = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) before += wave_tot[w];
+    const unsigned long long c = carry;
+    if (i < n) offsets[i] = c + before + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = c + before + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) offsets[n] = carry;
+}
+
+// the distinct records of every fine bucket, copied to their place in the send buffer
+__global__ __launch_bounds__(256) void k_shard_gather(const unsigned long long* records, const uint32_t* fine_base, const uint32_t* fine_count,
+                                                       const unsigned long long* send_offsets, unsigned long long* send, uint32_t n_fine,
+                                                       uint32_t p1_bits, uint32_t p2_bits, uint32_t world) {
+  for (uint32_t f = blockIdx.x; f < n_fine; f += gridDim.x) {
+    const uint32_t n = fine_count[f];
+    const unsigned long long* src = records + fine_base[f];
+    unsigned long long* dst = send + send_offsets[p2_owner_major(f, p1_bits, p2_bits, world)];
+    for (uint32_t i = threadIdx.x; i < n; i += 256) dst[i] = __builtin_nontemporal_load((P2WordPtr)(uint64_t)(src + i));
+  }
+}
+
+// the runs an owner received, per sending rank: seg_cnt[src][j] from the counts, seg_base[src][j]
+// their places in the receive buffer (rank src's records start at recv_start[src], buckets in order)
+__global__ __launch_bounds__(1024) void k_shard_runs(const unsigned long long* recv_counts64, const unsigned long long* recv_start, uint32_t* seg_base,
+                                                      uint32_t* seg_cnt, uint32_t n_own) {
+  // one workgroup per sending rank: a scan over its n_own counts
+  __shared__ unsigned long long wave_tot[16];
+  __shared__ unsigned long long carry;
+  const uint32_t src = blockIdx.x;
+  const unsigned long long* counts = recv_counts64 + (uint64_t)src * n_own;
+  if (threadIdx.x == 0) carry = recv_start[src];
+  __syncthreads();
+  for (uint32_t base = 0; base < n_own; base += 1024) {
+    const uint32_t i = base + threadIdx.x;
+    const unsigned long long v = i < n_own ? counts[i] : 0ull;
+    unsigned long long incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned long long o = __shfl_up(incl, off, 64);
+      if ((int)(threadIdx.x & 63) >= off) incl += o;
+    }
+    if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    unsigned long long before = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) before += wave_tot[w];
+    const unsigned long long c = carry;
+    if (i < n_own) {
+      seg_base[(uint64_t)src * n_own + i] = (uint32_t)(c + before + incl - v);
+      seg_cnt[(uint64_t)src * n_own + i] = (uint32_t)v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = c + before + incl;
+    __syncthreads();
   }
 }
 
@@ -588,12 +748,54 @@ void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q) {
   {
     KernelTimer timer(ctx, "part2_agg", q.n_rows * (q.compact ? 8 : 16));
     const size_t lds = (size_t)q.lds_entries * (q.compact ? 8 : 16);
-    auto kernel = q.compact ? k_part2_agg_compact : k_part2_agg;
+    if (q.emit_out && !q.compact) fail(PRISM_GPU_EINTERNAL, "distinct records are emitted in the one-word form only");
+    auto kernel = q.compact ? (q.emit_out ? k_part2_agg_compact<kP2Emit> : k_part2_agg_compact<kP2Count>) : k_part2_agg;
     PRISM_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint32_t grid = (uint32_t)std::min<uint64_t>(n_fine, (uint64_t)ctx->n_cus * kP2AggPerCu);
     kernel<<<dim3(grid), dim3(kP2AggBlock), lds, ctx->stream>>>(q, n_fine);
     PRISM_HIP(hipGetLastError());
   }
+}
+
+// ---- COUNT(DISTINCT) sharded over several GPUs: launch wrappers of the exchange's kernels ----
+
+void launch_shard_counts(prism_gpu_ctx* ctx, const uint32_t* fine_count, unsigned long long* counts64, uint32_t n_fine, uint32_t p1_bits,
+                         uint32_t p2_bits, uint32_t world) {
+  k_shard_counts<<<dim3((uint32_t)ceil_div(n_fine, 256)), dim3(256), 0, ctx->stream>>>(fine_count, counts64, n_fine, p1_bits, p2_bits, world);
+  PRISM_HIP(hipGetLastError());
+}
+
+void launch_scan_u64(prism_gpu_ctx* ctx, const unsigned long long* counts, unsigned long long* offsets, uint32_t n) {
+  k_scan_u64<<<dim3(1), dim3(1024), 0, ctx->stream>>>(counts, offsets, n);
+  PRISM_HIP(hipGetLastError());
+}
+
+void launch_shard_gather(prism_gpu_ctx* ctx, const unsigned long long* records, const uint32_t* fine_base, const uint32_t* fine_count,
+                         const unsigned long long* send_offsets, unsigned long long* send, uint32_t n_fine, uint32_t p1_bits,
+                         uint32_t p2_bits, uint32_t world) {
+  KernelTimer timer(ctx, "shard_gather", 0);
+  const uint32_t grid = (uint32_t)std::min<uint64_t>(n_fine, (uint64_t)ctx->n_cus * 16);
+  k_shard_gather<<<dim3(grid), dim3(256), 0, ctx->stream>>>(records, fine_base, fine_count, send_offsets, send, n_fine, p1_bits, p2_bits, world);
+  PRISM_HIP(hipGetLastError());
+}
+
+void launch_shard_runs(prism_gpu_ctx* ctx, const unsigned long long* recv_counts64, const unsigned long long* recv_start, uint32_t* seg_base,
+                       uint32_t* seg_cnt, uint32_t n_own, uint32_t world) {
+  k_shard_runs<<<dim3(world), dim3(1024), 0, ctx->stream>>>(recv_counts64, recv_start, seg_base, seg_cnt, n_own);
+  PRISM_HIP(hipGetLastError());
+}
+
+void launch_distinct_merge(prism_gpu_ctx* ctx, const Part2Params& q, uint32_t n_own) {
+  if (!q.compact || q.n_src == 0 || !q.seg_base || !q.seg_cnt || q.world == 0 || q.rank >= q.world)
+    fail(PRISM_GPU_EINTERNAL, "bad shape for the merge of distinct records");
+  if (q.lds_entries > part2_lds_entries(true)) fail(PRISM_GPU_EINTERNAL, "the pair table exceeds LDS");
+  if (n_own == 0) return;
+  KernelTimer timer(ctx, "part2_merge", 0);
+  const size_t lds = (size_t)q.lds_entries * 8;
+  PRISM_HIP(hipFuncSetAttribute((const void*)k_part2_agg_compact<kP2Merge>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const uint32_t grid = (uint32_t)std::min<uint64_t>(n_own, (uint64_t)ctx->n_cus * kP2AggPerCu);
+  k_part2_agg_compact<kP2Merge><<<dim3(grid), dim3(kP2AggBlock), lds, ctx->stream>>>(q, n_own);
+  PRISM_HIP(hipGetLastError());
 }
 
 }  // namespace prism

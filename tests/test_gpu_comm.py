@@ -130,8 +130,8 @@ def _rank_worker(rank: int, world: int, port: int, q):
     from prism_amd import workloads
     from prism_amd.distributed import exchange_and_finish, make_comm
     from prism_amd.engine import Context, Plan
-    from prism_amd.plan import (QueryPlan as Q, avg as avg_, count_distinct as cd, count_star as cs, date_bin as db, max_ as mx,
-                                min_ as mn, sum_ as sm)
+    from prism_amd.plan import (QueryPlan as Q, avg as avg_, col as col_, count_distinct as cd, count_star as cs, date_bin as db,
+                                max_ as mx, min_ as mn, sum_ as sm)
     from tests.helpers import assert_tables_match, assert_topk_match
 
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
@@ -179,6 +179,41 @@ def _rank_worker(rank: int, world: int, port: int, q):
             else:
                 assert got is None
         assert comm.stats()["bytes_sent"] > 0
+        # COUNT(DISTINCT) the way large scans take it (forced here on small ones): the pairs are
+        # partitioned twice on every rank, the fine buckets' DISTINCT records go to the buckets'
+        # owners, the owners count.  No set of pairs in HBM: k_group_by_wide does not run.
+        ctx.set_option("part_force", 1)
+        for wl, query, rows, n_keys, root, sharded in [
+            (c5, c5.query, 1_500_000, 2, 0, True),
+            (c5, Q([cd("user")], keys=[db(3_600_000, "timestamp"), "service"], predicate=col_("user") > (1 << 61)), 1_500_000, 2, world - 1, True),
+            # a group key of four bits is narrower than the coarse buckets' number: no one-word records, and
+            # one-word pairs are not partitioned twice at all -- the other way, on every rank alike
+            (c5, Q([cd("user")], keys=["service"]), 200_000, 1, world - 1, False),
+            (c2, Q([cd("value")], keys=["service"]), 100_000, 1, 0, False),
+        ]:
+            total = rows * world
+            table = workloads.build_gpu_table(ctx, wl, rows * rank, rows, total, 4)
+            plan = Plan(ctx, wl.schema, query)
+            ctx.reset_stats()
+            try:
+                # the last rank of a three-rank world scans nothing in the first case
+                parts = [] if (world == 3 and rank == 2 and query is c5.query) else None
+                got = exchange_and_finish(plan, table, parts, comm, root)
+            finally:
+                plan.close()
+                table.close()
+            ran = {k for k, v in ctx.stats()["kernels"].items() if v["launches"]}
+            assert ("part2_merge" in ran) == sharded, (query, ran)
+            if rank == root:
+                n_have = total if parts is None and not (world == 3 and query is c5.query) else rows * 2
+                st = pyoracle.SynthTable(wl.schema, wl.make_cols(), wl.seed, 0, n_have, total, n_parts=4)
+                try:
+                    want, _ = st.execute(query)
+                finally:
+                    st.close()
+                assert_tables_match(got, workloads.decode_dictionary_columns(wl, want), n_keys)
+            else:
+                assert got is None
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001
         import traceback
@@ -319,6 +354,78 @@ def test_a_failure_on_one_rank_is_an_error_on_every_rank():
     for p in procs:
         p.start()
     results = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert results == {r: "ok" for r in range(world)}, results
+
+
+def _distinct_at_scale_worker(rank: int, world: int, port: int, q):
+    """COUNT(DISTINCT) over 2.5e8 rows on two ranks that share GPU 0 (1.25e8 each): the sharded
+    result on the root equals the result of one context over all the rows, which the other GPU
+    tests check against the oracle; the set of pairs is never built in HBM."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+
+    from prism_amd import workloads
+    from prism_amd.distributed import exchange_and_finish, make_comm
+    from prism_amd.engine import Context, Plan
+    from tests.helpers import assert_tables_match
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    ctx = Context(0)
+    comm = make_comm(ctx)
+    try:
+        wl = workloads.c5()
+        rows = 125_000_000
+        total = rows * world
+        table = workloads.build_gpu_table(ctx, wl, rows * rank, rows, total, 8)
+        plan = Plan(ctx, wl.schema, wl.query)
+        ctx.reset_stats()
+        try:
+            got = exchange_and_finish(plan, table, None, comm, 0)
+        finally:
+            table.close()
+        ran = {k for k, v in ctx.stats()["kernels"].items() if v["launches"]}
+        assert "part2_merge" in ran and "shard_gather" in ran, ran
+        assert comm.stats()["bytes_sent"] > rows  # the distinct records of the other rank's buckets: gigabytes
+        if rank == 0:
+            whole = workloads.build_gpu_table(ctx, wl, 0, total, total, 16)
+            try:
+                want = plan.execute(whole)
+            finally:
+                whole.close()
+            assert got.num_rows == want.num_rows
+            assert_tables_match(got, want, 2)
+        plan.close()
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+
+        q.put((rank, traceback.format_exc() + repr(e)))
+    finally:
+        comm.close()
+        ctx.close()
+        dist.destroy_process_group()
+
+
+def test_sharded_count_distinct_at_scale_exchanges_distinct_records():
+    import socket
+
+    import torch.multiprocessing as mp
+
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_distinct_at_scale_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=400) for _ in procs)
     for p in procs:
         p.join(timeout=60)
     assert results == {r: "ok" for r in range(world)}, results
