@@ -254,6 +254,97 @@ def check_launch(args) -> int:
     return 0
 
 
+def parquet_feed(args) -> int:
+    """Loader figure: files shaped like prism-ingest's (data page v2, dictionary with PLAIN
+    fallback, Snappy, one file per partition; src/prism-ingest/src/ingest.rs:98-119) sit in host
+    memory, as after an object-store GET; prism_gpu_table_append_parquet decodes them (library
+    code, host threads) and stages the columns into HBM; then the C2 query runs over them and is
+    checked against the CPU oracle over the same rows.  Bounded by host decode, not by HBM."""
+    import io
+    from concurrent.futures import ThreadPoolExecutor
+
+    import numpy as np
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+
+    from prism_amd import workloads
+    from prism_amd.engine import Context, Plan, Table
+
+    if args.workload != "C2":
+        raise SystemExit("--feed parquet measures the C2 query")
+    n_files = args.partitions or 16
+    rows = args.rows or 32_000_000
+    per = rows // n_files
+    rows = per * n_files
+    wl = workloads.c2()
+    names = wl.dictionaries["service"]
+    rng = np.random.default_rng(7)
+    w = 1.0 / np.arange(1, len(names) + 1) ** 1.1
+    w /= w.sum()
+    files, tables = [], []
+    t0 = time.time()
+    for f in range(n_files):
+        ts = workloads.T0_MS + (np.arange(f * per, (f + 1) * per, dtype=np.int64) * workloads.DAY_MS) // rows
+        codes = rng.choice(len(names), size=per, p=w).astype(np.int32)
+        svc = pa.DictionaryArray.from_arrays(pa.array(codes), pa.array(names)).cast(pa.string())
+        t = pa.table({"timestamp": pa.array(ts, pa.timestamp("ms")), "service": svc,
+                      "value": pa.array(rng.integers(0, 50_000, per, dtype=np.int64))})
+        sink = io.BytesIO()
+        pq.write_table(t, sink, version="2.6", data_page_version="2.0", compression="snappy", use_dictionary=True)
+        files.append(sink.getvalue())
+        tables.append(t)
+    file_bytes = sum(len(b) for b in files)
+    decoded_bytes = sum(t.nbytes for t in tables)
+    log(f"[parquet] wrote {n_files} files, {file_bytes / 1e6:.0f} MB for {rows:,} rows ({decoded_bytes / 1e6:.0f} MB decoded) in {time.time() - t0:.1f}s")
+
+    ctx = Context(0)
+    ctx.set_option("parquet_threads", args.parquet_threads)
+    plan = Plan(ctx, wl.schema, wl.query)
+    threads = max(1, min(args.feed_threads, n_files))
+
+    def load_all():
+        table = Table(ctx, wl.schema)
+        with ThreadPoolExecutor(threads) as pool:  # (the call into the library releases the interpreter lock)
+            list(pool.map(lambda f: table.append_parquet(f, files[f]), range(n_files)))
+        return table
+
+    load_all().close()  # warm-up: pinned ring, pools
+    load_s, query_s, result = [], [], None
+    for _ in range(max(1, args.steps)):
+        t0 = time.perf_counter()
+        table = load_all()
+        t1 = time.perf_counter()
+        result = plan.execute(table)
+        t2 = time.perf_counter()
+        load_s.append(t1 - t0)
+        query_s.append(t2 - t1)
+        table.close()
+    from oracle import pyoracle
+    from tests.helpers import assert_tables_match
+
+    want = pyoracle.execute(pa.concat_tables(tables), wl.query)
+    assert_tables_match(result, want, wl.n_keys)
+    plan.close()
+    ctx.close()
+    load = sorted(load_s)[len(load_s) // 2]
+    line = {
+        "metric": "rows/sec Parquet files in host memory -> HBM-resident columns (host decode)",
+        "value": rows / load, "unit": "rows/s", "n_gpus": 1, "steps": len(load_s), "warmup": 1, "ms_per_step": load * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+        "config": {"workload": "C2 schema (timestamp ms, service Utf8 dictionary-encoded, value Int64) as prism-ingest writes it: "
+                               "data page v2, dictionary, Snappy, one file per partition", "feed": "parquet", "files": n_files,
+                   "total_rows": rows, "file_bytes": file_bytes, "decoded_bytes": decoded_bytes, "caller_threads": threads,
+                   "threads_per_file": args.parquet_threads},
+        "roofline": None,
+        "loader": {"bound": "host decode", "parquet_GBps": file_bytes / load / 1e9, "decoded_GBps": decoded_bytes / load / 1e9,
+                   "load_ms": load * 1e3, "query_ms_after_load": sorted(query_s)[len(query_s) // 2] * 1e3,
+                   "parity": "C2 result over the loaded rows equals the CPU oracle's over the same rows"},
+        "cpu_baseline": None,
+    }
+    print(json.dumps(line), flush=True)
+    return 0
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -272,7 +363,8 @@ def main() -> int:
                     help="merge between GPUs: device-resident group tables (state) or PARTIAL Arrow batches (arrow); "
                          "auto = state when the plan allows it.  With one GPU, state/arrow run the same code in a "
                          "one-rank group (to measure the exchange's overhead)")
-    ap.add_argument("--feed", default="resident", choices=["resident", "stream"],
+    ap.add_argument("--parquet-threads", type=int, default=4, help="--feed parquet: threads decoding the column chunks of one file")
+    ap.add_argument("--feed", default="resident", choices=["resident", "stream", "parquet"],
                     help="resident: partitions already in HBM when the timed region starts (the headline value). "
                          "stream: host Arrow batches of 8192 rows pushed through prism_gpu_push_batch on one thread "
                          "per partition, timed from the first push to the merged result (the end-to-end figure; "
@@ -288,6 +380,8 @@ def main() -> int:
     args = ap.parse_args()
     if args.feed == "stream":
         return stream_feed(args)
+    if args.feed == "parquet":
+        return parquet_feed(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args.gpus)
     if args.check_launch:

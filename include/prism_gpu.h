@@ -216,6 +216,8 @@ void prism_gpu_ctx_free(prism_gpu_ctx* ctx);
  *   "contains_windows" 0: LIKE '%needle%' over a column without a dictionary always uses the
  *                    byte-wise prefilter; 1 (default): needles of 4 bytes and more are found by
  *                    comparing 4-byte windows with the needle's leading words
+ *   "parquet_threads" threads that decode the column chunks of one Parquet row group in
+ *                    prism_gpu_table_append_parquet (default 4; 1..64)
  *   "shard_distinct" 0: prism_gpu_execute_sharded always builds a COUNT(DISTINCT)'s set of pairs as a
  *                    hash table in HBM before the exchange; 1 (default): over 2^24 rows and more the
  *                    pairs are partitioned twice, as on one GPU, and the buckets' distinct records travel

@@ -73,6 +73,7 @@ struct prism_gpu_ctx {
   std::atomic<int> part2_fixed{1};                   // 0: the second partition level of COUNT(DISTINCT) always runs its histogram pass
   std::atomic<int> part2_compact{1};                 // 0: the second partition level of COUNT(DISTINCT) always keeps two-word records
   std::atomic<int> contains_windows{1};              // 0: substring search always by the byte-wise prefilter
+  std::atomic<int> parquet_threads{4};               // threads that decode the column chunks of a Parquet row group
   std::atomic<int> shard_distinct{1};                // 0: a sharded COUNT(DISTINCT) always exchanges the set of pairs it built as a hash table in HBM
   std::atomic<int> sharded_fail_phase{0};            // tests: prism_gpu_execute_sharded fails on purpose in this local phase (1..5) on this context's rank
 

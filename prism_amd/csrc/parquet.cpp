@@ -11,7 +11,10 @@
 // v1 and v2; PLAIN, PLAIN_DICTIONARY / RLE_DICTIONARY; UNCOMPRESSED and SNAPPY.  Anything else
 // (nested columns, other physical types, encodings or codecs) is PRISM_GPU_EUNSUPPORTED and
 // names the column.
+#include <atomic>
 #include <cstring>
+#include <mutex>
+#include <thread>
 #include <memory>
 #include <string>
 #include <vector>
@@ -700,19 +703,46 @@ void table_append_parquet(prism_gpu_table* table, uint32_t partition_id, const v
   for (const RowGroupMeta& rg : fm.groups) {
     if (rg.num_rows == 0) continue;
     std::vector<PqColumn> cols(table->fields.size());
-    for (size_t f = 0; f < table->fields.size(); ++f) {
-      PqColumn& col = cols[f];
-      col.type = table->fields[f];
-      if (leaf_of[f] >= 0) {
-        decode_chunk(file, len, fm.leaves[leaf_of[f]], rg.chunks[leaf_of[f]], rg.num_rows, col);
-      } else {
-        col.rows = rg.num_rows;
-        col.nulls = rg.num_rows;
-        col.validity.assign((size_t)(rg.num_rows + 7) / 8, 0);
-        if (col.type.is_string) col.offsets.assign((size_t)rg.num_rows + 1, 0);
-        else col.values.assign((size_t)rg.num_rows * col.type.width, 0);
+    // The column chunks of a row group are independent byte ranges: they are decoded by a few
+    // threads at once (option "parquet_threads"; callers that append several files from threads
+    // of their own multiply that).  The first failure is kept and thrown once all have stopped.
+    std::atomic<size_t> next{0};
+    std::mutex err_mu;
+    std::unique_ptr<Error> err;
+    auto decode_columns = [&]() {
+      for (;;) {
+        const size_t f = next.fetch_add(1);
+        if (f >= table->fields.size()) return;
+        try {
+          PqColumn& col = cols[f];
+          col.type = table->fields[f];
+          if (leaf_of[f] >= 0) {
+            decode_chunk(file, len, fm.leaves[leaf_of[f]], rg.chunks[leaf_of[f]], rg.num_rows, col);
+          } else {
+            col.rows = rg.num_rows;
+            col.nulls = rg.num_rows;
+            col.validity.assign((size_t)(rg.num_rows + 7) / 8, 0);
+            if (col.type.is_string) col.offsets.assign((size_t)rg.num_rows + 1, 0);
+            else col.values.assign((size_t)rg.num_rows * col.type.width, 0);
+          }
+        } catch (const Error& e) {
+          std::lock_guard<std::mutex> g(err_mu);
+          if (!err) err.reset(new Error(e));
+        } catch (const std::bad_alloc&) {
+          std::lock_guard<std::mutex> g(err_mu);
+          if (!err) err.reset(new Error{PRISM_GPU_EOOM, "host memory exhausted while decoding a Parquet column chunk"});
+        } catch (const std::exception& e) {
+          std::lock_guard<std::mutex> g(err_mu);
+          if (!err) err.reset(new Error{PRISM_GPU_EINTERNAL, std::string("internal error: ") + e.what()});
+        }
       }
-    }
+    };
+    const size_t n_threads = std::min<size_t>(table->fields.size(), (size_t)std::max<int>(1, table->ctx->parquet_threads.load(std::memory_order_relaxed)));
+    std::vector<std::thread> helpers;
+    for (size_t i = 1; i < n_threads; ++i) helpers.emplace_back(decode_columns);
+    decode_columns();
+    for (std::thread& t : helpers) t.join();
+    if (err) throw *err;
     ArrowArray batch;
     export_columns(std::move(cols), rg.num_rows, &batch);
     table_append(table, partition_id, &batch, true);  // moves the batch
