@@ -216,6 +216,10 @@ void prism_gpu_ctx_free(prism_gpu_ctx* ctx);
  *   "contains_windows" 0: LIKE '%needle%' over a column without a dictionary always uses the
  *                    byte-wise prefilter; 1 (default): needles of 4 bytes and more are found by
  *                    comparing 4-byte windows with the needle's leading words
+ *   "dict_expand_device" 0: a string column that arrives dictionary encoded (an Arrow dictionary
+ *                    array; the dictionary-encoded chunks of a Parquet file) is expanded into
+ *                    offsets and bytes on the host; 1 (default): its indices and dictionaries are
+ *                    staged and kernels write the offsets, the bytes and the table-wide codes
  *   "parquet_threads" threads that decode the column chunks of one Parquet row group in
  *                    prism_gpu_table_append_parquet (default 4; 1..64)
  *   "shard_distinct" 0: prism_gpu_execute_sharded always builds a COUNT(DISTINCT)'s set of pairs as a

@@ -53,6 +53,10 @@ struct prism_gpu_ctx {
   hipEvent_t stage_done[2] = {nullptr, nullptr};
   bool stage_used[2] = {false, false};
   int stage_next = 0;
+  // device scratch of the loader's kernels (under stage_mu; grown on demand, reused by the next
+  // append: every use is ordered on copy_stream)
+  void* load_tmp = nullptr;
+  size_t load_tmp_bytes = 0;
 
   // ---- child contexts: same device, streams / ring / pool / statistics of their own ----
   prism_gpu_ctx* parent = nullptr;
@@ -74,6 +78,7 @@ struct prism_gpu_ctx {
   std::atomic<int> part2_compact{1};                 // 0: the second partition level of COUNT(DISTINCT) always keeps two-word records
   std::atomic<int> contains_windows{1};              // 0: substring search always by the byte-wise prefilter
   std::atomic<int> parquet_threads{4};               // threads that decode the column chunks of a Parquet row group
+  std::atomic<int> dict_expand_device{1};            // 0: dictionary-encoded string input is expanded into offsets + bytes on the host
   std::atomic<int> shard_distinct{1};                // 0: a sharded COUNT(DISTINCT) always exchanges the set of pairs it built as a hash table in HBM
   std::atomic<int> sharded_fail_phase{0};            // tests: prism_gpu_execute_sharded fails on purpose in this local phase (1..5) on this context's rank
 

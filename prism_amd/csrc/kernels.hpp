@@ -541,6 +541,25 @@ struct ColStats {
 void launch_col_stats(prism_gpu_ctx* ctx, const void* values, const uint64_t* validity, int width, bool is_unsigned,
                       uint64_t rows, ColStats* stats, hipStream_t stream);
 
+// A string column that arrives dictionary encoded is expanded on the device: `index` holds, per
+// row, the position of the row's value in the batches' dictionaries laid end to end
+// (0xffffffff: NULL, an empty string), `dict_off`/`dict_bytes` those dictionaries.  The kernels
+// write the column's offsets (rows + 1) and bytes and, when `codes` is set, the table-wide code
+// remap[index] of every row (`codes` may be the same buffer as `index`).
+struct DictExpand {
+  const uint32_t* index;
+  uint64_t rows;
+  const uint32_t* dict_off;
+  const uint8_t* dict_bytes;
+  const uint32_t* remap;
+  uint32_t* codes;
+  int32_t* offsets;
+  uint8_t* bytes;
+  uint32_t* block_sums;  // dict_expand_blocks(rows) words of scratch
+};
+size_t dict_expand_blocks(uint64_t rows);
+void launch_dict_expand(prism_gpu_ctx* ctx, const DictExpand& q, hipStream_t stream);
+
 struct SynthColDev {
   void* dst;
   int32_t width;  // 2, 4, 8

@@ -1,4 +1,5 @@
-// Loader-side kernels: column statistics (drive GROUP BY key packing) and the
+// Loader-side kernels: column statistics (drive GROUP BY key packing), the expansion of
+// dictionary-encoded string columns into offsets + bytes + table-wide codes, and the
 // device half of the synthetic generators of prism_synth.h.
 #include <algorithm>
 
@@ -49,7 +50,104 @@ __global__ __launch_bounds__(kBlock) void k_synth_url(const int32_t* offsets, ui
   }
 }
 
+// ---- dictionary-encoded strings -> offsets, bytes, codes --------------------------------------
+// A workgroup owns kDictRows consecutive rows, a thread kDictPerThread consecutive rows of
+// them, so that a thread's strings are one contiguous run of the output bytes.
+constexpr int kDictThreads = 256, kDictPerThread = 16, kDictRows = kDictThreads * kDictPerThread;
+
+__device__ __forceinline__ uint32_t dict_len(const uint32_t* dict_off, uint32_t g) {
+  return g == 0xffffffffu ? 0u : dict_off[g + 1] - dict_off[g];
+}
+
+// Sum of kDictThreads values; every thread gets the sum of the threads before it, thread 0 of
+// the caller may read the total from *total.
+__device__ __forceinline__ uint32_t dict_block_scan(uint32_t v, uint32_t* wave_sums, uint32_t* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += o;
+  }
+  if (lane == 63) wave_sums[wave] = incl;
+  __syncthreads();
+  uint32_t before = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < kDictThreads / 64; ++w) {
+    const uint32_t s = wave_sums[w];
+    if (w < wave) before += s;
+    all += s;
+  }
+  *total = all;
+  return before + incl - v;
+}
+
+__global__ __launch_bounds__(kDictThreads) void k_dict_lens(DictExpand q) {
+  __shared__ uint32_t wave_sums[kDictThreads / 64];
+  const uint64_t row0 = (uint64_t)blockIdx.x * kDictRows + (uint64_t)threadIdx.x * kDictPerThread;
+  uint32_t sum = 0;
+  for (int i = 0; i < kDictPerThread; ++i)
+    if (row0 + i < q.rows) sum += dict_len(q.dict_off, q.index[row0 + i]);
+  uint32_t total;
+  (void)dict_block_scan(sum, wave_sums, &total);
+  if (threadIdx.x == 0) q.block_sums[blockIdx.x] = total;
+}
+
+// One workgroup: block_sums becomes its own exclusive prefix sum; the grand total is the last offset.
+__global__ __launch_bounds__(kDictThreads) void k_dict_scan(DictExpand q, uint32_t n_blocks) {
+  __shared__ uint32_t wave_sums[kDictThreads / 64];
+  const uint32_t per = (n_blocks + kDictThreads - 1) / kDictThreads;
+  const uint32_t lo = threadIdx.x * per, hi = lo + per < n_blocks ? lo + per : n_blocks;
+  uint32_t sum = 0;
+  for (uint32_t b = lo; b < hi; ++b) sum += q.block_sums[b];
+  uint32_t total;
+  uint32_t at = dict_block_scan(sum, wave_sums, &total);
+  for (uint32_t b = lo; b < hi; ++b) {
+    const uint32_t v = q.block_sums[b];
+    q.block_sums[b] = at;
+    at += v;
+  }
+  if (threadIdx.x == 0) q.offsets[q.rows] = (int32_t)total;
+}
+
+__global__ __launch_bounds__(kDictThreads) void k_dict_expand(DictExpand q) {
+  __shared__ uint32_t wave_sums[kDictThreads / 64];
+  const uint64_t row0 = (uint64_t)blockIdx.x * kDictRows + (uint64_t)threadIdx.x * kDictPerThread;
+  uint32_t g[kDictPerThread];
+  uint32_t sum = 0;
+#pragma unroll
+  for (int i = 0; i < kDictPerThread; ++i) {
+    g[i] = row0 + i < q.rows ? q.index[row0 + i] : 0xffffffffu;
+    sum += dict_len(q.dict_off, g[i]);
+  }
+  uint32_t total;
+  uint32_t at = q.block_sums[blockIdx.x] + dict_block_scan(sum, wave_sums, &total);
+#pragma unroll
+  for (int i = 0; i < kDictPerThread; ++i) {
+    if (row0 + i >= q.rows) break;
+    q.offsets[row0 + i] = (int32_t)at;
+    if (g[i] != 0xffffffffu) {
+      const uint32_t from = q.dict_off[g[i]], len = q.dict_off[g[i] + 1] - from;
+      for (uint32_t k = 0; k < len; ++k) q.bytes[at + k] = q.dict_bytes[from + k];
+      at += len;
+    }
+    // (the index buffer doubles as the codes' buffer: a row's index is read by this thread alone)
+    if (q.codes) q.codes[row0 + i] = g[i] != 0xffffffffu ? q.remap[g[i]] : 0u;
+  }
+}
+
 }  // namespace
+
+size_t dict_expand_blocks(uint64_t rows) { return (size_t)ceil_div(rows, (uint64_t)kDictRows); }
+
+void launch_dict_expand(prism_gpu_ctx* ctx, const DictExpand& q, hipStream_t stream) {
+  if (q.rows == 0) return;
+  const uint32_t n_blocks = (uint32_t)dict_expand_blocks(q.rows);
+  k_dict_lens<<<dim3(n_blocks), dim3(kDictThreads), 0, stream>>>(q);
+  k_dict_scan<<<dim3(1), dim3(kDictThreads), 0, stream>>>(q, n_blocks);
+  k_dict_expand<<<dim3(n_blocks), dim3(kDictThreads), 0, stream>>>(q);
+  PRISM_HIP(hipGetLastError());
+}
 
 void launch_synth_url(prism_gpu_ctx* ctx, const int32_t* offsets, uint8_t* bytes, uint64_t n_rows, uint64_t first_row,
                       int64_t p0, int64_t p1, uint64_t column_key) {

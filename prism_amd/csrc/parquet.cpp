@@ -305,7 +305,8 @@ void snappy_decompress(const uint8_t* src, size_t n, std::vector<uint8_t>& out, 
         p += 4;
       }
       if (off == 0 || off > o || o + l > out.size()) bad("Snappy copy out of range");
-      for (size_t i = 0; i < l; ++i) out[o + i] = out[o - off + i];  // may overlap: byte by byte
+      if (off >= l) std::memcpy(&out[o], &out[o - off], l);
+      else for (size_t i = 0; i < l; ++i) out[o + i] = out[o - off + i];  // overlapping: byte by byte
       o += l;
     }
   }
@@ -331,12 +332,20 @@ void rle_decode(const uint8_t* p, const uint8_t* end, int bit_width, size_t coun
       const uint8_t* b = v.p;
       uint64_t bitpos = 0;
       const uint64_t values = groups * 8;
-      for (uint64_t i = 0; i < values && n < count; ++i, bitpos += bit_width) {
+      const uint64_t mask = (1ull << bit_width) - 1ull;
+      const uint64_t take = std::min<uint64_t>(values, count - n);
+      uint64_t i = 0;
+      // (whole 8-byte loads while they stay inside the run, then byte-exact ones)
+      for (; i < take && (bitpos >> 3) + 8 <= bytes; ++i, bitpos += bit_width) {
+        uint64_t word;
+        std::memcpy(&word, b + (bitpos >> 3), 8);
+        out[n++] = (uint32_t)((word >> (bitpos & 7)) & mask);
+      }
+      for (; i < take; ++i, bitpos += bit_width) {
         uint64_t word = 0;
         const uint64_t byte0 = bitpos >> 3;
-        const int avail = (int)std::min<uint64_t>(8, bytes - byte0);
-        std::memcpy(&word, b + byte0, avail);
-        out[n++] = (uint32_t)((word >> (bitpos & 7)) & ((1ull << bit_width) - 1ull));
+        std::memcpy(&word, b + byte0, (size_t)std::min<uint64_t>(8, bytes - byte0));
+        out[n++] = (uint32_t)((word >> (bitpos & 7)) & mask);
       }
       v.p += bytes;
     } else {
@@ -360,6 +369,13 @@ struct PqColumn {
   std::vector<uint8_t> validity;  // bit per row, all rows present
   int64_t nulls = 0;
   int64_t rows = 0;
+  // A string column whose every data page is dictionary encoded may stay in that form (for the
+  // table loader, which expands it on the device): one index per row (0 where the row is NULL)
+  // and the chunk's dictionary, instead of offsets and bytes.
+  bool dict_form = false;
+  std::vector<int32_t> index;
+  std::vector<int32_t> dict_offsets;  // entries + 1
+  std::vector<uint8_t> dict_bytes;
 };
 
 struct PageHeader {
@@ -407,16 +423,25 @@ struct Dictionary {
   size_t size() const { return ints.empty() ? spans.size() : ints.size(); }
 };
 
-void store_fixed(PqColumn& col, int64_t v, const Leaf& leaf) {
-  if (leaf.ts_unit == 2 || (leaf.ts_unit == 0 && leaf.converted == 10)) v /= 1000;  // us -> ms, as arrow's cast does
-  else if (leaf.ts_unit == 3) v /= 1000000;
-  const int w = col.type.width;
-  const size_t at = col.values.size();
-  col.values.resize(at + w);
-  std::memcpy(&col.values[at], &v, w);  // little endian: the low bytes are the narrow value
+// Divisor that brings a timestamp of the leaf's unit to milliseconds (as arrow's cast does).
+int64_t timestamp_divisor(const Leaf& leaf) {
+  if (leaf.ts_unit == 2 || (leaf.ts_unit == 0 && leaf.converted == 10)) return 1000;  // us
+  if (leaf.ts_unit == 3) return 1000000;                                               // ns
+  return 1;
 }
 
-void decode_chunk(const uint8_t* file, size_t len, const Leaf& leaf, const ChunkMeta& cm, int64_t rows, PqColumn& col) {
+void set_bits(std::vector<uint8_t>& bits, int64_t from, int64_t n) {
+  int64_t i = from;
+  const int64_t end = from + n;
+  for (; i < end && (i & 7); ++i) bits[(size_t)i >> 3] |= (uint8_t)(1u << (i & 7));
+  if (end - i >= 8) {
+    std::memset(&bits[(size_t)i >> 3], 0xff, (size_t)((end - i) >> 3));
+    i += (end - i) & ~(int64_t)7;
+  }
+  for (; i < end; ++i) bits[(size_t)i >> 3] |= (uint8_t)(1u << (i & 7));
+}
+
+void decode_chunk(const uint8_t* file, size_t len, const Leaf& leaf, const ChunkMeta& cm, int64_t rows, PqColumn& col, bool keep_dict = false) {
   if (cm.codec != 0 && cm.codec != 1) unsupported("column `" + leaf.name + "` uses a codec other than UNCOMPRESSED / SNAPPY");
   if (cm.physical != leaf.physical) bad("column chunk and schema disagree on the type of `" + leaf.name + "`");
   const bool strings = leaf.physical == kByteArray;
@@ -430,8 +455,21 @@ void decode_chunk(const uint8_t* file, size_t len, const Leaf& leaf, const Chunk
   std::vector<uint8_t> page, levels_buf;
   std::vector<uint32_t> def, idx;
   int64_t seen = 0;
-  if (strings) col.offsets.push_back(0);
+  bool as_index = strings && keep_dict;  // until a data page turns out not to be dictionary encoded
+  const int w = col.type.width;
+  const int64_t divisor = strings ? 1 : timestamp_divisor(leaf);
+  if (strings) {
+    if (as_index) col.index.reserve((size_t)rows);
+    else { col.offsets.reserve((size_t)rows + 1); col.offsets.push_back(0); }
+  } else {
+    col.values.assign((size_t)rows * (size_t)w, 0);  // (NULL rows keep the zero)
+  }
   col.validity.assign((size_t)(rows + 7) / 8, 0);
+  auto append_string = [&](const uint8_t* p, uint32_t l) {
+    if (col.bytes.size() + l > 0x7fffffffull) unsupported("more than 2 GiB of string data in one row group of `" + leaf.name + "`");
+    col.bytes.insert(col.bytes.end(), p, p + l);
+    col.offsets.push_back((int32_t)col.bytes.size());
+  };
   while (seen < cm.num_values) {
     if (pos >= chunk_end) bad("column chunk of `" + leaf.name + "` ends before its values do");
     Thrift t{file + pos, file + chunk_end};
@@ -525,64 +563,89 @@ void decode_chunk(const uint8_t* file, size_t len, const Leaf& leaf, const Chunk
       for (uint32_t k : idx)
         if (k >= dict.size()) bad("dictionary index out of range in `" + leaf.name + "`");
     }
+    if (present == n) set_bits(col.validity, seen, (int64_t)n);
+    else {
+      for (size_t i = 0; i < n; ++i)
+        if (def[i]) { const int64_t row = seen + (int64_t)i; col.validity[(size_t)row >> 3] |= (uint8_t)(1u << (row & 7)); }
+      col.nulls += (int64_t)(n - present);
+    }
+    const bool dense = present == n;
     const uint8_t* p = vals;
     size_t k = 0;  // position among the present values
-    for (size_t i = 0; i < n; ++i) {
-      const int64_t row = seen + (int64_t)i;
-      const bool ok = !leaf.optional || def[i] != 0;
-      if (ok) col.validity[(size_t)row >> 3] |= (uint8_t)(1u << (row & 7));
-      else ++col.nulls;
-      if (strings) {
-        if (ok) {
-          const uint8_t* s;
-          uint32_t l;
+    if (strings) {
+      if (as_index && !by_dict) {
+        // a page that fell back to PLAIN: the rows so far are expanded, and the chunk is decoded to offsets and bytes
+        col.offsets.reserve((size_t)rows + 1);
+        col.offsets.push_back(0);
+        for (int64_t r = 0; r < seen; ++r) {
+          const bool ok = col.validity[(size_t)r >> 3] >> (r & 7) & 1;
+          if (ok) append_string(dict.bytes.data() + dict.spans[(size_t)col.index[(size_t)r]].first, dict.spans[(size_t)col.index[(size_t)r]].second);
+          else col.offsets.push_back((int32_t)col.bytes.size());
+        }
+        col.index.clear();
+        col.index.shrink_to_fit();
+        as_index = false;
+      }
+      if (as_index) {
+        const size_t at = col.index.size();
+        col.index.resize(at + n);
+        int32_t* out = col.index.data() + at;
+        if (dense) for (size_t i = 0; i < n; ++i) out[i] = (int32_t)idx[i];
+        else for (size_t i = 0; i < n; ++i) out[i] = def[i] ? (int32_t)idx[k++] : 0;
+      } else {
+        for (size_t i = 0; i < n; ++i) {
+          if (!dense && !def[i]) { col.offsets.push_back((int32_t)col.bytes.size()); continue; }
           if (by_dict) {
-            s = dict.bytes.data() + dict.spans[idx[k]].first;
-            l = dict.spans[idx[k]].second;
+            append_string(dict.bytes.data() + dict.spans[idx[k]].first, dict.spans[idx[k]].second);
           } else {
             if (vals_end - p < 4) bad("page of `" + leaf.name + "` ends inside a value");
+            uint32_t l;
             std::memcpy(&l, p, 4);
             p += 4;
             if ((uint64_t)l > (uint64_t)(vals_end - p)) bad("value beyond the page in `" + leaf.name + "`");
-            s = p;
+            append_string(p, l);
             p += l;
           }
-          if (col.bytes.size() + l > 0x7fffffffull) unsupported("more than 2 GiB of string data in one row group of `" + leaf.name + "`");
-          col.bytes.insert(col.bytes.end(), s, s + l);
           ++k;
         }
-        col.offsets.push_back((int32_t)col.bytes.size());
+      }
+    } else {
+      const int pw = leaf.physical == kInt32 ? 4 : 8;
+      uint8_t* out = col.values.data() + (size_t)seen * (size_t)w;
+      if (!by_dict && (uint64_t)(vals_end - p) / (uint64_t)pw < (uint64_t)present) bad("page of `" + leaf.name + "` ends inside a value");
+      if (!by_dict && dense && divisor == 1 && pw == w) {
+        std::memcpy(out, p, n * (size_t)w);  // PLAIN values of the column's own width, none missing
       } else {
-        int64_t v = 0;
-        if (ok) {
-          if (by_dict) {
-            v = dict.ints[idx[k]];
-          } else if (leaf.physical == kInt32) {
-            if (vals_end - p < 4) bad("page of `" + leaf.name + "` ends inside a value");
-            int32_t x;
-            std::memcpy(&x, p, 4);
-            v = x;
-            p += 4;
-          } else {
-            if (vals_end - p < 8) bad("page of `" + leaf.name + "` ends inside a value");
-            std::memcpy(&v, p, 8);
-            p += 8;
-          }
+        for (size_t i = 0; i < n; ++i) {
+          if (!dense && !def[i]) continue;
+          int64_t v;
+          if (by_dict) v = dict.ints[idx[k]];
+          else if (pw == 4) { int32_t x; std::memcpy(&x, p + k * 4, 4); v = x; }
+          else std::memcpy(&v, p + k * 8, 8);
           ++k;
+          if (divisor != 1) v /= divisor;
+          std::memcpy(out + i * (size_t)w, &v, (size_t)w);  // little endian: the low bytes are the narrow value
         }
-        store_fixed(col, v, leaf);
       }
     }
     seen += (int64_t)n;
   }
   if (seen != rows) bad("column `" + leaf.name + "` holds " + std::to_string(seen) + " values for " + std::to_string(rows) + " rows");
   col.rows = rows;
+  if (as_index) {
+    col.dict_form = true;
+    col.dict_offsets.reserve(dict.spans.size() + 1);
+    for (const auto& sp : dict.spans) col.dict_offsets.push_back((int32_t)sp.first);  // (the spans lie in dict.bytes in order, end to end)
+    col.dict_offsets.push_back((int32_t)dict.bytes.size());
+    col.dict_bytes = std::move(dict.bytes);
+  }
 }
 
 // ---- Arrow export of decoded row groups ---------------------------------------------------------
 struct PqOwner {
   std::vector<PqColumn> cols;
   std::vector<ArrowArray> children;
+  std::vector<ArrowArray> dictionaries;  // of the children in dictionary form
   std::vector<ArrowArray*> child_ptrs;
   std::vector<std::vector<const void*>> buffers;
   const void* top_buffers[1] = {nullptr};
@@ -600,14 +663,29 @@ void export_columns(std::vector<PqColumn>&& cols, int64_t rows, ArrowArray* out)
   const size_t n = owner->cols.size();
   owner->children.resize(n);
   owner->child_ptrs.resize(n);
-  owner->buffers.resize(n);
+  owner->buffers.resize(2 * n);
+  owner->dictionaries.resize(n);
   for (size_t c = 0; c < n; ++c) {
     PqColumn& col = owner->cols[c];
     ArrowArray& a = owner->children[c];
     std::memset(&a, 0, sizeof(a));
     auto& b = owner->buffers[c];
     b.push_back(col.nulls ? (const void*)col.validity.data() : nullptr);
-    if (col.type.is_string) {
+    if (col.dict_form) {
+      // Int32 indices; the values are the dictionary child (a Utf8 / Binary array without NULLs)
+      b.push_back(col.index.empty() ? (const void*)"" : (const void*)col.index.data());
+      ArrowArray& d = owner->dictionaries[c];
+      std::memset(&d, 0, sizeof(d));
+      auto& db = owner->buffers[n + c];
+      db.push_back(nullptr);
+      db.push_back(col.dict_offsets.data());
+      db.push_back(col.dict_bytes.empty() ? (const void*)"" : (const void*)col.dict_bytes.data());
+      d.length = (int64_t)col.dict_offsets.size() - 1;
+      d.n_buffers = 3;
+      d.buffers = db.data();
+      d.release = release_pq_child;
+      a.dictionary = &d;
+    } else if (col.type.is_string) {
       b.push_back(col.offsets.data());
       b.push_back(col.bytes.empty() ? (const void*)"" : (const void*)col.bytes.data());
     } else {
@@ -717,7 +795,9 @@ void table_append_parquet(prism_gpu_table* table, uint32_t partition_id, const v
           PqColumn& col = cols[f];
           col.type = table->fields[f];
           if (leaf_of[f] >= 0) {
-            decode_chunk(file, len, fm.leaves[leaf_of[f]], rg.chunks[leaf_of[f]], rg.num_rows, col);
+            // (string chunks stay dictionary encoded where the file has them so: table_append maps
+            // a dictionary's values to the table's codes once, and the rows are expanded on the device)
+            decode_chunk(file, len, fm.leaves[leaf_of[f]], rg.chunks[leaf_of[f]], rg.num_rows, col, /*keep_dict=*/true);
           } else {
             col.rows = rg.num_rows;
             col.nulls = rg.num_rows;

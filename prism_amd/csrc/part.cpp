@@ -97,6 +97,7 @@ void ctx_destroy(prism_gpu_ctx* ctx) {
     if (ctx->stage[i]) (void)hipHostFree(ctx->stage[i]);
     if (ctx->stage_done[i]) (void)hipEventDestroy(ctx->stage_done[i]);
   }
+  if (ctx->load_tmp) (void)hipFree(ctx->load_tmp);
   if (ctx->result_pinned) (void)hipHostFree(ctx->result_pinned);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);

@@ -292,7 +292,6 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
     // ---- string column: raw representation + table-wide dictionary codes ----
     ColumnDict& dict = t->dicts[ci];
     std::vector<uint32_t> codes;
-    if (dict.alive) codes.resize((size_t)n);
     // Chunks of a streaming partition whose every batch is dictionary encoded keep only the
     // codes (the table-wide dictionary of such a table stays small: it is the union of the
     // batches' dictionaries).
@@ -301,7 +300,13 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
       const ArrowArray* a = &views[b][ci];
       codes_only = a->length == 0 || (a->dictionary != nullptr && a->dictionary->length <= 4096);
     }
-    std::vector<int32_t> offs(codes_only ? 1 : (size_t)n + 1);
+    // Input that is dictionary encoded throughout is not expanded here: its indices and
+    // dictionaries are staged, and kernels write the offsets, the bytes and the codes.
+    bool device_expand = !codes_only && ctx->dict_expand_device.load(std::memory_order_relaxed) != 0;
+    for (size_t b = 0; b < n_batches && device_expand; ++b) device_expand = views[b][ci].length == 0 || views[b][ci].dictionary != nullptr;
+    std::vector<uint32_t> index, cat_off, remap_all;  // (device_expand) rows' positions in the dictionaries laid end to end
+    if (dict.alive && !device_expand) codes.resize((size_t)n);
+    std::vector<int32_t> offs(codes_only || device_expand ? 1 : (size_t)n + 1);
     offs[0] = 0;
     // bytes of the chunk: total first (it sizes the device buffer), then the pieces
     uint64_t total = 0;
@@ -329,6 +334,31 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
         if (dict.alive) {
           remap.resize((size_t)d->length);
           for (int64_t k = 0; k < d->length; ++k) remap[(size_t)k] = dict.id_of(dbytes + doff[k], (size_t)(doff[k + 1] - doff[k]));
+        }
+        if (device_expand) {
+          if (cat_off.empty()) { cat_off.push_back(0); index.resize((size_t)n); }
+          const uint64_t base = cat_off.size() - 1;
+          if (base + (uint64_t)d->length >= 0xffffffffull) fail(PRISM_GPU_EUNSUPPORTED, "the dictionaries of one chunk of " + f.name + " hold 2^32 entries or more");
+          for (int64_t k = 0; k < d->length; ++k) {
+            if (doff[k + 1] < doff[k]) fail(PRISM_GPU_EINVAL, "dictionary offsets of " + f.name + " decrease");
+            const uint64_t end = (uint64_t)cat_off.back() + (uint64_t)(doff[k + 1] - doff[k]);
+            if (end > 0x7fffffffull) fail(PRISM_GPU_EUNSUPPORTED, "the dictionaries of one chunk of " + f.name + " exceed 2 GiB");
+            cat_off.push_back((uint32_t)end);
+          }
+          if (d->length > 0 && doff[d->length] > doff[0]) pieces.push_back({(const uint8_t*)dbytes + doff[0], (size_t)(doff[d->length] - doff[0])});
+          remap_all.insert(remap_all.end(), remap.begin(), remap.end());
+          const uint32_t* len_at = cat_off.data() + base;
+          for (int64_t i = 0; i < nb; ++i) {
+            const bool valid = !vbits || bit_at(vbits, a->offset + i);
+            if (!valid) { index[(size_t)(row0 + i)] = 0xffffffffu; continue; }
+            const int32_t k = idx[i];
+            if (k < 0 || k >= d->length) fail(PRISM_GPU_EINVAL, "dictionary index out of range in " + f.name);
+            index[(size_t)(row0 + i)] = (uint32_t)(base + (uint64_t)k);
+            total += len_at[k + 1] - len_at[k];
+          }
+          if (total > 0x7fffffffull) fail(PRISM_GPU_EUNSUPPORTED, "string data of one chunk exceeds 2 GiB");
+          row0 += nb;
+          continue;
         }
         if (codes_only) {
           // a streaming chunk whose input is dictionary encoded: the codes are all the kernels
@@ -390,6 +420,54 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
       }
     }
     if (codes_only && !dict.alive) fail(PRISM_GPU_EUNSUPPORTED, "dictionary-encoded column " + f.name + " has more than " + std::to_string(kMaxDictValues) + " distinct values");
+    if (device_expand) {
+      // (pieces holds the dictionaries' bytes here, total the bytes of the expanded column)
+      const size_t n_ent = cat_off.size() - 1, n_blocks = dict_expand_blocks((uint64_t)n);
+      auto pad = [](size_t v) { return (v + 15) & ~(size_t)15; };
+      const size_t off_at = 0, remap_at = off_at + pad(cat_off.size() * 4), sums_at = remap_at + pad(n_ent * 4),
+                   dbytes_at = sums_at + pad(n_blocks * 4), index_at = dbytes_at + pad((size_t)cat_off.back()),
+                   need = index_at + (dict.alive ? 0 : (size_t)n * 4);
+      if (ctx->load_tmp_bytes < need) {
+        // (hipFree waits for the device: the kernels of earlier appends no longer read the old block)
+        if (ctx->load_tmp) PRISM_HIP(hipFree(ctx->load_tmp));
+        ctx->load_tmp = nullptr;
+        ctx->load_tmp_bytes = 0;
+        const size_t grown = pow2_ceil(need);
+        hipError_t e = hipMalloc(&ctx->load_tmp, grown);
+        if (e != hipSuccess) fail(e == hipErrorOutOfMemory ? PRISM_GPU_EOOM : PRISM_GPU_EHIP, std::string("hipMalloc of the loader's scratch failed: ") + hipGetErrorString(e));
+        ctx->load_tmp_bytes = grown;
+      }
+      uint8_t* tmp = (uint8_t*)ctx->load_tmp;
+      dc.values = dev_alloc(t, ((size_t)n + 1) * 4);
+      dc.bytes = (uint8_t*)dev_alloc(t, (size_t)total);
+      dc.n_bytes = total;
+      if (dict.alive) dc.codes = (uint32_t*)dev_alloc(t, (size_t)n * 4);
+      w.begin(tmp + off_at);
+      w.write(cat_off.data(), cat_off.size() * 4);
+      if (dict.alive) {
+        w.begin(tmp + remap_at);
+        w.write(remap_all.data(), n_ent * 4);
+      }
+      w.begin(tmp + dbytes_at);
+      for (const Piece& pc : pieces) w.write(pc.p, pc.n);
+      uint32_t* d_index = dict.alive ? dc.codes : (uint32_t*)(tmp + index_at);
+      w.begin(d_index);
+      w.write(index.data(), (size_t)n * 4);
+      w.flush();
+      DictExpand q;
+      q.index = d_index;
+      q.rows = (uint64_t)n;
+      q.dict_off = (const uint32_t*)(tmp + off_at);
+      q.dict_bytes = tmp + dbytes_at;
+      q.remap = (const uint32_t*)(tmp + remap_at);
+      q.codes = dict.alive ? dc.codes : nullptr;
+      q.offsets = (int32_t*)dc.values;
+      q.bytes = dc.bytes;
+      q.block_sums = (uint32_t*)(tmp + sums_at);
+      launch_dict_expand(ctx, q, ctx->copy_stream);
+      launch_col_stats(ctx, dict.alive ? (const void*)dc.codes : dc.values, dc.validity, 4, true, (uint64_t)n, &ch.d_stats[ci], ctx->copy_stream);
+      continue;
+    }
     if (!codes_only) {
       dc.values = dev_alloc(t, offs.size() * 4);
       w.begin(dc.values);

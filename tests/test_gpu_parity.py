@@ -236,6 +236,45 @@ def test_dictionary_encoded_input(gpu_ctx, oracle):
         g.close()
 
 
+@pytest.mark.parametrize("on_device", [1, 0])
+def test_dictionary_encoded_input_is_expanded_to_the_same_column(gpu_ctx, oracle, on_device):
+    """Dictionary arrays (Int32 indices, NULL rows, several batches with dictionaries of their
+    own) become the same offsets / bytes / codes whether kernels expand them (the default) or the
+    host does: a column of few values is read through its codes (GROUP BY, =), one of more than
+    65536 values has no codes and is read through its bytes (LIKE over the raw strings)."""
+    import numpy as np
+
+    from prism_amd.engine import Plan, Table
+
+    n = 90_000
+    rng = np.random.default_rng(5)
+    ids = rng.integers(0, 70_000, n)
+    urls = pa.array([None if i % 97 == 0 else f"http://h{v % 13}.example/{'google' if v % 7 == 0 else 'q'}/{v}" for i, v in enumerate(ids)])
+    svc = pa.array([None if i % 41 == 0 else f"svc-{v % 23:02d}" for i, v in enumerate(ids)])
+    t = pa.table({"url": urls, "service": svc, "value": pa.array(rng.integers(-50, 50, n), pa.int64())})
+    gpu_ctx.set_option("dict_expand_device", on_device)
+    g = Table(gpu_ctx, t.schema)
+    try:
+        at = 0
+        for i, rows in enumerate([1, 40_000, 4097, n - 44_098]):  # (every slice is encoded by itself: dictionaries differ)
+            part = t.slice(at, rows)
+            at += rows
+            enc = pa.table({"url": part.column("url").combine_chunks().dictionary_encode(),
+                            "service": part.column("service").combine_chunks().dictionary_encode(), "value": part.column("value")})
+            g.append(i % 2, enc.to_batches()[0])
+        for q, nk in [(QueryPlan([count_star(), sum_("value")], keys=["service"], predicate=col("url").like("%google%")), 1),
+                      (QueryPlan([count_star()], predicate=col("url").like("http://h3.%") & (col("service") == "svc-03")), 0),
+                      (QueryPlan([count_star(), min_("value")], predicate=col("url").is_null() | col("service").is_null()), 0)]:
+            plan = Plan(gpu_ctx, t.schema, q)
+            try:
+                assert_tables_match(plan.execute(g), oracle.execute(t, q), nk)
+            finally:
+                plan.close()
+    finally:
+        gpu_ctx.set_option("dict_expand_device", 1)
+        g.close()
+
+
 def test_wrapping_sum_and_extremes(gpu_ctx, oracle):
     from prism_amd.engine import Plan, Table
 
