@@ -42,13 +42,14 @@ def stream_feed(args) -> int:
     beforehand.  The rate is bounded by PCIe, not HBM, and priced against that."""
     import subprocess
 
-    if args.workload != "C2" or int(os.environ.get("WORLD_SIZE", "1")) != 1:
-        raise SystemExit("--feed stream measures the C2 query on one GPU")
+    if args.workload not in ("C2", "C3") or int(os.environ.get("WORLD_SIZE", "1")) != 1:
+        raise SystemExit("--feed stream measures the C2 or the C3 query on one GPU")
     exe = os.path.join(ROOT, "tests", "c", "stream_bench")
     if not os.path.exists(exe):
         raise SystemExit(f"{exe} is not built (python -c 'import __graft_entry__ as g; g.build()')")
-    rows = args.rows or 1_000_000_000
-    r = subprocess.run([exe, str(rows), str(args.feed_threads), str(args.steps), "8192"], capture_output=True, text=True)
+    c3 = args.workload == "C3"
+    rows = args.rows or (100_000_000 if c3 else 1_000_000_000)
+    r = subprocess.run([exe, str(rows), str(args.feed_threads), str(args.steps), "8192", "c3" if c3 else "c2"], capture_output=True, text=True)
     if r.returncode != 0:
         raise SystemExit(f"stream_bench failed ({r.returncode}): {r.stderr.strip()}")
     m = json.loads(r.stdout.strip().splitlines()[-1])
@@ -65,8 +66,10 @@ def stream_feed(args) -> int:
         "vs_baseline": None,
         "dtype": "int64",
         "data": "synthetic",
-        "config": {"workload": "C2: date_bin(1 minute, timestamp), service -> COUNT(*), SUM(value), MAX(value); "
-                               "service dictionary encoded, batches of 8192 rows in pageable host memory",
+        "config": {"workload": ("C3: GROUP BY UserID -> COUNT(*) as PARTIAL state per partition, merged with ORDER BY COUNT(*) DESC LIMIT 10 (`groups`: rows of the PARTIAL states); ids log-uniform over 2^24 ranks, "
+                                "batches of 8192 rows in pageable host memory") if c3 else
+                               ("C2: date_bin(1 minute, timestamp), service -> COUNT(*), SUM(value), MAX(value); "
+                                "service dictionary encoded, batches of 8192 rows in pageable host memory"),
                    "feed": "stream", "total_rows": rows, "partitions": m["threads"], "batch_rows": m["batch_rows"],
                    "groups": m["groups"]},
         "roofline": None,

@@ -220,6 +220,15 @@ void prism_gpu_ctx_free(prism_gpu_ctx* ctx);
  *                    array; the dictionary-encoded chunks of a Parquet file) is expanded into
  *                    offsets and bytes on the host; 1 (default): its indices and dictionaries are
  *                    staged and kernels write the offsets, the bytes and the table-wide codes
+ *   "stream_chunk_rows" rows a streaming partition gathers before it stages them as one chunk
+ *                    (default 1048576; 1..2^28)
+ *   "stream_agg_chunks" staged chunks a streaming partition that keeps its groups in HBM lets gather
+ *                    before it aggregates them in one pass (default 8; 1..256)
+ *   "stream_state"   0: a streaming partition (prism_gpu_partition_open) aggregates every chunk of about
+ *                    2^20 rows into a PARTIAL batch on the host and merges the batches in finish;
+ *                    1 (default): plans with a GROUP BY and no COUNT(DISTINCT) keep one group table
+ *                    per partition in HBM, chunk results are folded into it on the device, and a
+ *                    PARTIAL batch is only made when a chunk's keys fall outside the table's layout
  *   "parquet_threads" threads that decode the column chunks of one Parquet row group in
  *                    prism_gpu_table_append_parquet (default 4; 1..64)
  *   "shard_distinct" 0: prism_gpu_execute_sharded always builds a COUNT(DISTINCT)'s set of pairs as a

@@ -79,6 +79,9 @@ struct prism_gpu_ctx {
   std::atomic<int> contains_windows{1};              // 0: substring search always by the byte-wise prefilter
   std::atomic<int> parquet_threads{4};               // threads that decode the column chunks of a Parquet row group
   std::atomic<int> dict_expand_device{1};            // 0: dictionary-encoded string input is expanded into offsets + bytes on the host
+  std::atomic<uint64_t> stream_chunk_rows{1ull << 20};  // rows a streaming partition gathers before it stages a chunk
+  std::atomic<int> stream_agg_chunks{8};             // staged chunks a streaming partition lets gather before it aggregates them in one pass
+  std::atomic<int> stream_state{1};                  // 0: a streaming partition turns every chunk into a PARTIAL batch instead of keeping one group table in HBM
   std::atomic<int> shard_distinct{1};                // 0: a sharded COUNT(DISTINCT) always exchanges the set of pairs it built as a hash table in HBM
   std::atomic<int> sharded_fail_phase{0};            // tests: prism_gpu_execute_sharded fails on purpose in this local phase (1..5) on this context's rank
 

@@ -71,6 +71,8 @@ void free_chunk_memory(prism_gpu_table* t, Chunk& ch);
 void table_synth(prism_gpu_table* t, uint32_t partition_id, uint64_t seed, uint64_t first_row, uint64_t n_rows,
                  uint64_t total_rows, const prism_gpu_synth_col* cols, uint32_t n_cols);
 void table_sync_stats(prism_gpu_table* t);
+// Frees the chunks of one partition (the caller knows that no kernel still reads them).
+void table_drop_partition(prism_gpu_table* t, uint32_t partition_id);
 
 // ---- plans --------------------------------------------------------------------
 
@@ -147,7 +149,7 @@ struct prism_gpu_plan {
 
 // One streaming partition (ExecutionPlan::execute(partition) on a thread of its own).  It
 // works on a child context (streams, pinned ring, scratch pool of its own), gathers the
-// incoming batches into chunks of about kPartChunkRows rows, stages a chunk while the one
+// incoming batches into chunks of about 2^20 rows (option "stream_chunk_rows"), stages a chunk while the one
 // before it is aggregated into PARTIAL state, and merges the states at the end.
 struct prism_gpu_part {
   prism_gpu_plan* plan = nullptr;
@@ -157,9 +159,17 @@ struct prism_gpu_part {
   uint64_t pending_rows = 0, rows_total = 0, chunks_done = 0;
   std::unique_ptr<prism_gpu_table> staged;    // the chunk in flight: staged, not yet aggregated
   std::unique_ptr<prism_gpu_table> partials;  // PARTIAL state of the chunks aggregated so far
+  // Plain GROUP BY plans keep the partition's groups in HBM instead (part.cpp):
+  bool keeps_state = false;
+  std::unique_ptr<prism_gpu_table> table;     // the chunks in flight, and the dictionaries of the whole partition
+  uint32_t next_id = 0;                       // chunks are told apart by a number of their own
+  std::vector<uint32_t> staged_ids;           // staged, not yet aggregated (the last one's copies may be under way)
+  prism_gpu_state* state = nullptr;           // the groups of the chunks aggregated so far
+  std::vector<prism_gpu_col_stats> layout_stats;  // the column statistics its keys are packed from
+  int widen = 16;                             // how far beyond a chunk's statistics the next layout reaches
+  uint64_t state_chunks = 0;
   ~prism_gpu_part();
 };
-constexpr uint64_t kPartChunkRows = 1ull << 20;
 
 namespace prism {
 
@@ -207,7 +217,14 @@ struct DistinctShard {
 void scan_stats(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions,
                 prism_gpu_col_stats* out);
 prism_gpu_state* aggregate_state(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids,
-                                 size_t n_partitions, const prism_gpu_col_stats* stats, const DistinctShardRequest* shard = nullptr);
+                                 size_t n_partitions, const prism_gpu_col_stats* stats, const DistinctShardRequest* shard = nullptr,
+                                 prism_gpu_ctx* ctx_override = nullptr);
+// The groups of `src` folded into `dst` (states of one plan built on one context from the same
+// column statistics).  False, and nothing done, when the two tables differ in kind (a dense
+// and a hashed one, dense tables of different sizes) or hold COUNT(DISTINCT) pairs.
+bool state_merge_state(prism_gpu_state* dst, prism_gpu_state* src);
+// The state's groups as a RecordBatch: the plan's result rows, or (partial) its PARTIAL state columns.
+void state_emit(prism_gpu_state* st, bool partial, ArrowArray* out);
 // The shard a state holds (null: the state is a table).
 DistinctShard* state_shard(prism_gpu_state* st);
 // The owner's part: `records` holds, for each of `world` ranks, the distinct records of this

@@ -1644,6 +1644,7 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggPar
 // A group table kept in HBM between prism_gpu_aggregate and prism_gpu_state_finish.
 struct prism_gpu_state {
   prism_gpu_plan* plan = nullptr;
+  prism_gpu_ctx* ctx = nullptr;  // the context the table was built on: the plan's, or the child context of a streaming partition
   prism_gpu_table* table = nullptr;
   std::vector<prism::KeySrc> keys;
   prism::KeyLayout layout;
@@ -2252,6 +2253,7 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       collect_timings(ctx);
       auto st = std::make_unique<prism_gpu_state>();
       st->plan = plan;
+      st->ctx = ctx;
       st->table = table;
       st->keys = keys;
       st->layout = layout;
@@ -2536,7 +2538,7 @@ namespace {
 
 void state_compact(prism_gpu_state* st) {
   if (st->compacted) return;
-  prism_gpu_ctx* ctx = st->plan->ctx;
+  prism_gpu_ctx* ctx = st->ctx;
   const GroupTable& g = st->gt;
   Scratch d_count(ctx, 256);
   PRISM_HIP(hipMemsetAsync(d_count.p, 0, 8, ctx->stream));
@@ -2599,10 +2601,54 @@ void scan_stats(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* pa
 }
 
 prism_gpu_state* aggregate_state(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids,
-                                 size_t n_partitions, const prism_gpu_col_stats* stats, const DistinctShardRequest* shard) {
+                                 size_t n_partitions, const prism_gpu_col_stats* stats, const DistinctShardRequest* shard,
+                                 prism_gpu_ctx* ctx_override) {
   prism_gpu_state* st = nullptr;
-  execute_impl(plan, table, partition_ids, n_partitions, false, nullptr, stats, &st, false, nullptr, nullptr, shard);
+  execute_impl(plan, table, partition_ids, n_partitions, false, nullptr, stats, &st, false, ctx_override, nullptr, shard);
   return st;
+}
+
+bool state_merge_state(prism_gpu_state* dst, prism_gpu_state* src) {
+  prism_gpu_ctx* ctx = dst->ctx;
+  bind(ctx);
+  if (dst->distinct || src->distinct || dst->ctx != src->ctx || dst->gt.n_slots != src->gt.n_slots || dst->slot_ops != src->slot_ops ||
+      dst->gt.key_words != src->gt.key_words)
+    return false;
+  if (dst->gt.dense != src->gt.dense) return false;
+  if (dst->gt.dense) {
+    if (dst->gt.capacity != src->gt.capacity) return false;
+    // entry by entry: the source's entries are their own keys
+    MergeParams mp = merge_params(dst, dst->gt);
+    mp.src_keys = nullptr;
+    mp.src_state = src->gt.state.as<int64_t>();
+    mp.src_stride = src->gt.capacity + 1;
+    mp.n = src->gt.capacity;
+    launch_merge_packed(ctx, mp);
+    PRISM_HIP(hipStreamSynchronize(ctx->stream));
+    collect_timings(ctx);
+    return true;
+  }
+  const StateView v = state_view(src);
+  state_merge_rows(dst, v.keys, v.keys_hi, v.state, v.entries);
+  return true;
+}
+
+void state_emit(prism_gpu_state* st, bool partial, ArrowArray* out) {
+  if (!partial) { state_finish(st, out); return; }
+  prism_gpu_plan* plan = st->plan;
+  prism_gpu_ctx* ctx = st->ctx;
+  bind(ctx);
+  if (st->distinct) fail(PRISM_GPU_EINTERNAL, "the PARTIAL form of a COUNT(DISTINCT) state is not read from a device state");
+  HostTimer whole(ctx, "host:state_finish");
+  std::vector<OutColumn> cols = make_columns(plan->partial_fields);
+  const uint64_t groups = emit_groups(ctx, plan, st->table, st->keys, st->layout, st->low, st->gt, true, cols);
+  PRISM_HIP(hipStreamSynchronize(ctx->stream));
+  collect_timings(ctx);
+  {
+    std::lock_guard<std::mutex> g(ctx->mu);
+    ctx->stats.groups_out += groups;
+  }
+  export_record_batch(cols, out);
 }
 
 DistinctShard* state_shard(prism_gpu_state* st) { return st->shard.get(); }
@@ -2610,13 +2656,14 @@ DistinctShard* state_shard(prism_gpu_state* st) { return st->shard.get(); }
 prism_gpu_state* distinct_shard_merge(prism_gpu_state* local, const uint64_t* records, uint64_t n_records, const uint64_t* counts64,
                                       const uint64_t* recv_start, uint32_t n_own, int world, int rank) {
   prism_gpu_plan* plan = local->plan;
-  prism_gpu_ctx* ctx = plan->ctx;
+  prism_gpu_ctx* ctx = local->ctx;
   bind(ctx);
   const DistinctShard* sh = local->shard.get();
   if (!sh) fail(PRISM_GPU_EINTERNAL, "not the distinct records of a sharded COUNT(DISTINCT)");
   if (n_records >= (1ull << 32)) fail(PRISM_GPU_EUNSUPPORTED, "more than 2^32 distinct records meet on one rank");
   auto st = std::make_unique<prism_gpu_state>();
   st->plan = plan;
+  st->ctx = ctx;
   st->table = local->table;
   st->keys = local->keys;
   st->layout = local->layout;  // (the pairs' layout: the outer rows are unpacked relative to it)
@@ -2664,7 +2711,7 @@ prism_gpu_state* distinct_shard_merge(prism_gpu_state* local, const uint64_t* re
 }
 
 void state_describe(prism_gpu_state* st, prism_gpu_state_info* out) {
-  bind(st->plan->ctx);
+  bind(st->ctx);
   if (st->distinct || st->gt.key_words != 1)
     fail(PRISM_GPU_EUNSUPPORTED, "states of COUNT(DISTINCT) plans and of keys wider than 64 bits are exchanged by "
                                  "prism_gpu_execute_sharded only: they can be finished, not exported");
@@ -2687,7 +2734,7 @@ void state_describe(prism_gpu_state* st, prism_gpu_state_info* out) {
 }
 
 void state_export(prism_gpu_state* st, void* device_dst, size_t bytes) {
-  prism_gpu_ctx* ctx = st->plan->ctx;
+  prism_gpu_ctx* ctx = st->ctx;
   bind(ctx);
   prism_gpu_state_info info;
   state_describe(st, &info);
@@ -2708,7 +2755,7 @@ void state_export(prism_gpu_state* st, void* device_dst, size_t bytes) {
 }
 
 void state_import(prism_gpu_state* st, const void* device_src, size_t bytes) {
-  prism_gpu_ctx* ctx = st->plan->ctx;
+  prism_gpu_ctx* ctx = st->ctx;
   bind(ctx);
   if (!st->gt.dense) fail(PRISM_GPU_EINVAL, "only a dense state can be replaced; merge rows into a hash state instead");
   const uint64_t n = st->gt.capacity;
@@ -2728,7 +2775,7 @@ void state_merge(prism_gpu_state* st, const void* device_src, uint64_t n_groups)
 
 void state_merge_rows(prism_gpu_state* st, const uint64_t* src_keys, const uint64_t* src_keys_hi, const int64_t* src_state,
                       uint64_t n_groups) {
-  prism_gpu_ctx* ctx = st->plan->ctx;
+  prism_gpu_ctx* ctx = st->ctx;
   bind(ctx);
   if (n_groups == 0) return;
   if ((st->gt.key_words == 2) != (src_keys_hi != nullptr)) fail(PRISM_GPU_EINTERNAL, "merged rows and state differ in key width");
@@ -2769,7 +2816,7 @@ void state_merge_rows(prism_gpu_state* st, const uint64_t* src_keys, const uint6
 
 void state_finish(prism_gpu_state* st, ArrowArray* out) {
   prism_gpu_plan* plan = st->plan;
-  prism_gpu_ctx* ctx = plan->ctx;
+  prism_gpu_ctx* ctx = st->ctx;
   bind(ctx);
   HostTimer whole(ctx, "host:state_finish");
   std::vector<OutColumn> cols = make_columns(plan->final_fields);
@@ -2794,16 +2841,17 @@ void state_finish(prism_gpu_state* st, ArrowArray* out) {
 }
 
 void state_free(prism_gpu_state* st) {
-  if (st) bind(st->plan->ctx);
+  if (st) bind(st->ctx);
   delete st;
 }
 
 prism_gpu_state* state_distinct_outer(prism_gpu_state* inner) {
   if (inner->distinct != 1) fail(PRISM_GPU_EINTERNAL, "not the pair set of a COUNT(DISTINCT) plan");
-  prism_gpu_ctx* ctx = inner->plan->ctx;
+  prism_gpu_ctx* ctx = inner->ctx;
   bind(ctx);
   auto st = std::make_unique<prism_gpu_state>();
   st->plan = inner->plan;
+  st->ctx = inner->ctx;
   st->table = inner->table;
   st->keys = inner->keys;
   st->layout = inner->layout;  // (the pairs' layout: the outer rows are unpacked relative to it)
@@ -2818,7 +2866,7 @@ prism_gpu_state* state_distinct_outer(prism_gpu_state* inner) {
 }
 
 StateView state_view(prism_gpu_state* st) {
-  bind(st->plan->ctx);
+  bind(st->ctx);
   StateView v;
   v.plan = st->plan;
   v.dense = st->gt.dense;
@@ -2843,7 +2891,7 @@ StateView state_view(prism_gpu_state* st) {
 
 uint64_t state_leading_rows(prism_gpu_state* st, Scratch& out_keys, Scratch& out_keys_hi, Scratch& out_state) {
   prism_gpu_plan* plan = st->plan;
-  prism_gpu_ctx* ctx = plan->ctx;
+  prism_gpu_ctx* ctx = st->ctx;
   bind(ctx);
   const GroupTable& g = st->gt;
   if (g.dense) fail(PRISM_GPU_EINTERNAL, "leading rows are read from hash states");

@@ -488,9 +488,10 @@ struct MergeParams {
   uint32_t* overflow;
   int n_slots;
   int ops[kMaxSlots];  // SlotOp of each slot
-  const uint64_t* src_keys;
+  const uint64_t* src_keys;   // null: row i has key i (a dense table merged entry by entry)
   const int64_t* src_state;
   uint64_t n;
+  uint64_t src_stride;        // values between two slots of the source (0: n)
   // two-word keys (null otherwise): the table's and the source's high words
   uint64_t* g_keys_hi;
   const uint64_t* src_keys_hi;
@@ -557,6 +558,10 @@ struct DictExpand {
   uint8_t* bytes;
   uint32_t* block_sums;  // dict_expand_blocks(rows) words of scratch
 };
+// codes[r] (an index into the dictionary of r's batch) becomes remap[seg_base[s] + codes[r]], s the
+// segment of row r (seg_row: first rows, ascending, seg_row[0] == 0); NULL rows become 0.
+void launch_dict_codes(prism_gpu_ctx* ctx, uint32_t* codes, const uint64_t* validity, uint64_t rows, const uint32_t* seg_row,
+                       const uint32_t* seg_base, uint32_t n_segs, const uint32_t* remap, hipStream_t stream);
 size_t dict_expand_blocks(uint64_t rows);
 void launch_dict_expand(prism_gpu_ctx* ctx, const DictExpand& q, hipStream_t stream);
 

@@ -432,8 +432,9 @@ __global__ __launch_bounds__(kFoldBlock) void k_distinct_fold_lds(DistinctFoldPa
 // ---- table maintenance --------------------------------------------------------------
 
 __global__ __launch_bounds__(kBlock) void k_merge_packed(MergeParams p) {
+  const uint64_t stride = p.src_stride ? p.src_stride : p.n;
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < p.n; i += (uint64_t)gridDim.x * kBlock) {
-    const uint64_t key = p.src_keys[i];
+    const uint64_t key = p.src_keys ? p.src_keys[i] : i;
     // a dense table is indexed by the key itself: a key beyond it comes from a state that
     // was packed from other statistics, and must not be written anywhere
     if (p.dense && key >= p.capacity) { *p.overflow = 2u; continue; }
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(kBlock) void k_merge_packed(MergeParams p) {
     if (e == ~0ull) continue;
     for (int s = 0; s < p.n_slots; ++s) {
       const int op = p.ops[s];
-      const long long v = p.src_state[(uint64_t)s * p.n + i];
+      const long long v = p.src_state[(uint64_t)s * stride + i];
       if (v == slot_identity(op)) continue;
       // counters merge by addition, like the sums
       atomic_apply(&p.g_state[(uint64_t)s * (p.capacity + 1) + e], (op == kSlotAddOne || op == kSlotAddValid) ? kSlotAddI64 : op, v);

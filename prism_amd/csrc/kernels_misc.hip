@@ -136,7 +136,29 @@ __global__ __launch_bounds__(kDictThreads) void k_dict_expand(DictExpand q) {
   }
 }
 
+// Indices into the batches' dictionaries -> table-wide codes, in place.  Rows [seg_row[s],
+// seg_row[s + 1]) came with the dictionary whose codes start at remap[seg_base[s]].
+__global__ __launch_bounds__(kBlock) void k_dict_codes(uint32_t* codes, const uint64_t* validity, uint64_t rows, const uint32_t* seg_row,
+                                                      const uint32_t* seg_base, uint32_t n_segs, const uint32_t* remap) {
+  for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < rows; r += (uint64_t)gridDim.x * kBlock) {
+    uint32_t lo = 0, hi = n_segs;
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (seg_row[mid] <= r) lo = mid; else hi = mid;
+    }
+    codes[r] = valid_at(validity, r) ? remap[seg_base[lo] + codes[r]] : 0u;
+  }
+}
+
 }  // namespace
+
+void launch_dict_codes(prism_gpu_ctx* ctx, uint32_t* codes, const uint64_t* validity, uint64_t rows, const uint32_t* seg_row,
+                       const uint32_t* seg_base, uint32_t n_segs, const uint32_t* remap, hipStream_t stream) {
+  if (rows == 0) return;
+  uint32_t grid = (uint32_t)std::min<uint64_t>(ceil_div(rows, (uint64_t)kBlock * 4), (uint64_t)ctx->n_cus * 8);
+  k_dict_codes<<<dim3(std::max(1u, grid)), dim3(kBlock), 0, stream>>>(codes, validity, rows, seg_row, seg_base, n_segs, remap);
+  PRISM_HIP(hipGetLastError());
+}
 
 size_t dict_expand_blocks(uint64_t rows) { return (size_t)ceil_div(rows, (uint64_t)kDictRows); }
 

@@ -29,6 +29,7 @@ void copy_options(prism_gpu_ctx* c, prism_gpu_ctx* parent) {
   c->part2_fixed.store(parent->part2_fixed.load());
   c->part_wc_min_rows.store(parent->part_wc_min_rows.load());
   c->contains_windows.store(parent->contains_windows.load());
+  c->dict_expand_device.store(parent->dict_expand_device.load());
 }
 }  // namespace
 
@@ -117,32 +118,180 @@ std::unique_ptr<prism_gpu_table> chunk_table(prism_gpu_ctx* ctx, const std::vect
   return t;
 }
 
-// The staged chunk -> PARTIAL state, kept in part->partials; the chunk's memory goes back to the pool.
-void aggregate_staged(prism_gpu_part* part) {
+// ---- device-resident state ----------------------------------------------------------------
+// A part whose plan is a plain GROUP BY keeps ONE group table in HBM for the whole partition:
+// every staged chunk is aggregated on the device (a table of its own, packed from the part's
+// key layout) and folded into the part's table; nothing leaves the device before `finish`.
+// The layout is fixed from the first chunk's column statistics, widened: a later chunk whose
+// keys or NULLs fall outside it makes the part set its table aside as a PARTIAL batch (the
+// form chunks always took before) and start a new one, widened further each time.
+
+bool plan_keeps_state(const prism_gpu_plan* plan) {
+  return !plan->keys.empty() && !plan->distinct_plan && !plan->mixed && plan->ctx->stream_state.load(std::memory_order_relaxed) != 0;
+}
+
+// The statistics the part's keys are packed from: those of the chunks `seen`, widened by `factor`.
+std::vector<prism_gpu_col_stats> widened_stats(const prism_gpu_part* part, const std::vector<const Chunk*>& seen, int factor) {
+  const prism_gpu_plan* plan = part->plan;
+  const prism_gpu_table* t = part->table.get();
+  std::vector<prism_gpu_col_stats> out(t->fields.size());
+  for (size_t c = 0; c < t->fields.size(); ++c) {
+    out[c].min = 0x7fffffffffffffffll;
+    out[c].max = -0x7fffffffffffffffll - 1;
+    out[c].nulls = 0;
+    for (const Chunk* ch : seen) {
+      out[c].min = std::min<long long>(out[c].min, ch->stats[c].min);
+      out[c].max = std::max<long long>(out[c].max, ch->stats[c].max);
+      out[c].nulls += ch->stats[c].null_count;
+    }
+  }
+  std::vector<bool> is_key(t->fields.size(), false), is_time(t->fields.size(), false);
+  for (const KeyPlan& k : plan->keys) {
+    is_key[(size_t)k.column] = true;
+    if (k.kind == PRISM_KEY_DATE_BIN || t->fields[(size_t)k.column].logical == PRISM_COL_TIMESTAMP) is_time[(size_t)k.column] = true;
+  }
+  for (size_t c = 0; c < t->fields.size(); ++c) {
+    const FieldType& f = t->fields[c];
+    prism_gpu_col_stats& o = out[c];
+    if (!is_key[c]) {
+      // values: only whether the column has NULLs shapes the accumulators; any value is covered
+      o.min = -0x7fffffffffffffffll - 1;
+      o.max = 0x7fffffffffffffffll;
+      continue;
+    }
+    if (o.min > o.max) { o.min = 0; o.max = 0; }  // (a chunk of NULLs only)
+    if (f.is_string) {
+      // dictionary codes are handed out from 0 in order of appearance
+      o.min = 0;
+      o.max = std::max<long long>(255, std::min<long long>((long long)kMaxDictValues, o.max * 4 + 3));
+      continue;
+    }
+    // the type's own limits
+    long long lo = -0x7fffffffffffffffll - 1, hi = 0x7fffffffffffffffll;
+    if (f.width == 2) { lo = f.is_unsigned ? 0 : -32768; hi = f.is_unsigned ? 65535 : 32767; }
+    else if (f.width == 4) { lo = f.is_unsigned ? 0 : -2147483648ll; hi = f.is_unsigned ? 4294967295ll : 2147483647ll; }
+    else if (f.is_unsigned) lo = 0;
+    const __int128 range = (__int128)o.max - (__int128)o.min + 1;
+    // time mostly moves forward within a partition; other keys are as likely to grow either way
+    const __int128 below = is_time[c] ? range : range * (factor / 2), above = is_time[c] ? range * factor : range * (factor / 2);
+    const __int128 nlo = (__int128)o.min - below, nhi = (__int128)o.max + above;
+    o.min = nlo < (__int128)lo ? lo : (long long)nlo;
+    o.max = nhi > (__int128)hi ? hi : (long long)nhi;
+  }
+  return out;
+}
+
+bool stats_cover(const prism_gpu_part* part, const Chunk& ch) {
+  const prism_gpu_plan* plan = part->plan;
+  std::vector<int> used;
+  for (const KeyPlan& k : plan->keys) used.push_back(k.column);
+  for (const AggPlan& a : plan->aggs) if (a.column >= 0) used.push_back(a.column);
+  for (int c : used) {
+    const ColStats& cs = ch.stats[(size_t)c];
+    const prism_gpu_col_stats& o = part->layout_stats[(size_t)c];
+    if (!((cs.min > cs.max || (o.min <= cs.min && cs.max <= o.max)) && (cs.null_count == 0 || o.nulls > 0))) return false;
+  }
+  return true;
+}
+
+void partial_append(prism_gpu_part* part, ArrowArray* state) {
+  if (!part->partials) part->partials = chunk_table(part->ctx, part->plan->partial_fields);
+  table_append(part->partials.get(), 0, state, true);
+  part->chunks_done += 1;
+}
+
+// The part's table leaves the device as one PARTIAL batch (a chunk did not fit its layout).
+void set_state_aside(prism_gpu_part* part) {
+  if (!part->state) return;
+  HostTimer timer(part->ctx, "host:state_aside");
+  ArrowArray batch;
+  std::memset(&batch, 0, sizeof(batch));
+  state_emit(part->state, true, &batch);
+  state_free(part->state);
+  part->state = nullptr;
+  partial_append(part, &batch);
+  part->widen = std::min(part->widen * 4, 1 << 20);
+}
+
+// The staged chunks `ids` -> one group table, folded into the part's.
+void aggregate_into_state(prism_gpu_part* part, const std::vector<uint32_t>& ids) {
+  if (ids.empty()) return;
+  prism_gpu_table* t = part->table.get();
+  table_sync_stats(t);
+  std::vector<const Chunk*> chunks;
+  for (const Chunk& c : t->chunks)
+    for (uint32_t id : ids) if (c.partition_id == id) chunks.push_back(&c);
+  if (chunks.size() != ids.size()) fail(PRISM_GPU_EINTERNAL, "a staged chunk is gone");
+  bool covered = part->state != nullptr;
+  for (const Chunk* ch : chunks) covered = covered && stats_cover(part, *ch);
+  if (part->state && !covered) set_state_aside(part);
+  if (!part->state) part->layout_stats = widened_stats(part, chunks, part->widen);
+  prism_gpu_state* st = aggregate_state(part->plan, t, ids.data(), ids.size(), part->layout_stats.data(), nullptr, part->ctx);
+  if (!part->state) {
+    part->state = st;
+  } else {
+    bool merged = false;
+    try {
+      merged = state_merge_state(part->state, st);
+    } catch (...) {
+      state_free(st);
+      throw;
+    }
+    if (!merged) {
+      // tables of different kinds (the chunks' came out dense, the part's hashed, or the like): both go the PARTIAL way
+      set_state_aside(part);
+      part->state = st;
+    } else {
+      state_free(st);
+    }
+  }
+  for (uint32_t id : ids) table_drop_partition(t, id);
+  part->state_chunks += ids.size();
+}
+
+// Aggregates what is staged: every chunk (`all`), or every chunk but the newest, whose copies
+// are still under way.
+void aggregate_staged(prism_gpu_part* part, bool all) {
+  if (part->keeps_state) {
+    std::vector<uint32_t> ids = part->staged_ids;
+    if (!all && !ids.empty()) ids.pop_back();
+    aggregate_into_state(part, ids);
+    part->staged_ids.erase(part->staged_ids.begin(), part->staged_ids.begin() + (ptrdiff_t)ids.size());
+    return;
+  }
+  // The staged chunk -> PARTIAL state, kept in part->partials; the chunk's memory goes back to the pool.
   if (!part->staged) return;
   ArrowArray state;
   std::memset(&state, 0, sizeof(state));
   execute_plan_on(part->ctx, part->plan, part->staged.get(), false, true, &state);
   part->staged.reset();
-  if (!part->partials) part->partials = chunk_table(part->ctx, part->plan->partial_fields);
-  table_append(part->partials.get(), 0, &state, true);
-  part->chunks_done += 1;
+  partial_append(part, &state);
 }
 
-// The pending batches -> one chunk on its way to HBM; the chunk before it is aggregated meanwhile.
+// The pending batches -> one chunk on its way to HBM; the chunks before it are aggregated meanwhile.
 void stage_pending(prism_gpu_part* part) {
   if (part->pending.empty()) return;
-  auto next = chunk_table(part->ctx, part->plan->fields);
-  std::vector<ArrowArray*> ptrs;
-  for (ArrowArray& a : part->pending) ptrs.push_back(&a);
   // (moved: released by the append, also when it fails)
   std::vector<ArrowArray> batches;
   batches.swap(part->pending);
   part->pending_rows = 0;
-  ptrs.clear();
+  std::vector<ArrowArray*> ptrs;
   for (ArrowArray& a : batches) ptrs.push_back(&a);
+  if (part->keeps_state) {
+    // One table for the whole partition (its dictionaries give a string the same code in every
+    // chunk); a chunk is known in it by a number of its own.  Chunks wait in HBM until a few
+    // have gathered (option "stream_agg_chunks"): one aggregation over several million rows
+    // costs far less than one per chunk, and takes the paths that need that many rows.
+    if (!part->table) part->table = chunk_table(part->ctx, part->plan->fields);
+    const uint32_t id = part->next_id++;
+    table_append_batches(part->table.get(), id, ptrs.data(), ptrs.size(), true);
+    part->staged_ids.push_back(id);
+    if (part->staged_ids.size() > (size_t)std::max(1, part->plan->ctx->stream_agg_chunks.load(std::memory_order_relaxed))) aggregate_staged(part, false);
+    return;
+  }
+  auto next = chunk_table(part->ctx, part->plan->fields);
   table_append_batches(next.get(), part->partition, ptrs.data(), ptrs.size(), true);
-  aggregate_staged(part);
+  aggregate_staged(part, true);
   part->staged = std::move(next);
 }
 
@@ -155,6 +304,7 @@ std::unique_ptr<prism_gpu_part> part_open(prism_gpu_plan* plan, uint32_t partiti
   part->plan = plan;
   part->partition = partition;
   part->ctx = ctx_acquire_child(plan->ctx);
+  part->keeps_state = plan_keeps_state(plan);
   return part;
 }
 
@@ -178,21 +328,37 @@ void part_push(prism_gpu_part* part, ArrowArray* batch) {
   part->pending_rows += (uint64_t)held.length;
   part->rows_total += (uint64_t)held.length;
   part->pending.push_back(held);
-  if (part->pending_rows >= kPartChunkRows) stage_pending(part);
+  if (part->pending_rows >= part->plan->ctx->stream_chunk_rows.load(std::memory_order_relaxed)) stage_pending(part);
 }
 
 void part_finish(prism_gpu_part* part, ArrowArray* out) {
   bind(part->ctx);
   stage_pending(part);
-  if (part->staged && part->chunks_done == 0) {
-    // the whole partition is this one chunk: its result is the partition's
-    execute_plan_on(part->ctx, part->plan, part->staged.get(), false, false, out);
-    part->staged.reset();
-    return;
+  const bool partial_out = part->plan->mode == PRISM_MODE_PARTIAL;
+  if (part->keeps_state) {
+    aggregate_staged(part, true);
+    if (part->state && part->chunks_done == 0) {
+      // the partition's groups never left the device: they are read once, in the form asked for
+      state_emit(part->state, partial_out, out);
+      state_free(part->state);
+      part->state = nullptr;
+      part->state_chunks = 0;
+      return;
+    }
+    set_state_aside(part);
+    part->widen = 16;
+    part->state_chunks = 0;
+  } else {
+    if (part->staged && part->chunks_done == 0) {
+      // the whole partition is this one chunk: its result is the partition's
+      execute_plan_on(part->ctx, part->plan, part->staged.get(), false, false, out);
+      part->staged.reset();
+      return;
+    }
+    aggregate_staged(part, true);
   }
-  aggregate_staged(part);
   if (!part->partials) part->partials = chunk_table(part->ctx, part->plan->partial_fields);
-  execute_plan_on(part->ctx, part->plan, part->partials.get(), true, part->plan->mode == PRISM_MODE_PARTIAL, out);
+  execute_plan_on(part->ctx, part->plan, part->partials.get(), true, partial_out, out);
   part->partials.reset();
   part->chunks_done = 0;
 }
@@ -205,5 +371,8 @@ prism_gpu_part::~prism_gpu_part() {
   pending.clear();
   staged.reset();
   partials.reset();
+  if (state) prism::state_free(state);
+  state = nullptr;
+  table.reset();
   if (ctx) prism::ctx_release_child(ctx);
 }

@@ -8,6 +8,9 @@
 // run on 4-byte codes), validity bitmaps are re-aligned to the chunk's first row,
 // and a statistics kernel records min / max / NULL count per column, which is
 // what lets GROUP BY keys be packed into a few bits.
+#if defined(__x86_64__)
+#include <emmintrin.h>
+#endif
 #include <chrono>
 #include <cstring>
 
@@ -45,6 +48,31 @@ void dev_free(prism_gpu_table* t, void* p) {
   else (void)hipFree(p);
 }
 
+// Bytes into the pinned ring.  The host never reads them back (the copy engine does), so they
+// are written with streaming stores: no line of the ring is fetched before it is overwritten,
+// and the caller's working set stays in cache.
+inline void copy_into_ring(uint8_t* d, const uint8_t* s, size_t n) {
+#if defined(__x86_64__)
+  if (n >= 1024) {
+    const size_t head = (size_t)(-(uintptr_t)d) & 63;
+    std::memcpy(d, s, head);
+    d += head; s += head; n -= head;
+    const size_t lines = n >> 6;
+    for (size_t i = 0; i < lines; ++i, d += 64, s += 64) {
+      const __m128i a = _mm_loadu_si128((const __m128i*)s), b = _mm_loadu_si128((const __m128i*)(s + 16)),
+                    c = _mm_loadu_si128((const __m128i*)(s + 32)), e = _mm_loadu_si128((const __m128i*)(s + 48));
+      _mm_stream_si128((__m128i*)d, a);
+      _mm_stream_si128((__m128i*)(d + 16), b);
+      _mm_stream_si128((__m128i*)(d + 32), c);
+      _mm_stream_si128((__m128i*)(d + 48), e);
+    }
+    _mm_sfence();
+    n &= 63;
+  }
+#endif
+  std::memcpy(d, s, n);
+}
+
 // Host -> HBM through the pinned ring: bytes are gathered into a pinned half (they may come
 // from many small Arrow buffers) and leave with one copy per half while the other half
 // fills.  A half is reused only after the copy that read it has completed (its event); the
@@ -55,7 +83,20 @@ struct StageWriter {
   int half = -1;
   size_t fill = 0;
   uint64_t staged = 0;  // bytes handed to the copy stream; the owner adds them to the statistics under ctx->mu
+  bool direct = false;  // some bytes travel straight from the caller's (pinned) buffers: await the stream before those may go
   explicit StageWriter(prism_gpu_ctx* c) : ctx(c) {}
+  // Large buffers that already are page-locked memory of this process (the PARTIAL batches this
+  // library hands out are; so is whatever a caller allocated with hipHostMalloc) need no second
+  // host copy: the copy engine reads them where they are.
+  static constexpr size_t kDirectMinBytes = 1u << 20;
+  static bool page_locked(const void* p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+      (void)hipGetLastError();  // (ordinary host memory is reported as an error: not one of ours)
+      return false;
+    }
+    return at.type == hipMemoryTypeHost;
+  }
   void begin(void* device_dst) { flush(); dst = (uint8_t*)device_dst; }
   void acquire() {
     half = ctx->stage_next;
@@ -65,10 +106,18 @@ struct StageWriter {
   }
   void write(const void* src, size_t bytes) {
     const uint8_t* s = (const uint8_t*)src;
+    if (bytes >= kDirectMinBytes && page_locked(src)) {
+      flush();
+      PRISM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+      staged += bytes;
+      dst += bytes;
+      direct = true;
+      return;
+    }
     while (bytes) {
       if (half < 0) acquire();
       const size_t room = ctx->stage_bytes - fill, n = bytes < room ? bytes : room;
-      std::memcpy((uint8_t*)ctx->stage[half] + fill, s, n);
+      copy_into_ring((uint8_t*)ctx->stage[half] + fill, s, n);
       fill += n;
       s += n;
       bytes -= n;
@@ -96,6 +145,23 @@ void stage_copy(prism_gpu_ctx* ctx, void* dst, const void* src, size_t bytes) {
   w.flush();
   std::lock_guard<std::mutex> gs(ctx->mu);
   ctx->stats.bytes_staged += w.staged;
+}
+
+// Device scratch of the loader's kernels, at least `need` bytes (under ctx->stage_mu).  One
+// block per context, grown on demand: a column's use follows the previous one's on copy_stream,
+// and what the host writes into it travels on that stream too.
+void* load_scratch(prism_gpu_ctx* ctx, size_t need) {
+  if (ctx->load_tmp_bytes < need) {
+    // (hipFree waits for the device: the kernels of earlier appends no longer read the old block)
+    if (ctx->load_tmp) PRISM_HIP(hipFree(ctx->load_tmp));
+    ctx->load_tmp = nullptr;
+    ctx->load_tmp_bytes = 0;
+    const size_t grown = pow2_ceil(need < 4096 ? 4096 : need);
+    hipError_t e = hipMalloc(&ctx->load_tmp, grown);
+    if (e != hipSuccess) fail(e == hipErrorOutOfMemory ? PRISM_GPU_EOOM : PRISM_GPU_EHIP, std::string("hipMalloc of the loader's scratch failed: ") + hipGetErrorString(e));
+    ctx->load_tmp_bytes = grown;
+  }
+  return ctx->load_tmp;
 }
 
 bool bit_at(const uint8_t* bits, int64_t i) { return (bits[i >> 3] >> (i & 7)) & 1; }
@@ -239,7 +305,11 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
     prism_gpu_table* t;
     Chunk* ch;
     bool armed = true;
-    ~ChunkGuard() { if (armed) free_chunk_memory(t, *ch); }
+    ~ChunkGuard() {
+      if (!armed) return;
+      (void)hipStreamSynchronize(t->ctx->copy_stream);  // copies into the chunk may be under way
+      free_chunk_memory(t, *ch);
+    }
   } guard{t, &ch};
   init_stats(t, ch, t->fields.size());
 
@@ -295,7 +365,8 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
     // Chunks of a streaming partition whose every batch is dictionary encoded keep only the
     // codes (the table-wide dictionary of such a table stays small: it is the union of the
     // batches' dictionaries).
-    bool codes_only = t->pooled && dict.alive && t->chunks.empty();
+    bool codes_only = t->pooled && dict.alive;
+    for (const Chunk& old : t->chunks) codes_only = codes_only && old.cols[ci].values == nullptr;  // (the table of a part holds the chunks in flight)
     for (size_t b = 0; b < n_batches && codes_only; ++b) {
       const ArrowArray* a = &views[b][ci];
       codes_only = a->length == 0 || (a->dictionary != nullptr && a->dictionary->length <= 4096);
@@ -305,7 +376,12 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
     bool device_expand = !codes_only && ctx->dict_expand_device.load(std::memory_order_relaxed) != 0;
     for (size_t b = 0; b < n_batches && device_expand; ++b) device_expand = views[b][ci].length == 0 || views[b][ci].dictionary != nullptr;
     std::vector<uint32_t> index, cat_off, remap_all;  // (device_expand) rows' positions in the dictionaries laid end to end
-    if (dict.alive && !device_expand) codes.resize((size_t)n);
+    // A codes-only chunk takes its codes on the device as well: the batches' index buffers are
+    // staged as they are, and a kernel maps them through the dictionaries' codes.
+    const bool device_codes = codes_only && ctx->dict_expand_device.load(std::memory_order_relaxed) != 0;
+    std::vector<uint32_t> seg_row, seg_base;
+    const ArrowArray* seg_dict = nullptr;  // the dictionary of the last segment: batches that share it extend the segment
+    if (dict.alive && !device_expand && !device_codes) codes.resize((size_t)n);
     std::vector<int32_t> offs(codes_only || device_expand ? 1 : (size_t)n + 1);
     offs[0] = 0;
     // bytes of the chunk: total first (it sizes the device buffer), then the pieces
@@ -330,6 +406,28 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
         const char* dbytes = (const char*)d->buffers[2];
         const uint8_t* dvalid = (d->null_count != 0 && d->n_buffers > 0) ? (const uint8_t*)d->buffers[0] : nullptr;
         if (dvalid) fail(PRISM_GPU_EUNSUPPORTED, "NULL entries inside a dictionary are not supported (column " + f.name + ")");
+        if (device_codes) {
+          const bool same = seg_dict && seg_dict->length == d->length && seg_dict->offset == d->offset &&
+                            seg_dict->buffers[1] == d->buffers[1] && seg_dict->buffers[2] == d->buffers[2];
+          if (!same) {
+            seg_row.push_back((uint32_t)row0);
+            seg_base.push_back((uint32_t)remap_all.size());
+            for (int64_t k = 0; k < d->length; ++k) remap_all.push_back(dict.id_of(dbytes + doff[k], (size_t)(doff[k + 1] - doff[k])));
+            seg_dict = d;
+          }
+          // every index a row uses must lie inside the dictionary (rows without NULLs: one pass for the extremes)
+          if (!vbits) {
+            int32_t lo = 0, hi = -1;
+            for (int64_t i = 0; i < nb; ++i) { lo = idx[i] < lo ? idx[i] : lo; hi = idx[i] > hi ? idx[i] : hi; }
+            if (lo < 0 || hi >= d->length) fail(PRISM_GPU_EINVAL, "dictionary index out of range in " + f.name);
+          } else {
+            for (int64_t i = 0; i < nb; ++i)
+              if (bit_at(vbits, a->offset + i) && (idx[i] < 0 || idx[i] >= d->length)) fail(PRISM_GPU_EINVAL, "dictionary index out of range in " + f.name);
+          }
+          pieces.push_back({(const uint8_t*)idx, (size_t)nb * 4});
+          row0 += nb;
+          continue;
+        }
         std::vector<uint32_t> remap;
         if (dict.alive) {
           remap.resize((size_t)d->length);
@@ -420,6 +518,27 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
       }
     }
     if (codes_only && !dict.alive) fail(PRISM_GPU_EUNSUPPORTED, "dictionary-encoded column " + f.name + " has more than " + std::to_string(kMaxDictValues) + " distinct values");
+    if (device_codes) {
+      // (pieces holds the batches' index buffers)
+      auto pad = [](size_t v) { return (v + 15) & ~(size_t)15; };
+      const size_t n_segs = seg_row.size(), base_at = pad(n_segs * 4), remap_at = base_at + pad(n_segs * 4),
+                   need = remap_at + pad(remap_all.size() * 4);
+      uint8_t* tmp = (uint8_t*)load_scratch(ctx, need);
+      dc.codes = (uint32_t*)dev_alloc(t, (size_t)n * 4);
+      w.begin(tmp);
+      w.write(seg_row.data(), n_segs * 4);
+      w.begin(tmp + base_at);
+      w.write(seg_base.data(), n_segs * 4);
+      w.begin(tmp + remap_at);
+      w.write(remap_all.data(), remap_all.size() * 4);
+      w.begin(dc.codes);
+      for (const Piece& pc : pieces) w.write(pc.p, pc.n);
+      w.flush();
+      launch_dict_codes(ctx, dc.codes, dc.validity, (uint64_t)n, (const uint32_t*)tmp, (const uint32_t*)(tmp + base_at), (uint32_t)n_segs,
+                        (const uint32_t*)(tmp + remap_at), ctx->copy_stream);
+      launch_col_stats(ctx, dc.codes, dc.validity, 4, true, (uint64_t)n, &ch.d_stats[ci], ctx->copy_stream);
+      continue;
+    }
     if (device_expand) {
       // (pieces holds the dictionaries' bytes here, total the bytes of the expanded column)
       const size_t n_ent = cat_off.size() - 1, n_blocks = dict_expand_blocks((uint64_t)n);
@@ -427,17 +546,7 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
       const size_t off_at = 0, remap_at = off_at + pad(cat_off.size() * 4), sums_at = remap_at + pad(n_ent * 4),
                    dbytes_at = sums_at + pad(n_blocks * 4), index_at = dbytes_at + pad((size_t)cat_off.back()),
                    need = index_at + (dict.alive ? 0 : (size_t)n * 4);
-      if (ctx->load_tmp_bytes < need) {
-        // (hipFree waits for the device: the kernels of earlier appends no longer read the old block)
-        if (ctx->load_tmp) PRISM_HIP(hipFree(ctx->load_tmp));
-        ctx->load_tmp = nullptr;
-        ctx->load_tmp_bytes = 0;
-        const size_t grown = pow2_ceil(need);
-        hipError_t e = hipMalloc(&ctx->load_tmp, grown);
-        if (e != hipSuccess) fail(e == hipErrorOutOfMemory ? PRISM_GPU_EOOM : PRISM_GPU_EHIP, std::string("hipMalloc of the loader's scratch failed: ") + hipGetErrorString(e));
-        ctx->load_tmp_bytes = grown;
-      }
-      uint8_t* tmp = (uint8_t*)ctx->load_tmp;
+      uint8_t* tmp = (uint8_t*)load_scratch(ctx, need);
       dc.values = dev_alloc(t, ((size_t)n + 1) * 4);
       dc.bytes = (uint8_t*)dev_alloc(t, (size_t)total);
       dc.n_bytes = total;
@@ -492,6 +601,8 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
   w.flush();
   // The bytes are in pinned memory or on their way: the batches can go.  The copies are
   // awaited where the chunk's statistics are read (table_sync_stats), before any scan.
+  // (Bytes that travel straight from the batches' own buffers must have left them first.)
+  if (w.direct) PRISM_HIP(hipStreamSynchronize(ctx->copy_stream));
   {
     std::lock_guard<std::mutex> gs(ctx->mu);
     ctx->stats.staging_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -612,6 +723,15 @@ void table_synth(prism_gpu_table* t, uint32_t partition_id, uint64_t seed, uint6
     if (!ch.cols[ci].values && !ch.cols[ci].codes) fail(PRISM_GPU_EINVAL, "column " + t->fields[ci].name + " has no generator");
   guard.armed = false;
   t->chunks.push_back(std::move(ch));
+}
+
+void table_drop_partition(prism_gpu_table* t, uint32_t partition_id) {
+  std::lock_guard<std::mutex> g(t->mu);
+  for (size_t i = 0; i < t->chunks.size();) {
+    if (t->chunks[i].partition_id != partition_id) { ++i; continue; }
+    free_chunk_memory(t, t->chunks[i]);
+    t->chunks.erase(t->chunks.begin() + (ptrdiff_t)i);
+  }
 }
 
 void table_sync_stats(prism_gpu_table* t) {

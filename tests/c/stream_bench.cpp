@@ -5,8 +5,12 @@
 // (date_bin(1 minute, timestamp), service -> COUNT(*), SUM(value), MAX(value)); `service`
 // arrives dictionary encoded.  Prints one JSON object: rows/s from the first push to the
 // merged result, and the staging rate against the PCIe bound.
+// With `c3` as the workload: one Int64 id column (log-uniform ranks over 2^24 hashed to 63 bits,
+// as the C3 generator of prism_synth.h draws them) grouped by the id with COUNT(*): most rows of
+// a chunk are groups of their own, every partition meets nearly every id.
 //
-//   stream_bench <rows> <threads> <steps> [batch_rows]
+//   stream_bench <rows> <threads> <steps> [batch_rows] [c2|c3] [state|nostate] [option=value ...]
+// (nostate: option "stream_state" 0, a PARTIAL batch per chunk instead of one table per partition in HBM)
 #include <chrono>
 #include <cinttypes>
 #include <cstdio>
@@ -18,6 +22,7 @@
 
 #include "../../include/arrow_c_data.h"
 #include "../../include/prism_gpu.h"
+#include "../../include/prism_synth.h"
 
 static void noop_release_schema(ArrowSchema* s) { s->release = nullptr; }
 static void noop_release_array(ArrowArray* a) { a->release = nullptr; }
@@ -52,6 +57,7 @@ int main(int argc, char** argv) {
   const int threads = argc > 2 ? atoi(argv[2]) : 16;
   const int steps = argc > 3 ? atoi(argv[3]) : 3;
   const int64_t batch_rows = argc > 4 ? atoll(argv[4]) : 8192;
+  const bool c3 = argc > 5 && strcmp(argv[5], "c3") == 0;
   const int n_services = 64;
   const int64_t t0 = 1700000000000ll, day = 86400000ll;
 
@@ -79,6 +85,12 @@ int main(int argc, char** argv) {
   for (auto& x : f) { x.flags = ARROW_FLAG_NULLABLE; x.release = noop_release_schema; }
   top.format = "+s"; top.name = ""; top.n_children = 3; top.children = fp; top.release = noop_release_schema;
 
+  if (argc > 6 && strcmp(argv[6], "nostate") == 0) CHECK(prism_gpu_set_option(ctx, "stream_state", 0));
+  for (int a = 7; a < argc; ++a) {  // further arguments: option=value (prism_gpu_set_option)
+    const char* eq = strchr(argv[a], '=');
+    if (!eq) { fprintf(stderr, "expected option=value, got %s\n", argv[a]); return 2; }
+    CHECK(prism_gpu_set_option(ctx, std::string(argv[a], eq - argv[a]).c_str(), atoll(eq + 1)));
+  }
   prism_gpu_key keys[2] = {{PRISM_KEY_DATE_BIN, 0, 60000, 0, nullptr}, {PRISM_KEY_COLUMN, 1, 0, 0, nullptr}};
   prism_gpu_agg aggs[3] = {{PRISM_AGG_COUNT_STAR, -1, nullptr}, {PRISM_AGG_SUM, 2, nullptr}, {PRISM_AGG_MAX, 2, nullptr}};
   prism_gpu_plan_desc desc;
@@ -89,6 +101,16 @@ int main(int argc, char** argv) {
   desc.keys = keys; desc.n_keys = 2;
   desc.aggs = aggs; desc.n_aggs = 3;
   desc.order_by = -1; desc.limit = -1;
+  if (c3) {  // {UserID: Int64}, GROUP BY UserID -> COUNT(*)
+    f[0].format = "l"; f[0].name = "UserID";
+    top.n_children = 1;
+    keys[0] = {PRISM_KEY_COLUMN, 0, 0, 0, nullptr};
+    desc.n_keys = 1;
+    desc.n_aggs = 1;
+    // ORDER BY COUNT(*) DESC LIMIT 10, applied by the merge (a PARTIAL state carries every group)
+    desc.order_by = 1; desc.descending = 1; desc.limit = 10;
+  }
+  const int n_cols = c3 ? 1 : 3;
   prism_gpu_plan* plan = nullptr;
   CHECK(prism_gpu_plan_create(ctx, &top, &desc, &plan));
 
@@ -101,6 +123,13 @@ int main(int argc, char** argv) {
       gen.emplace_back([&, p] {
         const uint64_t lo = rows * p / n_parts, hi = rows * (p + 1) / n_parts, n = hi - lo;
         Partition& P = parts[p];
+        if (c3) {
+          const int64_t prm[2] = {24, 0x5EED};
+          const uint64_t key = prism_synth_column_key(3, 0);
+          P.ts.resize(n);  // (the id column lives in `ts`)
+          for (uint64_t i = 0; i < n; ++i) P.ts[i] = prism_synth_value(PRISM_SYNTH_LOGUNIFORM_ID, prm, nullptr, 0, key, lo + i, rows);
+          return;
+        }
         P.ts.resize(n); P.value.resize(n); P.svc.resize(n);
         for (uint64_t i = 0; i < n; ++i) {
           const uint64_t r = lo + i, h = mix64(r);
@@ -111,7 +140,7 @@ int main(int argc, char** argv) {
       });
     for (auto& t : gen) t.join();
   }
-  const uint64_t bytes_per_row = 8 + 4 + 8;
+  const uint64_t bytes_per_row = c3 ? 8 : 8 + 4 + 8;
 
   double best = 1e30, total = 0;
   uint64_t groups = 0;
@@ -132,20 +161,20 @@ int main(int argc, char** argv) {
           memset(&b, 0, sizeof(b));
           b.ts_buf[1] = P.ts.data(); b.svc_buf[1] = P.svc.data(); b.val_buf[1] = P.value.data();
           const void** bufs[3] = {b.ts_buf, b.svc_buf, b.val_buf};
-          for (int c = 0; c < 3; ++c) {
+          for (int c = 0; c < n_cols; ++c) {
             b.cols[c].length = len; b.cols[c].offset = lo; b.cols[c].n_buffers = 2;
             b.cols[c].buffers = bufs[c]; b.cols[c].release = noop_release_array;
             b.children[c] = &b.cols[c];
           }
           b.dict.length = n_services; b.dict.n_buffers = 3; b.dict.buffers = dict_buf; b.dict.release = noop_release_array;
-          b.cols[1].dictionary = &b.dict;
-          b.top.length = len; b.top.n_buffers = 1; b.top.buffers = b.top_buf; b.top.n_children = 3;
+          if (!c3) b.cols[1].dictionary = &b.dict;
+          b.top.length = len; b.top.n_buffers = 1; b.top.buffers = b.top_buf; b.top.n_children = n_cols;
           b.top.children = b.children; b.top.release = noop_release_array;
           // (the part keeps the ArrowArray struct by value; the children live in `b`... so a
           // batch must outlive the push until it is staged: allocate it)
           Batch* hb = new Batch(b);
-          for (int c = 0; c < 3; ++c) { hb->cols[c].buffers = c == 0 ? hb->ts_buf : c == 1 ? hb->svc_buf : hb->val_buf; hb->children[c] = &hb->cols[c]; }
-          hb->cols[1].dictionary = &hb->dict;
+          for (int c = 0; c < n_cols; ++c) { hb->cols[c].buffers = c == 0 ? hb->ts_buf : c == 1 ? hb->svc_buf : hb->val_buf; hb->children[c] = &hb->cols[c]; }
+          if (!c3) hb->cols[1].dictionary = &hb->dict;
           hb->top.buffers = hb->top_buf; hb->top.children = hb->children;
           hb->top.private_data = hb;
           hb->top.release = [](ArrowArray* a) { Batch* x = (Batch*)a->private_data; a->release = nullptr; delete x; };
@@ -155,28 +184,45 @@ int main(int argc, char** argv) {
         prism_gpu_part_free(part);
       });
     for (auto& t : th) t.join();
+    const double parts_sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     std::vector<ArrowArray*> ptrs;
     for (auto& s : states) ptrs.push_back(&s);
     ArrowArray out;
     CHECK(prism_gpu_merge(plan, ptrs.data(), ptrs.size(), &out));
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
-    // every row lands in exactly one group
-    const int64_t* cnt = (const int64_t*)out.children[2]->buffers[1];
-    uint64_t sum = 0;
-    for (int64_t i = 0; i < out.length; ++i) sum += (uint64_t)cnt[i];
-    if (sum != rows) { fprintf(stderr, "COUNT(*) adds up to %" PRIu64 ", not %" PRIu64 "\n", sum, rows); return 1; }
-    groups = (uint64_t)out.length;
+    const int64_t* cnt = (const int64_t*)out.children[c3 ? 1 : 2]->buffers[1];
+    if (c3) {
+      // the ten most frequent ids, in order; the ids a partition saw are counted in its state
+      if (out.length != 10) { fprintf(stderr, "%lld rows, not the 10 leading ones\n", (long long)out.length); return 1; }
+      for (int64_t i = 1; i < out.length; ++i)
+        if (cnt[i] > cnt[i - 1]) { fprintf(stderr, "result is not ordered by COUNT(*)\n"); return 1; }
+      groups = 0;
+      for (auto& s : states) groups += (uint64_t)s.length;
+    } else {
+      // every row lands in exactly one group
+      uint64_t sum = 0;
+      for (int64_t i = 0; i < out.length; ++i) sum += (uint64_t)cnt[i];
+      if (sum != rows) { fprintf(stderr, "COUNT(*) adds up to %" PRIu64 ", not %" PRIu64 "\n", sum, rows); return 1; }
+      groups = (uint64_t)out.length;
+    }
     out.release(&out);
     for (auto& s : states) s.release(&s);
     if (step > 0) { total += sec; if (sec < best) best = sec; }
+    if (step == steps && getenv("STREAM_BENCH_VERBOSE")) {
+      prism_gpu_stats vs;
+      CHECK(prism_gpu_get_stats(ctx, &vs));
+      fprintf(stderr, "last step: partitions done after %.1f ms, merged result after %.1f ms\n", parts_sec * 1e3, sec * 1e3);
+      for (uint32_t k = 0; k < vs.n_kernels; ++k)
+        fprintf(stderr, "  %-24s %8llu x  %10.2f ms in all\n", vs.kernels[k].name, (unsigned long long)vs.kernels[k].launches, vs.kernels[k].total_ms);
+    }
   }
   prism_gpu_stats st;
   CHECK(prism_gpu_get_stats(ctx, &st));
   const double avg = total / steps;
-  printf("{\"rows\": %" PRIu64 ", \"threads\": %d, \"batch_rows\": %lld, \"steps\": %d, \"groups\": %" PRIu64
+  printf("{\"workload\": \"%s\", \"rows\": %" PRIu64 ", \"threads\": %d, \"batch_rows\": %lld, \"steps\": %d, \"groups\": %" PRIu64
          ", \"seconds_avg\": %.6f, \"seconds_best\": %.6f, \"rows_per_s\": %.1f, \"host_bytes_per_row\": %" PRIu64
          ", \"host_to_hbm_GBps\": %.3f, \"bytes_staged_last_step\": %" PRIu64 ", \"staging_thread_ms_last_step\": %.1f}\n",
-         rows, threads, (long long)batch_rows, steps, groups, avg, best, rows / avg, bytes_per_row,
+         c3 ? "c3" : "c2", rows, threads, (long long)batch_rows, steps, groups, avg, best, rows / avg, bytes_per_row,
          rows * bytes_per_row / avg / 1e9, (uint64_t)st.bytes_staged, st.staging_ms);
   prism_gpu_plan_free(plan);
   prism_gpu_ctx_free(ctx);

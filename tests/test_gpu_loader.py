@@ -179,3 +179,38 @@ def test_a_batch_of_more_rows_than_a_chunk_holds_becomes_several_chunks(gpu_ctx)
         assert counts == {i: int(c) for i, c in enumerate(want)}
     finally:
         g.close()
+
+
+@pytest.mark.parametrize("nulls", [True, False])
+@pytest.mark.parametrize("case", sorted(__import__("tests.test_parquet_reader", fromlist=["CASES"]).CASES))
+def test_every_writer_configuration_lands_in_hbm_as_the_host_reader_decodes_it(gpu_ctx, case, nulls):
+    """The writer configurations the host reader is checked on (data pages v1 / v2, with and
+    without dictionary and Snappy, several row groups, dictionaries that overflow into PLAIN
+    pages) through prism_gpu_table_append_parquet: string chunks that are dictionary encoded
+    reach HBM as indices and are expanded by kernels, the others as decoded bytes; queries that
+    read the codes (GROUP BY, =), the raw bytes (LIKE on the column without a dictionary) and
+    the validity must equal the oracle's over prism_gpu_parquet_read's decode of the same file."""
+    from oracle import pyoracle
+    from prism_amd.engine import Plan, Table, parquet_read
+    from tests.test_parquet_reader import CASES, _table, _write
+
+    data = _write(_table(7000, seed=len(case), nulls=nulls), **CASES[case])
+    t = parquet_read(data)
+    g = Table(gpu_ctx, t.schema)
+    try:
+        g.append_parquet(0, data)
+        assert g.num_rows == t.num_rows
+        for q, n_keys in [
+            (QueryPlan([count_star(), sum_("small64"), max_("i32")], keys=["method"]), 1),
+            (QueryPlan([count_star()], predicate=col("url").like("%host7%") & (col("method") != "GET")), 0),
+            (QueryPlan([count_star(), sum_("i16")], keys=["method"], predicate=col("url").like("http://host1%") | col("blob").is_null()), 1),
+            (QueryPlan([count_star()], predicate=col("method").is_null() | col("url").is_null() | col("all_null").is_null()), 0),
+        ]:
+            plan = Plan(gpu_ctx, t.schema, q)
+            try:
+                got = plan.execute(g)
+            finally:
+                plan.close()
+            assert_tables_match(got, pyoracle.execute(t, q), n_keys)
+    finally:
+        g.close()
