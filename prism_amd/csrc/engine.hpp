@@ -41,6 +41,10 @@ struct Chunk {
 // few distinct values; once it dies the column only has its raw representation.
 struct ColumnDict {
   bool alive = true;
+  // Not alive, but every chunk has codes all the same: kernels numbered the column's distinct
+  // strings (table_device_dictionary) and `values` holds them.  Only GROUP BY keys read such
+  // codes; predicates keep to the raw strings.  An append ends it (the next query rebuilds).
+  bool device_built = false;
   std::unordered_map<std::string, uint32_t> ids;
   std::vector<std::string> values;
   uint32_t id_of(const char* s, size_t n);
@@ -71,6 +75,10 @@ void free_chunk_memory(prism_gpu_table* t, Chunk& ch);
 void table_synth(prism_gpu_table* t, uint32_t partition_id, uint64_t seed, uint64_t first_row, uint64_t n_rows,
                  uint64_t total_rows, const prism_gpu_synth_col* cols, uint32_t n_cols);
 void table_sync_stats(prism_gpu_table* t);
+// Codes for a string column whose host dictionary gave up (more than kMaxDictValues values):
+// built on the device over all chunks, exact (no two different strings share a code).  No-op
+// when the column has a live dictionary or the device-built one is complete.
+void table_device_dictionary(prism_gpu_table* t, int column);
 // Frees the chunks of one partition (the caller knows that no kernel still reads them).
 void table_drop_partition(prism_gpu_table* t, uint32_t partition_id);
 

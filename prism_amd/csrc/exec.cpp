@@ -189,7 +189,7 @@ void layout_keys(ScanSet& ss, const prism_gpu_table* t, const std::vector<KeySrc
   for (size_t ki : order) {
     const KeySrc& k = keys[ki];
     const FieldType& f = t->fields[k.column];
-    if (f.is_string && !t->dicts[k.column].alive)
+    if (f.is_string && !t->dicts[k.column].alive && !t->dicts[k.column].device_built)
       fail(PRISM_GPU_EUNSUPPORTED, "GROUP BY / DISTINCT on string column `" + f.name + "` with more than " +
                                        std::to_string(kMaxDictValues) + " distinct values is not supported");
     ColInfo ci = col_info(ss, k.column);
@@ -1838,6 +1838,15 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
   for (size_t i = 0; i < expect.size(); ++i)
     if (table->fields[i].logical != expect[i].logical)
       fail(PRISM_GPU_EINVAL, "column " + std::to_string(i) + " (`" + table->fields[i].name + "`) has a different type than the plan expects");
+  // A string key whose host dictionary gave up gets its codes from the device (exactly: see
+  // table_device_dictionary); so does the column of a COUNT(DISTINCT).
+  {
+    std::vector<int> string_keys;
+    for (size_t i = 0; i < plan->keys.size(); ++i) string_keys.push_back(merge_input ? (int)i : plan->keys[i].column);
+    if (plan->distinct_plan) string_keys.push_back(merge_input ? (int)plan->keys.size() : plan->distinct_col);
+    for (int c : string_keys)
+      if (c >= 0 && (size_t)c < table->fields.size() && table->fields[(size_t)c].is_string) table_device_dictionary(table, c);
+  }
   table_sync_stats(table);
 
   // ---- which chunks ----

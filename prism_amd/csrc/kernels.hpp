@@ -565,6 +565,32 @@ void launch_dict_codes(prism_gpu_ctx* ctx, uint32_t* codes, const uint64_t* vali
 size_t dict_expand_blocks(uint64_t rows);
 void launch_dict_expand(prism_gpu_ctx* ctx, const DictExpand& q, hipStream_t stream);
 
+// ---- a dictionary built on the device (kernels_strdict.hip) ----
+// One chunk's raw string column; rows are numbered over the chunks (base + row).
+struct StrSeg {
+  const int32_t* off;
+  const uint8_t* bytes;
+  const uint64_t* validity;
+  uint32_t* codes;  // out: the rows' codes
+  uint64_t base;
+  uint64_t rows;
+};
+// hashes[row]: 63 bits of the row's bytes (all ones: NULL).
+void launch_str_hash(prism_gpu_ctx* ctx, const StrSeg* segs, uint32_t n_segs, uint64_t n_rows, uint64_t seed, uint64_t* hashes);
+// keys / rep (capacity entries, a power of two, all ones on entry): the distinct hashes and the smallest row of each.
+void launch_str_insert(prism_gpu_ctx* ctx, const uint64_t* hashes, uint64_t n_rows, uint64_t* keys, uint32_t* rep, uint64_t capacity);
+// Numbers the occupied entries: code_of_entry, rep_by_code, *n_values; block_sums: str_dict_blocks(capacity) + 1 words.
+size_t str_dict_blocks(uint64_t entries);
+void launch_str_number(prism_gpu_ctx* ctx, const uint64_t* keys, uint64_t capacity, const uint32_t* rep, uint32_t* block_sums,
+                       uint32_t* code_of_entry, uint32_t* rep_by_code, uint32_t* n_values);
+// Every row's code into its segment's `codes`; *flag becomes 1 when two different strings share a hash.
+void launch_str_codes(prism_gpu_ctx* ctx, const StrSeg* segs, uint32_t n_segs, uint64_t n_rows, const uint64_t* hashes, const uint64_t* keys,
+                      const uint32_t* rep, const uint32_t* code_of_entry, uint64_t capacity, uint32_t* flag);
+// The strings of the codes' representatives: value_off (n_values + 1) and, when value_bytes is
+// set, the bytes (at most bytes_capacity of them); block_sums: str_dict_blocks(n_values) + 1 words.
+void launch_str_values(prism_gpu_ctx* ctx, const StrSeg* segs, uint32_t n_segs, const uint32_t* rep_by_code, uint32_t n_values,
+                       uint32_t* block_sums, uint32_t* value_off, uint8_t* value_bytes, uint64_t bytes_capacity);
+
 struct SynthColDev {
   void* dst;
   int32_t width;  // 2, 4, 8

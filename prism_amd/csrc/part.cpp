@@ -163,7 +163,7 @@ std::vector<prism_gpu_col_stats> widened_stats(const prism_gpu_part* part, const
     if (f.is_string) {
       // dictionary codes are handed out from 0 in order of appearance
       o.min = 0;
-      o.max = std::max<long long>(255, std::min<long long>((long long)kMaxDictValues, o.max * 4 + 3));
+      o.max = std::max<long long>(255, o.max * 4 + 3);
       continue;
     }
     // the type's own limits
@@ -213,10 +213,26 @@ void set_state_aside(prism_gpu_part* part) {
   part->widen = std::min(part->widen * 4, 1 << 20);
 }
 
+// The key columns that are strings without a host dictionary: their codes are numbered by the
+// device anew whenever chunks have arrived, so a group table that holds such codes cannot wait
+// for the next chunks -- it is set aside (as strings) right after it was built.
+std::vector<int> undictionaried_keys(const prism_gpu_part* part) {
+  std::vector<int> out;
+  if (!part->table) return out;
+  for (const KeyPlan& k : part->plan->keys)
+    if (part->table->fields[(size_t)k.column].is_string && !part->table->dicts[(size_t)k.column].alive) out.push_back(k.column);
+  return out;
+}
+
 // The staged chunks `ids` -> one group table, folded into the part's.
 void aggregate_into_state(prism_gpu_part* part, const std::vector<uint32_t>& ids) {
   if (ids.empty()) return;
   prism_gpu_table* t = part->table.get();
+  const std::vector<int> renumbered = undictionaried_keys(part);
+  if (!renumbered.empty()) {
+    set_state_aside(part);  // (it holds codes of the dictionary as it was)
+    for (int c : renumbered) table_device_dictionary(t, c);
+  }
   table_sync_stats(t);
   std::vector<const Chunk*> chunks;
   for (const Chunk& c : t->chunks)
@@ -245,6 +261,7 @@ void aggregate_into_state(prism_gpu_part* part, const std::vector<uint32_t>& ids
       state_free(st);
     }
   }
+  if (!renumbered.empty()) set_state_aside(part);
   for (uint32_t id : ids) table_drop_partition(t, id);
   part->state_chunks += ids.size();
 }
@@ -284,8 +301,11 @@ void stage_pending(prism_gpu_part* part) {
     // costs far less than one per chunk, and takes the paths that need that many rows.
     if (!part->table) part->table = chunk_table(part->ctx, part->plan->fields);
     const uint32_t id = part->next_id++;
+    const bool had_dictionaries = undictionaried_keys(part).empty();
     table_append_batches(part->table.get(), id, ptrs.data(), ptrs.size(), true);
     part->staged_ids.push_back(id);
+    // a key's dictionary gave up during this append: the table built so far is read out through the values it had
+    if (had_dictionaries && !undictionaried_keys(part).empty()) set_state_aside(part);
     if (part->staged_ids.size() > (size_t)std::max(1, part->plan->ctx->stream_agg_chunks.load(std::memory_order_relaxed))) aggregate_staged(part, false);
     return;
   }

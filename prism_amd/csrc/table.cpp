@@ -509,9 +509,10 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
     }
     if (dict.alive && dict.values.size() > kMaxDictValues) {
       // too many distinct values: this column keeps only its raw form from now on
+      // (the values stay: group tables built so far hold their codes and are still read out through them)
       dict.alive = false;
+      dict.device_built = false;
       dict.ids.clear();
-      dict.values.clear();
       for (auto& old : t->chunks) {
         dev_free(t, old.cols[ci].codes);
         old.cols[ci].codes = nullptr;
@@ -732,6 +733,93 @@ void table_drop_partition(prism_gpu_table* t, uint32_t partition_id) {
     free_chunk_memory(t, t->chunks[i]);
     t->chunks.erase(t->chunks.begin() + (ptrdiff_t)i);
   }
+}
+
+void table_device_dictionary(prism_gpu_table* t, int ci) {
+  prism_gpu_ctx* ctx = t->ctx;
+  bind(ctx);
+  std::lock_guard<std::mutex> g(t->mu);
+  ColumnDict& dict = t->dicts[(size_t)ci];
+  if (dict.alive || !t->fields[(size_t)ci].is_string) return;
+  bool complete = dict.device_built;
+  for (const Chunk& ch : t->chunks) complete = complete && (ch.rows == 0 || ch.cols[(size_t)ci].codes != nullptr);
+  if (complete) return;
+  HostTimer timer(ctx, "host:device_dictionary");
+  // the chunks' copies run on the staging stream; the kernels below on the compute stream
+  PRISM_HIP(hipStreamSynchronize(ctx->copy_stream));
+  std::vector<StrSeg> segs;
+  std::vector<Chunk*> seg_chunks;
+  uint64_t n_rows = 0, col_bytes = 0;
+  for (Chunk& ch : t->chunks) {
+    DeviceColumn& dc = ch.cols[(size_t)ci];
+    dev_free(t, dc.codes);
+    dc.codes = nullptr;
+    if (ch.rows == 0) continue;
+    if (!dc.values) fail(PRISM_GPU_EINTERNAL, "string column " + t->fields[(size_t)ci].name + " has neither a dictionary nor its raw form");
+    dc.codes = (uint32_t*)dev_alloc(t, (size_t)ch.rows * 4);
+    segs.push_back({(const int32_t*)dc.values, dc.bytes, dc.validity, dc.codes, n_rows, ch.rows});
+    seg_chunks.push_back(&ch);
+    n_rows += ch.rows;
+    col_bytes += dc.n_bytes;
+  }
+  dict.values.clear();
+  dict.device_built = false;
+  if (n_rows >= 0xfffffff0ull) fail(PRISM_GPU_EUNSUPPORTED, "GROUP BY on string column " + t->fields[(size_t)ci].name + ": 2^32 rows or more");
+  if (col_bytes >= 0xfffffff0ull) fail(PRISM_GPU_EUNSUPPORTED, "GROUP BY on string column " + t->fields[(size_t)ci].name + ": 4 GiB of string data or more");
+  if (segs.empty()) { dict.device_built = true; return; }
+  const uint64_t capacity = pow2_ceil(std::max<uint64_t>(1024, 2 * n_rows));
+  const size_t count_blocks = str_dict_blocks(capacity) + 1;
+  Scratch d_segs(ctx, segs.size() * sizeof(StrSeg)), hashes(ctx, n_rows * 8), keys(ctx, capacity * 8), rep(ctx, capacity * 4),
+      code_of_entry(ctx, capacity * 4), rep_by_code(ctx, n_rows * 4), sums(ctx, count_blocks * 4), small(ctx, 256);
+  PRISM_HIP(hipMemcpyAsync(d_segs.p, segs.data(), segs.size() * sizeof(StrSeg), hipMemcpyHostToDevice, ctx->stream));
+  uint32_t* const d_flag = small.as<uint32_t>();
+  uint32_t* const d_n_values = d_flag + 1;
+  uint32_t h_small[2] = {1, 0};
+  for (uint64_t attempt = 0; attempt < 4 && h_small[0] != 0; ++attempt) {
+    // (a new seed only after two different strings met in one hash: with 63 bits, practically never)
+    PRISM_HIP(hipMemsetAsync(keys.p, 0xff, capacity * 8, ctx->stream));
+    PRISM_HIP(hipMemsetAsync(rep.p, 0xff, capacity * 4, ctx->stream));
+    PRISM_HIP(hipMemsetAsync(small.p, 0, 8, ctx->stream));
+    launch_str_hash(ctx, d_segs.as<StrSeg>(), (uint32_t)segs.size(), n_rows, 0x5bd1e9955bd1e995ull + attempt * 0x9E3779B97F4A7C15ull, hashes.as<uint64_t>());
+    launch_str_insert(ctx, hashes.as<uint64_t>(), n_rows, keys.as<uint64_t>(), rep.as<uint32_t>(), capacity);
+    launch_str_number(ctx, keys.as<uint64_t>(), capacity, rep.as<uint32_t>(), sums.as<uint32_t>(), code_of_entry.as<uint32_t>(),
+                      rep_by_code.as<uint32_t>(), d_n_values);
+    launch_str_codes(ctx, d_segs.as<StrSeg>(), (uint32_t)segs.size(), n_rows, hashes.as<uint64_t>(), keys.as<uint64_t>(), rep.as<uint32_t>(),
+                     code_of_entry.as<uint32_t>(), capacity, d_flag);
+    PRISM_HIP(hipMemcpyAsync(h_small, small.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PRISM_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  if (h_small[0] != 0) fail(PRISM_GPU_EINTERNAL, "different strings of column " + t->fields[(size_t)ci].name + " kept meeting in one hash");
+  const uint32_t n_values = h_small[1];
+  // the distinct strings, in code order: offsets first (they tell the size), then the bytes
+  const size_t value_blocks = str_dict_blocks(n_values) + 1;
+  Scratch vsums(ctx, value_blocks * 4), value_off(ctx, ((size_t)n_values + 1) * 4);
+  launch_str_values(ctx, d_segs.as<StrSeg>(), (uint32_t)segs.size(), rep_by_code.as<uint32_t>(), n_values, vsums.as<uint32_t>(),
+                    value_off.as<uint32_t>(), nullptr, 0);
+  std::vector<uint32_t> off((size_t)n_values + 1);
+  PRISM_HIP(hipMemcpyAsync(off.data(), value_off.p, off.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+  PRISM_HIP(hipStreamSynchronize(ctx->stream));
+  const uint64_t total = off[n_values];
+  std::vector<uint8_t> bytes((size_t)total);
+  if (total) {
+    Scratch value_bytes(ctx, (size_t)total);
+    launch_str_values(ctx, d_segs.as<StrSeg>(), (uint32_t)segs.size(), rep_by_code.as<uint32_t>(), n_values, vsums.as<uint32_t>(),
+                      value_off.as<uint32_t>(), value_bytes.as<uint8_t>(), total);
+    PRISM_HIP(hipMemcpyAsync(bytes.data(), value_bytes.p, (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
+    PRISM_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  dict.values.reserve(n_values);
+  for (uint32_t v = 0; v < n_values; ++v) dict.values.emplace_back((const char*)bytes.data() + off[v], (size_t)(off[v + 1] - off[v]));
+  // the column's statistics are those of its codes from now on (they size the key's bits)
+  const ColStats identity{0x7fffffffffffffffll, -0x7fffffffffffffffll - 1, 0};
+  for (Chunk* ch : seg_chunks) {
+    PRISM_HIP(hipMemcpyAsync(&ch->d_stats[ci], &identity, sizeof(identity), hipMemcpyHostToDevice, ctx->stream));
+    launch_col_stats(ctx, ch->cols[(size_t)ci].codes, ch->cols[(size_t)ci].validity, 4, true, ch->rows, &ch->d_stats[ci], ctx->stream);
+    ch->stats_ready = false;
+  }
+  PRISM_HIP(hipStreamSynchronize(ctx->stream));
+  collect_timings(ctx);
+  dict.device_built = true;
 }
 
 void table_sync_stats(prism_gpu_table* t) {

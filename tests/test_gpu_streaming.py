@@ -157,3 +157,23 @@ def test_many_groups_per_chunk_stay_on_the_device(gpu_ctx, oracle):
             check(got, oracle.execute(t, q), 1)
     finally:
         gpu_ctx.set_option("stream_chunk_rows", 1 << 20)
+
+
+def test_a_string_key_outgrows_its_dictionary_mid_stream(small_chunks, oracle):
+    """The part's table numbers a string key's values on the host until there are more than
+    65536 of them; from then on the device numbers them per aggregation pass, and a group table
+    that holds such codes is set aside as strings at once.  The groups before, across and after
+    that point must add up to the oracle's."""
+    from prism_amd.engine import Plan
+
+    n = 120_000
+    i = np.arange(n)
+    t = pa.table({"u": pa.array([None if k % 1000 == 999 else f"user-{(k * 7919) % 90_001:06d}" for k in i]),
+                  "v": pa.array((i % 13) - 6, pa.int64())})
+    q = QueryPlan([count_star(), sum_("v")], keys=["u"])
+    plan = Plan(small_chunks, t.schema, q)
+    try:
+        got = plan.run_batches(0, t.to_batches(max_chunksize=3000))
+    finally:
+        plan.close()
+    assert_tables_match(got, oracle.execute(t, q), 1)

@@ -165,15 +165,59 @@ def test_c4_like_on_high_cardinality_strings(gpu_ctx, oracle):
                 assert_tables_match(plan.execute(g), oracle.execute(t, q), n_keys)
             finally:
                 plan.close()
-        from prism_amd.engine import PrismGpuError
+    finally:
+        g.close()
 
-        with pytest.raises(PrismGpuError) as e:  # no dictionary -> no GROUP BY on this column
-            p = Plan(gpu_ctx, t.schema, QueryPlan([count_star()], keys=["URL"]))
+
+def test_group_by_a_string_column_without_a_dictionary(gpu_ctx, oracle):
+    """> 65536 distinct URLs: the host dictionary has given up, and the column's codes are
+    numbered on the device (hash of the bytes, one representative row per hash, every row
+    compared with its representative).  The reference groups by any Utf8 column
+    (src/prism-query/src/providers/schema_provider.rs:96-107 maps them to plain strings).
+    GROUP BY alone, beside another key, under a WHERE on the same column, as COUNT(DISTINCT),
+    in PARTIAL mode with a merge, over some partitions only, and again after an append."""
+    from prism_amd.engine import Plan, Table
+
+    t = _url_table(150_000, seed=4)
+    assert len(set(t.column("URL").to_pylist())) > 70_000
+    g = Table(gpu_ctx, t.schema)
+    g.append_table(t, 3)
+    try:
+        queries = [
+            (QueryPlan([count_star()], keys=["URL"]), 1),
+            (QueryPlan([count_star(), sum_("v"), max_("UserID")], keys=["URL"], predicate=col("URL").like("%google%")), 1),
+            (QueryPlan([count_star(), avg("v")], keys=["UserID", "URL"], predicate=col("v") > 50), 2),
+            (QueryPlan([count_distinct("URL")], keys=["v"]), 1),
+            (QueryPlan([count_distinct("URL")]), 0),
+        ]
+        for q, n_keys in queries:
+            plan = Plan(gpu_ctx, t.schema, q)
             try:
-                p.execute(g)
+                assert_tables_match(plan.execute(g), oracle.execute(t, q), n_keys)
             finally:
-                p.close()
-        assert e.value.code == abi.EUNSUPPORTED
+                plan.close()
+        # PARTIAL per partition (the state's key column is Utf8), merged by the GPU and by the oracle
+        q = QueryPlan([count_star(), min_("v")], keys=["URL"])
+        qp = q.with_mode(abi.MODE_PARTIAL)
+        plan = Plan(gpu_ctx, t.schema, qp)
+        try:
+            states = [plan.execute(g, [p]) for p in range(g.num_partitions)]
+            got = plan.merge(states)
+        finally:
+            plan.close()
+        want = oracle.execute(t, q)
+        assert_tables_match(got, want, 1)
+        assert_tables_match(oracle.merge(t.schema, states, q), want, 1)
+        # rows arrive after the codes were numbered: the next query numbers them again
+        more = _url_table(20_000, seed=5)
+        g.append_table(more, 1)
+        both = pa.concat_tables([t, more])
+        q = QueryPlan([count_star(), sum_("v")], keys=["URL"])
+        plan = Plan(gpu_ctx, t.schema, q)
+        try:
+            assert_tables_match(plan.execute(g), oracle.execute(both, q), 1)
+        finally:
+            plan.close()
     finally:
         g.close()
 
