@@ -140,13 +140,16 @@ typedef enum prism_gpu_agg_func {
   PRISM_AGG_COUNT = 2,      /* counts non-NULL values                          */
   PRISM_AGG_SUM = 3,        /* Int* -> Int64, UInt16 -> UInt64, wrapping       */
   PRISM_AGG_MIN = 4,        /* type preserving, NULLs ignored; Utf8 / Binary:
-                               byte-lexicographic, SINGLE mode over resident
-                               partitions (columns GROUP BY accepts)            */
+                               byte-lexicographic (columns GROUP BY accepts); its
+                               PARTIAL state is the string so far, "MIN(s)[min]" */
   PRISM_AGG_MAX = 5,
   PRISM_AGG_AVG = 6,        /* Float64 = f64 sum of values cast to f64 / count */
-  PRISM_AGG_COUNT_DISTINCT = 7 /* Next to other aggregates, or over more than one column: SINGLE
-                                  mode over resident partitions only (prism_gpu_execute: one
-                                  pass per kind of aggregate, joined on the group keys) */
+  PRISM_AGG_COUNT_DISTINCT = 7 /* Next to other aggregates, or over more than one column: one pass
+                                  per kind of aggregate, joined on the group keys; its PARTIAL
+                                  state is then a List<T> column "COUNT(DISTINCT x)[count distinct]"
+                                  holding the group's distinct values (DataFusion's state of a
+                                  distinct count), which prism_gpu_merge and the streaming finish
+                                  accept; prism_gpu_execute_sharded does not take such plans */
 } prism_gpu_agg_func;
 
 typedef struct prism_gpu_agg {

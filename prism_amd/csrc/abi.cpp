@@ -215,6 +215,10 @@ int prism_gpu_merge(prism_gpu_plan* plan, struct ArrowArray* const* states, size
   return guarded([&] {
     require(plan && out && (states || n_states == 0), "null argument");
     require(plan->ctx != nullptr, "the plan was created without a context: it can be inspected, not run");
+    if (plan->mixed) {
+      prism::merge_mixed(plan, states, n_states, false, out);
+      return;
+    }
     auto table = new_table(plan->ctx, plan->partial_fields);
     for (size_t i = 0; i < n_states; ++i) {
       require(states[i] != nullptr, "null state array");

@@ -2,6 +2,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -27,12 +28,30 @@ FieldType field_from_format(const char* format) {
   return t;
 }
 
+FieldType list_field(const std::string& name, const std::string& item_format) {
+  (void)field_from_format(item_format.c_str());  // (a supported value type)
+  FieldType t;
+  t.logical = kTypeList;
+  t.format = "+l";
+  t.name = name;
+  t.nullable = true;
+  t.list_item = item_format;
+  return t;
+}
+
 std::vector<FieldType> parse_schema(const ArrowSchema* schema) {
   if (!schema || !schema->format || std::string(schema->format) != "+s")
     fail(PRISM_GPU_EINVAL, "schema must be a struct (record batch) schema");
   std::vector<FieldType> out;
   for (int64_t i = 0; i < schema->n_children; ++i) {
     const ArrowSchema* c = schema->children[i];
+    if (c->format && std::string(c->format) == "+l") {
+      if (c->n_children != 1 || !c->children[0] || c->children[0]->dictionary) fail(PRISM_GPU_EUNSUPPORTED, "a List column must have one plain value type");
+      FieldType t = list_field(c->name ? c->name : "", c->children[0]->format ? c->children[0]->format : "");
+      t.nullable = (c->flags & ARROW_FLAG_NULLABLE) != 0;
+      out.push_back(t);
+      continue;
+    }
     FieldType t = field_from_format(c->dictionary ? c->dictionary->format : c->format);
     if (c->dictionary) {
       if (!t.is_string) fail(PRISM_GPU_EUNSUPPORTED, "dictionary-encoded columns must have string values");
@@ -102,6 +121,12 @@ void OutColumn::push_str(const std::string& s) { materialise(); valid.push_back(
 
 OutColumn make_out_column(const std::string& name, const std::string& format, bool nullable) {
   OutColumn c;
+  if (format.rfind("+l:", 0) == 0) {  // (a List of the format behind the colon: see make_columns' callers)
+    c.type = list_field(name, format.substr(3));
+    c.items = std::make_shared<OutColumn>(make_out_column("item", format.substr(3), true));
+    c.list_off.assign(1, 0);
+    return c;
+  }
   c.type = field_from_format(format.c_str());
   c.type.name = name;
   c.type.nullable = nullable;
@@ -161,7 +186,9 @@ struct BatchOwner {
   std::vector<std::vector<double>> kept_f64;
   // blocks that borrowed columns point into
   std::vector<std::shared_ptr<void>> leases;
-  std::vector<std::vector<const void*>> buffer_lists;
+  std::deque<std::vector<const void*>> nested_buffer_lists;  // (deques: the arrays point at their elements)
+  std::deque<ArrowArray> nested;                            // the item arrays of list columns
+  std::deque<std::vector<ArrowArray*>> nested_ptrs;
   std::vector<ArrowArray> children;
   std::vector<ArrowArray*> child_ptrs;
   const void* struct_buffers[1] = {nullptr};
@@ -194,6 +221,9 @@ struct SchemaOwner {
   std::vector<std::string> names, formats;
   std::vector<ArrowSchema> children;
   std::vector<ArrowSchema*> child_ptrs;
+  std::deque<std::string> item_formats;  // the value types of List fields
+  std::deque<ArrowSchema> items;
+  std::deque<std::vector<ArrowSchema*>> item_ptrs;
 };
 void release_schema_owner(ArrowSchema* s) {
   delete static_cast<SchemaOwner*>(s->private_data);
@@ -203,15 +233,11 @@ void release_noop_schema(ArrowSchema* s) { s->release = nullptr; }
 
 }  // namespace
 
-void export_record_batch(std::vector<OutColumn>& cols, ArrowArray* out) {
-  auto owner = std::make_unique<BatchOwner>();
-  const size_t n = cols.empty() ? 0 : cols[0].rows();
-  owner->children.resize(cols.size());
-  owner->buffer_lists.resize(cols.size());
-  for (size_t c = 0; c < cols.size(); ++c) {
-    OutColumn& col = cols[c];
-    if (col.rows() != n) fail(PRISM_GPU_EINTERNAL, "output columns have different lengths");
-    ArrowArray& a = owner->children[c];
+namespace {
+
+// One column -> one ArrowArray whose buffers the owner keeps.
+void fill_array(BatchOwner* owner, OutColumn& col, ArrowArray& a) {
+    const size_t n = col.rows();
     std::memset(&a, 0, sizeof(a));
     int64_t nulls = 0;
     uint8_t* bits = nullptr;
@@ -223,9 +249,21 @@ void export_record_batch(std::vector<OutColumn>& cols, ArrowArray* out) {
         else ++nulls;
       }
     }
-    auto& bl = owner->buffer_lists[c];
+    owner->nested_buffer_lists.emplace_back();
+    auto& bl = owner->nested_buffer_lists.back();
     bl.push_back(nulls ? bits : nullptr);
-    if (col.type.is_string) {
+    if (col.type.logical == kTypeList) {
+      if (!col.items || col.list_off.size() != n + 1) fail(PRISM_GPU_EINTERNAL, "list column without its items");
+      int32_t* off = (int32_t*)owner->block((n + 1) * 4, false);
+      std::memcpy(off, col.list_off.data(), (n + 1) * 4);
+      bl.push_back(off);
+      owner->nested.emplace_back();
+      ArrowArray& child = owner->nested.back();
+      fill_array(owner, *col.items, child);
+      owner->nested_ptrs.emplace_back(1, &child);
+      a.n_children = 1;
+      a.children = owner->nested_ptrs.back().data();
+    } else if (col.type.is_string) {
       int32_t* off = (int32_t*)owner->block((n + 1) * 4, false);
       off[0] = 0;
       uint8_t* data = nullptr;
@@ -314,6 +352,17 @@ void export_record_batch(std::vector<OutColumn>& cols, ArrowArray* out) {
     a.buffers = bl.data();
     a.release = release_noop_array;
   }
+
+}  // namespace
+
+void export_record_batch(std::vector<OutColumn>& cols, ArrowArray* out) {
+  auto owner = std::make_unique<BatchOwner>();
+  const size_t n = cols.empty() ? 0 : cols[0].rows();
+  owner->children.resize(cols.size());
+  for (size_t c = 0; c < cols.size(); ++c) {
+    if (cols[c].rows() != n) fail(PRISM_GPU_EINTERNAL, "output columns have different lengths");
+    fill_array(owner.get(), cols[c], owner->children[c]);
+  }
   for (auto& a : owner->children) owner->child_ptrs.push_back(&a);
   std::memset(out, 0, sizeof(*out));
   out->length = (int64_t)n;
@@ -336,6 +385,19 @@ void export_schema(const std::vector<FieldType>& fields, ArrowSchema* out) {
     s.name = owner->names[i].c_str();
     s.flags = fields[i].nullable ? ARROW_FLAG_NULLABLE : 0;
     s.release = release_noop_schema;
+    if (fields[i].logical == kTypeList) {
+      owner->item_formats.push_back(fields[i].list_item);
+      owner->items.emplace_back();
+      ArrowSchema& item = owner->items.back();
+      std::memset(&item, 0, sizeof(item));
+      item.format = owner->item_formats.back().c_str();
+      item.name = "item";
+      item.flags = ARROW_FLAG_NULLABLE;
+      item.release = release_noop_schema;
+      owner->item_ptrs.emplace_back(1, &item);
+      s.n_children = 1;
+      s.children = owner->item_ptrs.back().data();
+    }
   }
   for (auto& s : owner->children) owner->child_ptrs.push_back(&s);
   std::memset(out, 0, sizeof(*out));

@@ -15,6 +15,9 @@ namespace prism {
 // state batches consumed by prism_gpu_merge.
 constexpr int kTypeUInt64 = 100;
 constexpr int kTypeFloat64 = 101;
+// List<T>: the state of a COUNT(DISTINCT) that stands next to other aggregates (the distinct
+// values a partition saw per group).  Only result batches and prism_gpu_merge's input carry it.
+constexpr int kTypeList = 102;
 
 struct FieldType {
   int logical = 0;      // prism_gpu_col_type or kTypeUInt64 / kTypeFloat64
@@ -25,7 +28,9 @@ struct FieldType {
   bool nullable = true;
   std::string format;   // Arrow format string of the value type
   std::string name;
+  std::string list_item;  // kTypeList: the format of the list's values (format is "+l")
 };
+FieldType list_field(const std::string& name, const std::string& item_format);
 
 FieldType field_from_format(const char* format);
 // Parses a struct-typed ArrowSchema into fields (dictionary-encoded Utf8 fields
@@ -45,6 +50,9 @@ struct OutColumn {
   const std::vector<std::string>* dict = nullptr;
   std::vector<uint32_t> codes;
   std::vector<uint8_t> valid;      // one byte per row
+  // kTypeList: row i holds items [list_off[i], list_off[i + 1]) of `items` (list_off starts with one 0)
+  std::shared_ptr<OutColumn> items;
+  std::vector<int32_t> list_off;
   // Borrowed rows: `ext_rows` 8-byte values (integers, doubles, or dictionary codes, by
   // `type` and `dict`) and validity bytes in a block that `ext_owner` keeps alive (a pinned
   // landing block the device wrote whole result columns into).  A column is either

@@ -167,6 +167,7 @@ struct prism_gpu_part {
   uint64_t pending_rows = 0, rows_total = 0, chunks_done = 0;
   std::unique_ptr<prism_gpu_table> staged;    // the chunk in flight: staged, not yet aggregated
   std::unique_ptr<prism_gpu_table> partials;  // PARTIAL state of the chunks aggregated so far
+  std::vector<ArrowArray> mixed_partials;     // the same for plans whose PARTIAL batches hold List columns (kept on the host)
   // Plain GROUP BY plans keep the partition's groups in HBM instead (part.cpp):
   bool keeps_state = false;
   std::unique_ptr<prism_gpu_table> table;     // the chunks in flight, and the dictionaries of the whole partition
@@ -191,6 +192,11 @@ void plan_value_range(const prism_gpu_plan* plan, int column, int64_t* lo, int64
 // batches of this plan and the result is the final rows.
 void execute_plan(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions,
                   bool merge_input, ArrowArray* out);
+
+// prism_gpu_merge for plans whose aggregates are of several kinds (COUNT(DISTINCT) next to
+// others or over several columns, MIN / MAX over strings): host batches in the plan's PARTIAL schema.
+void merge_mixed(prism_gpu_plan* plan, ArrowArray* const* states, size_t n_states, bool emit_partial, ArrowArray* out,
+                 prism_gpu_ctx* ctx_override = nullptr);
 
 // The same on a given (child) context, over all chunks of the table; emit_partial: PARTIAL
 // state columns whatever the plan's mode (merge_input + emit_partial merges states into states).

@@ -611,7 +611,7 @@ void append_key_columns(const prism_gpu_table* t, const std::vector<KeySrc>& key
 
 std::vector<OutColumn> make_columns(const std::vector<FieldType>& fields) {
   std::vector<OutColumn> cols;
-  for (auto& f : fields) cols.push_back(make_out_column(f.name, f.format, f.nullable));
+  for (auto& f : fields) cols.push_back(make_out_column(f.name, f.logical == kTypeList ? "+l:" + f.list_item : f.format, f.nullable));
   return cols;
 }
 
@@ -1801,7 +1801,8 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
                   bool merge_input, ArrowArray* out, const prism_gpu_col_stats* stats_override, prism_gpu_state** capture,
                   bool emit_partial = false, prism_gpu_ctx* ctx_override = nullptr, std::vector<OutColumn>* cols_out = nullptr,
                   const DistinctShardRequest* shard_req = nullptr);
-void execute_mixed(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions, ArrowArray* out);
+void execute_mixed(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions, ArrowArray* out,
+                   bool emit_partial = false, prism_gpu_ctx* ctx_override = nullptr);
 }
 
 void execute_plan(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions,
@@ -1815,6 +1816,10 @@ void execute_plan(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
 
 void execute_plan_on(prism_gpu_ctx* ctx, prism_gpu_plan* plan, prism_gpu_table* table, bool merge_input, bool emit_partial,
                      ArrowArray* out) {
+  if (plan->mixed && !merge_input) {
+    execute_mixed(plan, table, nullptr, 0, out, emit_partial, ctx);
+    return;
+  }
   execute_impl(plan, table, nullptr, 0, merge_input, out, nullptr, nullptr, emit_partial, ctx);
 }
 
@@ -2344,11 +2349,14 @@ void append_row_key(const std::vector<OutColumn>& cols, size_t n_keys, size_t ro
 // group) give the order, the others' results are looked up by group key and placed in the
 // order the plan lists its aggregates.  A string sub-plan lists (group, value) pairs: the
 // byte-lexicographic extremes per group are picked from them here.
-void execute_mixed(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions, ArrowArray* out) {
+// `res[k]`: sub-plan k's rows.  Sub-plan 0 and the COUNT(DISTINCT) sub-plans come as result
+// rows (partial == false) or as PARTIAL state rows (the plain aggregates' state columns; one
+// row per distinct (group, value) pair); the string sub-plans always as (group, value, count)
+// rows.  The output is the plan's result, or its PARTIAL state: per aggregate the plain state
+// columns, a List of the group's distinct values (DataFusion's state of a distinct count), or
+// the smallest / largest string so far.
+void mixed_join(prism_gpu_plan* plan, std::vector<std::vector<OutColumn>>& res, bool partial, ArrowArray* out) {
   const size_t n_subs = plan->subs.size(), n_keys = plan->keys.size();
-  std::vector<std::vector<OutColumn>> res(n_subs);
-  for (size_t k = 0; k < n_subs; ++k)
-    execute_impl(plan->subs[k].get(), table, partition_ids, n_partitions, false, nullptr, nullptr, nullptr, false, nullptr, &res[k]);
   const size_t rows = res[0].empty() ? 0 : res[0][0].rows();
   std::string key;
   std::unordered_map<std::string, size_t> group_row;  // group key -> row of sub-plan 0
@@ -2367,12 +2375,29 @@ void execute_mixed(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t*
     return it->second;
   };
   // per sub-plan: for every group (row of sub-plan 0) the row of the sub-plan's result, or for
-  // a string sub-plan the rows holding the group's smallest and largest value
+  // a string sub-plan the rows holding the group's smallest and largest value; for the pairs
+  // of a distinct sub-plan in PARTIAL form, the pair rows sorted by group
   constexpr size_t kNone = ~(size_t)0;
-  std::vector<std::vector<size_t>> row_of(n_subs), max_row_of(n_subs);
+  std::vector<std::vector<size_t>> row_of(n_subs), max_row_of(n_subs), pair_start(n_subs), pair_rows(n_subs);
   for (size_t k = 1; k < n_subs; ++k) {
     const size_t n_k = res[k].empty() ? 0 : res[k][0].rows();
     row_of[k].assign(rows, kNone);
+    if (plan->sub_string_col[k] < 0 && partial) {
+      const OutColumn& x = res[k][n_keys];
+      std::vector<size_t> group(n_k, kNone);
+      pair_start[k].assign(rows + 1, 0);
+      for (size_t i = 0; i < n_k; ++i) {
+        if (!x.valid_data()[i]) continue;  // COUNT(DISTINCT) ignores NULLs
+        group[i] = rows ? group_of(res[k], i) : kNone;
+        if (group[i] != kNone) pair_start[k][group[i] + 1] += 1;
+      }
+      for (size_t g = 0; g < rows; ++g) pair_start[k][g + 1] += pair_start[k][g];
+      pair_rows[k].resize(pair_start[k][rows]);
+      std::vector<size_t> at(pair_start[k].begin(), pair_start[k].end() - 1);
+      for (size_t i = 0; i < n_k; ++i)
+        if (group[i] != kNone) pair_rows[k][at[group[i]]++] = i;
+      continue;
+    }
     if (plan->sub_string_col[k] < 0) {
       if (n_k != rows) fail(PRISM_GPU_EINTERNAL, "the parts of the plan found different groups");
       for (size_t i = 0; i < n_k; ++i) row_of[k][group_of(res[k], i)] = i;
@@ -2388,22 +2413,53 @@ void execute_mixed(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t*
       if (max_row_of[k][g] == kNone || s > v.str_at(max_row_of[k][g])) max_row_of[k][g] = i;
     }
   }
-  std::vector<OutColumn> cols = make_columns(plan->final_fields);
+  std::vector<OutColumn> cols = make_columns(partial ? plan->partial_fields : plan->final_fields);
+  // where sub-plan 0's aggregates start among its columns (AVG has two state columns)
+  std::vector<size_t> sub0_at;
+  {
+    size_t at = n_keys;
+    for (const AggPlan& a : plan->subs[0]->aggs) {
+      sub0_at.push_back(at);
+      at += partial && a.func == PRISM_AGG_AVG ? 2 : 1;
+    }
+  }
+  size_t c = n_keys;
   for (size_t i = 0; i < plan->aggs.size(); ++i) {
-    OutColumn& dst = cols[n_keys + i];
     const auto [k, idx] = plan->mixed_map[i];
+    const size_t width = partial && plan->aggs[i].func == PRISM_AGG_AVG ? 2 : 1;
     if (k == 0) {
-      FieldType t = dst.type;
-      dst = std::move(res[0][n_keys + (size_t)idx]);
-      dst.type = t;
+      for (size_t w = 0; w < width; ++w) {
+        OutColumn& dst = cols[c + w];
+        FieldType t = dst.type;
+        // (an aggregate listed twice maps to the same column of sub-plan 0: copy, do not move)
+        dst = res[0][sub0_at[(size_t)idx] + w];
+        dst.type = t;
+      }
+      c += width;
       continue;
     }
+    OutColumn& dst = cols[c++];
     if (plan->sub_string_col[(size_t)k] >= 0) {
       const OutColumn& v = res[(size_t)k][n_keys];
       const std::vector<size_t>& pick = plan->aggs[i].func == PRISM_AGG_MIN ? row_of[(size_t)k] : max_row_of[(size_t)k];
       for (size_t r = 0; r < rows; ++r) {
         if (pick[r] == kNone) dst.push_null();
         else dst.push_str(v.str_at(pick[r]));
+      }
+      continue;
+    }
+    if (partial) {
+      const OutColumn& x = res[(size_t)k][n_keys];
+      OutColumn& items = *dst.items;
+      for (size_t r = 0; r < rows; ++r) {
+        for (size_t p = pair_start[(size_t)k][r]; p < pair_start[(size_t)k][r + 1]; ++p) {
+          const size_t at = pair_rows[(size_t)k][p];
+          if (x.type.is_string) items.push_str(x.str_at(at));
+          else items.push_int(x.i64_data()[at]);
+        }
+        if (items.rows() > 0x7fffffffull) fail(PRISM_GPU_EUNSUPPORTED, "more than 2^31 distinct values in one PARTIAL batch");
+        dst.list_off.push_back((int32_t)items.rows());
+        dst.valid.push_back(1);
       }
       continue;
     }
@@ -2417,14 +2473,170 @@ void execute_mixed(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t*
       else dst.push_int(src.i64[at]);
     }
   }
-  for (size_t c = 0; c < n_keys; ++c) {
-    FieldType t = cols[c].type;
-    cols[c] = std::move(res[0][c]);
-    cols[c].type = t;
+  for (size_t kc = 0; kc < n_keys; ++kc) {
+    FieldType t = cols[kc].type;
+    cols[kc] = std::move(res[0][kc]);
+    cols[kc].type = t;
   }
-  sort_and_limit(plan, cols);
+  if (!partial) sort_and_limit(plan, cols);
   export_record_batch(cols, out);
 }
+
+// COUNT(DISTINCT) next to other aggregates or over several columns, MIN / MAX over strings:
+// the sub-plans see the same rows and therefore the same groups; sub-plan 0's rows (one per
+// group) give the order, the others' results are looked up by group key and placed in the
+// order the plan lists its aggregates.  A string sub-plan lists (group, value) pairs: the
+// byte-lexicographic extremes per group are picked from them.
+void execute_mixed(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* partition_ids, size_t n_partitions, ArrowArray* out,
+                   bool emit_partial, prism_gpu_ctx* ctx_override) {
+  const size_t n_subs = plan->subs.size();
+  const bool partial = emit_partial || plan->mode == PRISM_MODE_PARTIAL;
+  std::vector<std::vector<OutColumn>> res(n_subs);
+  for (size_t k = 0; k < n_subs; ++k)
+    execute_impl(plan->subs[k].get(), table, partition_ids, n_partitions, false, nullptr, nullptr, nullptr,
+                 partial && plan->sub_string_col[k] < 0, ctx_override, &res[k]);
+  mixed_join(plan, res, partial, out);
+}
+
+// One cell of an Arrow array of the caller's (host memory) appended to an output column.
+void append_cell(OutColumn& dst, const ArrowArray* a, int64_t row) {
+  const int64_t at = a->offset + row;
+  const uint8_t* bits = a->n_buffers > 0 ? (const uint8_t*)a->buffers[0] : nullptr;
+  if (a->null_count != 0 && bits && !((bits[at >> 3] >> (at & 7)) & 1)) { dst.push_null(); return; }
+  const FieldType& f = dst.type;
+  if (f.is_string) {
+    const int32_t* off = (const int32_t*)a->buffers[1];
+    const char* data = (const char*)a->buffers[2];
+    dst.push_str(std::string(data + off[at], (size_t)(off[at + 1] - off[at])));
+  } else if (f.is_float) {
+    dst.push_float(((const double*)a->buffers[1])[at]);
+  } else if (f.width == 8) {
+    dst.push_int(((const int64_t*)a->buffers[1])[at]);
+  } else if (f.width == 4) {
+    dst.push_int(f.is_unsigned ? (int64_t)((const uint32_t*)a->buffers[1])[at] : (int64_t)((const int32_t*)a->buffers[1])[at]);
+  } else {
+    dst.push_int(f.is_unsigned ? (int64_t)((const uint16_t*)a->buffers[1])[at] : (int64_t)((const int16_t*)a->buffers[1])[at]);
+  }
+}
+
+}  // namespace
+
+// AggregateExec(Final) -- or, with emit_partial, state -> state -- over PARTIAL batches of a plan
+// whose aggregates are of several kinds: every batch is cut into the PARTIAL batches of the
+// sub-plans (the plain state columns as they are; a List of distinct values as one (group,
+// value) row per item; the smallest and the largest string as two (group, value) rows), the
+// sub-plans merge theirs on the device, and the results are joined as in execute_mixed.
+void merge_mixed(prism_gpu_plan* plan, ArrowArray* const* states, size_t n_states, bool emit_partial, ArrowArray* out, prism_gpu_ctx* ctx_override) {
+  prism_gpu_ctx* ctx = ctx_override ? ctx_override : plan->ctx;
+  bind(ctx);
+  const size_t n_subs = plan->subs.size(), n_keys = plan->keys.size();
+  const std::vector<FieldType>& in_fields = plan->partial_fields;
+  // the plan's aggregates -> their columns in a PARTIAL batch
+  std::vector<size_t> agg_at;
+  {
+    size_t at = n_keys;
+    for (const AggPlan& a : plan->aggs) {
+      agg_at.push_back(at);
+      at += a.func == PRISM_AGG_AVG ? 2 : 1;
+    }
+    if (at != in_fields.size()) fail(PRISM_GPU_EINTERNAL, "PARTIAL schema of the plan and its aggregates disagree");
+  }
+  for (size_t b = 0; b < n_states; ++b) {
+    const ArrowArray* batch = states[b];
+    if (!batch) fail(PRISM_GPU_EINVAL, "null state array");
+    if (batch->n_children != (int64_t)in_fields.size())
+      fail(PRISM_GPU_EINVAL, "state batch has " + std::to_string(batch->n_children) + " columns, the plan's PARTIAL schema has " + std::to_string(in_fields.size()));
+    if (batch->offset != 0) fail(PRISM_GPU_EUNSUPPORTED, "struct arrays with a non-zero offset are not supported");
+    for (int64_t cidx = 0; cidx < batch->n_children; ++cidx) {
+      const ArrowArray* a = batch->children[cidx];
+      if (a->dictionary) fail(PRISM_GPU_EUNSUPPORTED, "dictionary-encoded columns in the PARTIAL batches of this plan");
+      if (a->length < batch->length) fail(PRISM_GPU_EINVAL, "a state column is shorter than its batch");
+    }
+  }
+  std::vector<std::vector<OutColumn>> res(n_subs);
+  std::vector<std::unique_ptr<prism_gpu_table>> tables(n_subs);  // (string columns of `res` read the tables' dictionaries)
+  for (size_t k = 0; k < n_subs; ++k) {
+    prism_gpu_plan* sub = plan->subs[k].get();
+    const bool string_sub = plan->sub_string_col[k] >= 0;
+    tables[k] = std::make_unique<prism_gpu_table>();
+    prism_gpu_table* const table = tables[k].get();
+    table->ctx = ctx;
+    table->fields = sub->partial_fields;
+    table->dicts.resize(table->fields.size());
+    for (size_t b = 0; b < n_states; ++b) {
+      const ArrowArray* batch = states[b];
+      std::vector<OutColumn> cols = make_columns(sub->partial_fields);
+      auto keys_of = [&](int64_t r) {
+        for (size_t kc = 0; kc < n_keys; ++kc) append_cell(cols[kc], batch->children[kc], r);
+      };
+      if (k == 0) {
+        // the plain aggregates' state columns, in sub-plan 0's order
+        std::vector<size_t> src;  // column of the batch for every column of the sub-plan's PARTIAL schema
+        for (size_t kc = 0; kc < n_keys; ++kc) src.push_back(kc);
+        std::vector<size_t> sub_cols(sub->aggs.size(), ~(size_t)0);
+        for (size_t i = 0; i < plan->aggs.size(); ++i)
+          if (plan->mixed_map[i].first == 0) sub_cols[(size_t)plan->mixed_map[i].second] = agg_at[i];
+        for (size_t j = 0; j < sub->aggs.size(); ++j) {
+          if (sub_cols[j] == ~(size_t)0) {
+            // (no plain aggregate in the plan: sub-plan 0 counts rows only to list the groups)
+            src.push_back(~(size_t)0);
+            continue;
+          }
+          src.push_back(sub_cols[j]);
+          if (sub->aggs[j].func == PRISM_AGG_AVG) src.push_back(sub_cols[j] + 1);
+        }
+        if (src.size() != cols.size()) fail(PRISM_GPU_EINTERNAL, "PARTIAL schema of the plain aggregates disagrees with the plan's");
+        for (int64_t r = 0; r < batch->length; ++r)
+          for (size_t cidx = 0; cidx < cols.size(); ++cidx) {
+            if (src[cidx] == ~(size_t)0) cols[cidx].push_int(1);
+            else append_cell(cols[cidx], batch->children[src[cidx]], r);
+          }
+      } else if (!string_sub) {
+        // every item of the group's list: one (group, value) row; a group without items still is a group
+        size_t list_col = ~(size_t)0;
+        for (size_t i = 0; i < plan->aggs.size() && list_col == ~(size_t)0; ++i)
+          if (plan->mixed_map[i].first == (int)k) list_col = agg_at[i];
+        const ArrowArray* la = batch->children[list_col];
+        if (la->n_children != 1 || la->n_buffers < 2 || !la->buffers[1]) fail(PRISM_GPU_EINVAL, "the state of a COUNT(DISTINCT) must be a List column");
+        const int32_t* off = (const int32_t*)la->buffers[1] + la->offset;
+        const ArrowArray* items = la->children[0];
+        if (items->dictionary) fail(PRISM_GPU_EUNSUPPORTED, "dictionary-encoded list items");
+        const uint8_t* lbits = la->null_count != 0 && la->n_buffers > 0 ? (const uint8_t*)la->buffers[0] : nullptr;
+        for (int64_t r = 0; r < batch->length; ++r) {
+          const int64_t lr = la->offset + r;
+          const bool has = !lbits || ((lbits[lr >> 3] >> (lr & 7)) & 1);
+          const int32_t lo = has ? off[r] : 0, hi = has ? off[r + 1] : 0;
+          if (lo == hi) {
+            keys_of(r);
+            cols[n_keys].push_null();
+          }
+          for (int32_t j = lo; j < hi; ++j) {
+            keys_of(r);
+            append_cell(cols[n_keys], items, j);
+          }
+        }
+      } else {
+        // the smallest and the largest string so far: two (group, value) rows, each counted once
+        std::vector<size_t> from;
+        for (size_t i = 0; i < plan->aggs.size(); ++i)
+          if (plan->mixed_map[i].first == (int)k) from.push_back(agg_at[i]);
+        for (int64_t r = 0; r < batch->length; ++r)
+          for (size_t cidx : from) {
+            keys_of(r);
+            append_cell(cols[n_keys], batch->children[cidx], r);
+            cols[n_keys + 1].push_int(1);
+          }
+      }
+      ArrowArray piece;
+      export_record_batch(cols, &piece);
+      table_append(table, (uint32_t)b, &piece, true);
+    }
+    execute_impl(sub, table, nullptr, 0, true, nullptr, nullptr, nullptr, emit_partial && !string_sub, ctx_override, &res[k]);
+  }
+  mixed_join(plan, res, emit_partial, out);
+}
+
+namespace {
 
 }  // namespace
 

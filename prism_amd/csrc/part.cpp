@@ -195,6 +195,13 @@ bool stats_cover(const prism_gpu_part* part, const Chunk& ch) {
 }
 
 void partial_append(prism_gpu_part* part, ArrowArray* state) {
+  if (part->plan->mixed) {
+    // (List columns do not go into a table: the batches wait on the host for merge_mixed)
+    part->mixed_partials.push_back(*state);
+    state->release = nullptr;
+    part->chunks_done += 1;
+    return;
+  }
   if (!part->partials) part->partials = chunk_table(part->ctx, part->plan->partial_fields);
   table_append(part->partials.get(), 0, state, true);
   part->chunks_done += 1;
@@ -318,8 +325,6 @@ void stage_pending(prism_gpu_part* part) {
 }  // namespace
 
 std::unique_ptr<prism_gpu_part> part_open(prism_gpu_plan* plan, uint32_t partition) {
-  if (plan->mixed)
-    fail(PRISM_GPU_EUNSUPPORTED, "COUNT(DISTINCT) next to other aggregates has no PARTIAL form: it runs over resident partitions (prism_gpu_execute)");
   auto part = std::make_unique<prism_gpu_part>();
   part->plan = plan;
   part->partition = partition;
@@ -377,6 +382,16 @@ void part_finish(prism_gpu_part* part, ArrowArray* out) {
     }
     aggregate_staged(part, true);
   }
+  if (part->plan->mixed) {
+    std::vector<ArrowArray*> ptrs;
+    for (ArrowArray& a : part->mixed_partials) ptrs.push_back(&a);
+    merge_mixed(part->plan, ptrs.data(), ptrs.size(), partial_out, out, part->ctx);
+    for (ArrowArray& a : part->mixed_partials)
+      if (a.release) a.release(&a);
+    part->mixed_partials.clear();
+    part->chunks_done = 0;
+    return;
+  }
   if (!part->partials) part->partials = chunk_table(part->ctx, part->plan->partial_fields);
   execute_plan_on(part->ctx, part->plan, part->partials.get(), true, partial_out, out);
   part->partials.reset();
@@ -391,6 +406,9 @@ prism_gpu_part::~prism_gpu_part() {
   pending.clear();
   staged.reset();
   partials.reset();
+  for (ArrowArray& a : mixed_partials)
+    if (a.release) a.release(&a);
+  mixed_partials.clear();
   if (state) prism::state_free(state);
   state = nullptr;
   table.reset();

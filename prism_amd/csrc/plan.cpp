@@ -225,9 +225,6 @@ std::unique_ptr<prism_gpu_plan> plan_create(prism_gpu_ctx* ctx, const ArrowSchem
   if ((n_distinct && (n_distinct != d->n_aggs || several_distinct_columns)) || string_min_max) {
     // COUNT(DISTINCT) next to other aggregates or over several columns, MIN / MAX over strings:
     // one plan per kind over the same rows, joined on the keys
-    if (d->mode != PRISM_MODE_SINGLE)
-      fail(PRISM_GPU_EUNSUPPORTED, "COUNT(DISTINCT) next to other aggregates or over several columns, and MIN / MAX over "
-                                   "strings, are supported in SINGLE mode only");
     // kind 0: the plain aggregates; then one kind per distinct column (kind id = column) and
     // one per string column under MIN / MAX (kind id = -2 - column)
     std::vector<std::vector<prism_gpu_agg>> kinds(1);
@@ -245,6 +242,7 @@ std::unique_ptr<prism_gpu_plan> plan_create(prism_gpu_ctx* ctx, const ArrowSchem
     const prism_gpu_agg count_rows{PRISM_AGG_COUNT_STAR, -1, nullptr};
     for (size_t k = 0; k < kinds.size(); ++k) {
       prism_gpu_plan_desc sub = *d;
+      sub.mode = PRISM_MODE_SINGLE;  // (the plan asks a sub-plan for state rows where it wants them: exec.cpp, execute_mixed)
       sub.order_by = -1;
       sub.limit = -1;
       std::vector<prism_gpu_key> keys(d->keys, d->keys + d->n_keys);
@@ -290,6 +288,9 @@ std::unique_ptr<prism_gpu_plan> plan_create(prism_gpu_ctx* ctx, const ArrowSchem
         break;
       case PRISM_AGG_COUNT_DISTINCT:
         plan->final_fields.push_back(named(a.name, "l", false));
+        // next to other aggregates the state is the list of the group's distinct values (what
+        // DataFusion's distinct-count accumulator keeps); alone, the rows of the inner GROUP BY
+        if (plan->mixed) plan->partial_fields.push_back(list_field(a.name + "[count distinct]", f->format));
         break;
       case PRISM_AGG_SUM: {
         const char* fmt = f->is_unsigned ? "L" : "l";

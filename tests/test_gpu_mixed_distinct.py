@@ -1,7 +1,11 @@
-"""COUNT(DISTINCT x) next to other aggregates (SINGLE mode): the library runs the two halves
-over the same rows and joins them on the group keys.  The expectation is built the same way
-from two oracle runs (the oracle, like DataFusion's SingleDistinctToGroupBy rewrite, handles
-plans whose aggregates are all COUNT(DISTINCT) or none)."""
+"""COUNT(DISTINCT x) next to other aggregates: the library runs the two halves over the same
+rows and joins them on the group keys.  The expectation is built the same way from two oracle
+runs (the oracle, like DataFusion's SingleDistinctToGroupBy rewrite, handles plans whose
+aggregates are all COUNT(DISTINCT) or none).  In PARTIAL mode -- the mode the reference's
+physical plan runs an aggregate's first stage in, per partition
+(src/prism-query/src/providers/table_provider.rs:73-132 hands DataFusion one file group per
+partition) -- the state of such a COUNT(DISTINCT) is a List of the group's distinct values
+next to the ordinary state columns, and the state of a string MIN / MAX the string so far."""
 import pyarrow as pa
 import pytest
 
@@ -14,16 +18,23 @@ from prism_amd import _cabi as abi  # noqa: E402
 from prism_amd.plan import QueryPlan, avg, col, count_distinct, count_star, date_bin, max_, sum_  # noqa: E402
 
 
-def _expected(oracle, t, keys, aggs, predicate):
-    """One oracle run per kind of aggregate (the plain ones; the COUNT(DISTINCT)s of each
-    column), aligned on the group keys."""
+def _kinds(aggs):
     kinds = {}
     for i, a in enumerate(aggs):
         kinds.setdefault(a.column if a.func == abi.AGG_COUNT_DISTINCT else None, []).append(i)
+    return kinds
+
+
+def _expected(oracle, t, keys, aggs, predicate, run=None):
+    """One oracle run per kind of aggregate (the plain ones; the COUNT(DISTINCT)s of each
+    column), aligned on the group keys.  `run(kind, plan)`: where a kind's result comes from
+    (default: the oracle over `t`)."""
+    kinds = _kinds(aggs)
     n_keys = len(keys)
     per_kind = {}
     for kind, idxs in kinds.items():
-        res = oracle.execute(t, QueryPlan([aggs[i] for i in idxs], keys=keys, predicate=predicate))
+        q = QueryPlan([aggs[i] for i in idxs], keys=keys, predicate=predicate)
+        res = run(kind, q) if run else oracle.execute(t, q)
         rows = {}
         for r in range(res.num_rows):
             key = tuple(res.column(c)[r].as_py() for c in range(n_keys))
@@ -77,6 +88,83 @@ def test_count_distinct_beside_other_aggregates(gpu_ctx, keys, aggs, pred):
         g.close()
 
 
+def _kind_states(oracle, t, states, keys, aggs, kind, q):
+    """The PARTIAL batches of a plan of several kinds, cut down to the PARTIAL batches of one
+    kind in the oracle's own layout: the plain aggregates' state columns as they are; a List
+    column as one (group, value) row per item (and a NULL-value row per group, which a distinct
+    count ignores)."""
+    import pyarrow.compute as pc
+
+    n_keys = len(keys)
+    at, col_of = n_keys, []
+    for a in aggs:
+        col_of.append(at)
+        at += 2 if a.func == abi.AGG_AVG else 1
+    want = oracle.output_schema(t.schema, q.with_mode(abi.MODE_PARTIAL))
+    out = []
+    for s in states:
+        s = s.combine_chunks()
+        if kind is None:
+            cols = list(range(n_keys))
+            for i, a in enumerate(aggs):
+                if a.func != abi.AGG_COUNT_DISTINCT:
+                    cols += [col_of[i]] + ([col_of[i] + 1] if a.func == abi.AGG_AVG else [])
+            out.append(pa.table([s.column(c) for c in cols], schema=want))
+            continue
+        i = next(i for i, a in enumerate(aggs) if a.func == abi.AGG_COUNT_DISTINCT and a.column == kind)
+        lists = s.column(col_of[i]).chunk(0) if s.num_rows else pa.array([], type=s.schema.field(col_of[i]).type)
+        assert pa.types.is_list(lists.type)
+        parents = pc.list_parent_indices(lists)
+        arrays = [pa.concat_arrays([s.column(c).chunk(0).take(parents), s.column(c).chunk(0)]) if s.num_rows else s.column(c).chunk(0)
+                  for c in range(n_keys)]
+        values = pc.list_flatten(lists)
+        arrays.append(pa.concat_arrays([values, pa.nulls(s.num_rows, values.type)]) if s.num_rows else values)
+        out.append(pa.table(arrays, schema=want))
+    return out
+
+
+@pytest.mark.parametrize("keys,aggs,pred", [
+    (["service"], [count_star(), count_distinct("user"), sum_("value")], None),
+    (["service", "i16"], [count_distinct("user"), max_("u16"), avg("value")], "filter"),
+    ([], [count_distinct("i16"), count_star(), max_("value")], "filter"),
+    ([date_bin(3_600_000, "ts")], [sum_("i32"), count_distinct("service")], None),
+    (["service"], [count_distinct("user"), count_distinct("i16")], None),
+    (["i16"], [count_distinct("service"), count_star(), count_distinct("user"), count_distinct("service")], "filter"),
+    ([], [count_distinct("user"), count_distinct("value")], None),
+])
+def test_partial_then_merge_of_count_distinct_beside_other_aggregates(gpu_ctx, keys, aggs, pred):
+    """PARTIAL per partition on the GPU; the states merged by the GPU (prism_gpu_merge) and,
+    kind by kind, by the oracle's Final stage: both must equal the single-pass result."""
+    from oracle import pyoracle
+    from prism_amd.engine import Plan, Table
+
+    t = helpers.random_table(40_000, seed=31, nulls=True)
+    g = Table(gpu_ctx, t.schema)
+    g.append_table(t, 3)
+    predicate = (col("i32") > -500) if pred else None
+    try:
+        q = QueryPlan(aggs, keys=keys, predicate=predicate)
+        plan = Plan(gpu_ctx, t.schema, q.with_mode(abi.MODE_PARTIAL))
+        try:
+            states = [plan.execute(g, [p]) for p in range(g.num_partitions)]
+            got = plan.merge(states)
+        finally:
+            plan.close()
+        for s in states:  # a List per COUNT(DISTINCT), of the column's type
+            at = len(keys)
+            for a in aggs:
+                if a.func == abi.AGG_COUNT_DISTINCT:
+                    assert s.schema.field(at).type == pa.list_(t.schema.field(a.column).type), s.schema
+                at += 2 if a.func == abi.AGG_AVG else 1
+        want = _expected(pyoracle, t, keys, aggs, predicate)
+        assert_tables_match(got.rename_columns(want.schema.names), want, len(keys))
+        via_oracle = _expected(pyoracle, t, keys, aggs, predicate,
+                               run=lambda kind, qk: pyoracle.merge(t.schema, _kind_states(pyoracle, t, states, keys, aggs, kind, qk), qk))
+        assert_tables_match(via_oracle, want, len(keys))
+    finally:
+        g.close()
+
+
 def test_order_by_the_distinct_count_and_what_is_refused(gpu_ctx):
     from oracle import pyoracle
     from prism_amd.engine import Plan, PrismGpuError, Table
@@ -98,17 +186,21 @@ def test_order_by_the_distinct_count_and_what_is_refused(gpu_ctx):
         assert want.num_rows > 3
         for r in got.rename_columns(["service", "n", "d"]).to_pylist():
             assert by_service[r["service"]] == r
-        # no PARTIAL form, no streaming form
-        with pytest.raises(PrismGpuError) as e:
-            Plan(gpu_ctx, t.schema, QueryPlan(aggs, keys=["service"]).with_mode(abi.MODE_PARTIAL))
-        assert e.value.code == abi.EUNSUPPORTED
-        plan = Plan(gpu_ctx, t.schema, QueryPlan(aggs, keys=["service"]))
+        # the streaming form: every chunk becomes a PARTIAL batch (a List of distinct values per group), merged in finish
+        gpu_ctx.set_option("stream_chunk_rows", 5000)
         try:
-            with pytest.raises(PrismGpuError) as e:
-                plan.run_batches(0, t.to_batches(max_chunksize=8192))
-            assert e.value.code == abi.EUNSUPPORTED
+            for mode in (abi.MODE_SINGLE, abi.MODE_PARTIAL):
+                plan = Plan(gpu_ctx, t.schema, QueryPlan(aggs, keys=["service"]).with_mode(mode))
+                try:
+                    streamed = plan.run_batches(0, t.to_batches(max_chunksize=2048))
+                    if mode == abi.MODE_PARTIAL:
+                        assert pa.types.is_list(streamed.schema.field(2).type)
+                        streamed = plan.merge([streamed])
+                finally:
+                    plan.close()
+                assert_tables_match(streamed.rename_columns(want.schema.names), want, 1)
         finally:
-            plan.close()
+            gpu_ctx.set_option("stream_chunk_rows", 1 << 20)
     finally:
         g.close()
 
@@ -182,10 +274,18 @@ def test_min_max_over_strings(gpu_ctx):
         finally:
             plan.close()
         assert list(one.values()) == [_string_extremes(t, [], "w")[()][1], _string_extremes(t, [], "path")[()][0]]
-        # no PARTIAL form; SUM over strings stays refused
-        with pytest.raises(PrismGpuError) as e:
-            Plan(gpu_ctx, t.schema, QueryPlan([min_("w")], keys=["k"]).with_mode(abi.MODE_PARTIAL))
-        assert e.value.code == abi.EUNSUPPORTED
+        # PARTIAL per partition: the state is the smallest / largest string so far (Utf8), merged by prism_gpu_merge
+        plan = Plan(gpu_ctx, t.schema, q.with_mode(abi.MODE_PARTIAL))
+        try:
+            states = [plan.execute(g, [p]) for p in range(g.num_partitions)]
+            merged = plan.merge(states)
+        finally:
+            plan.close()
+        for s in states:
+            assert [s.schema.field(c).type for c in (1, 3, 4)] == [pa.string()] * 3 and s.schema.names[1].endswith("[min]")
+        assert sorted(merged.to_pylist(), key=lambda r: (r[names[0]] is None, r[names[0]])) == \
+            sorted(rows, key=lambda r: (r[names[0]] is None, r[names[0]]))
+        # SUM over strings stays refused
         with pytest.raises(PrismGpuError) as e:
             Plan(gpu_ctx, t.schema, QueryPlan([sum_("w")]))
         assert e.value.code == abi.EUNSUPPORTED
