@@ -742,8 +742,34 @@ __global__ __launch_bounds__(kBlock) void k_contains_mark(const ContainsSeg* seg
     const uint64_t m = matches[i];
     const ContainsSeg& s = segs[m >> 32];
     const uint64_t pos = m & 0xffffffffull;
-    // row with off[row] <= pos < off[row + 1]
-    uint64_t lo = 0, hi = s.rows;
+    // row with off[row] <= pos < off[row + 1].  A plain binary search over a segment's offsets is
+    // twenty dependent loads from twenty cache lines; the offsets grow almost linearly, so the
+    // search starts where the mean string length puts the row, corrects that guess twice by the
+    // byte distance still missing (a secant step: one load each), widens a bracket around it by
+    // doubling, and only then bisects -- a handful of loads, the last ones from one line.
+    const float inv_mean = (float)s.rows / (float)(s.n_bytes ? s.n_bytes : 1);
+    int64_t g = (int64_t)((float)pos * inv_mean);
+    const int64_t last = (int64_t)s.rows - 1;
+    g = g < 0 ? 0 : (g > last ? last : g);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int64_t d = (int64_t)(((float)pos - (float)(uint32_t)s.off[g]) * inv_mean);
+      g += d;
+      g = g < 0 ? 0 : (g > last ? last : g);
+    }
+    uint64_t lo, hi;
+    if ((uint64_t)(uint32_t)s.off[g] <= pos) {
+      lo = (uint64_t)g;
+      uint64_t step = 4;
+      hi = lo + step;
+      while (hi < s.rows && (uint64_t)(uint32_t)s.off[hi] <= pos) { lo = hi; step <<= 1; hi = lo + step; }
+      if (hi > s.rows) hi = s.rows;
+    } else {
+      hi = (uint64_t)g;
+      uint64_t step = 4;
+      lo = hi > step ? hi - step : 0;
+      while (lo > 0 && (uint64_t)(uint32_t)s.off[lo] > pos) { hi = lo; step <<= 1; lo = hi > step ? hi - step : 0; }
+    }
     while (hi - lo > 1) {
       const uint64_t mid = (lo + hi) >> 1;
       if ((uint64_t)(uint32_t)s.off[mid] <= pos) lo = mid; else hi = mid;

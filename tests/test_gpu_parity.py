@@ -328,12 +328,14 @@ def test_unsupported_and_invalid_plans(gpu_ctx):
     with pytest.raises(PrismGpuError) as e:
         Plan(gpu_ctx, t.schema, QueryPlan([count_star()], keys=[date_bin(0, "ts")]))
     assert e.value.code == abi.EINVAL
-    with pytest.raises(PrismGpuError) as e:  # COUNT(DISTINCT) beside other aggregates has no PARTIAL form
-        Plan(gpu_ctx, t.schema, QueryPlan([count_distinct("user"), count_star()]).with_mode(abi.MODE_PARTIAL))
-    assert e.value.code == abi.EUNSUPPORTED
-    with pytest.raises(PrismGpuError) as e:  # nor has COUNT(DISTINCT) over several columns
-        Plan(gpu_ctx, t.schema, QueryPlan([count_distinct("user"), count_distinct("i16")]).with_mode(abi.MODE_PARTIAL))
-    assert e.value.code == abi.EUNSUPPORTED
+    # COUNT(DISTINCT) beside other aggregates, or over several columns: the PARTIAL state of each is a List of its column's type
+    for aggs in ([count_distinct("user"), count_star()], [count_distinct("user"), count_distinct("i16")]):
+        p = Plan(gpu_ctx, t.schema, QueryPlan(aggs).with_mode(abi.MODE_PARTIAL))
+        try:
+            assert p.output_schema.field(0).type == pa.list_(pa.int64())
+            assert p.output_schema.field(1).type == (pa.int64() if aggs[1].func == abi.AGG_COUNT_STAR else pa.list_(pa.int16()))
+        finally:
+            p.close()
     with pytest.raises(KeyError):
         Plan(gpu_ctx, t.schema, QueryPlan([count_star()], keys=["something"]))
 
