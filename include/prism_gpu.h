@@ -214,6 +214,10 @@ void prism_gpu_ctx_free(prism_gpu_ctx* ctx);
  *   "part2_fixed"    0: the second partition level of COUNT(DISTINCT) always counts the rows of its
  *                    fine buckets first; 1 (default): fine buckets get regions of fixed size, and the counting
  *                    pass only runs when one overflows
+ *   "part2_direct"   0: COUNT(DISTINCT) partitioned twice always sorts its pairs into coarse buckets by the
+ *                    group key first; 1 (default): when the group key starts with a time key, the rows are
+ *                    taken to arrive in time order -- sorted by those bits already -- and the second level
+ *                    reads the columns itself (a plan whose rows turn out not to goes back to two levels)
  *   "part2_compact"  0: COUNT(DISTINCT) partitioned twice always keeps two-word records at the
  *                    second level; 1 (default): one-word records when the pairs allow it
  *   "contains_windows" 0: LIKE '%needle%' over a column without a dictionary always uses the

@@ -354,11 +354,21 @@ struct Part2Params {
   uint32_t n_src, world, rank;
   const uint32_t* seg_base;
   const uint32_t* seg_cnt;
+  // direct (one-word records only): there is no first level.  The pairs are packed from the
+  // scan's columns (the AggParams passed along: tiles [0, n_tiles), slice_tiles per workgroup) and
+  // the coarse bucket is the top p1_bits of the high word AS IT IS -- the group key's time
+  // bucket, which rows that arrive in time order already are sorted by; in_lo / in_hi /
+  // coarse_base are unused.  Rows whose coarse bucket lies outside the LDS counters of their
+  // slice (rows out of time order) are counted through global atomics and in *strays.
+  int32_t direct;
+  uint64_t n_tiles;
+  uint32_t slice_tiles;
+  unsigned long long* strays;
 };
 uint32_t part2_lds_entries(bool compact);
 // Records the output arrays must hold when the fine buckets get regions of fixed size.
 uint64_t part2_fixed_capacity(uint64_t n_rows, uint32_t n_fine);
-void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q);
+void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q, const AggParams* scan = nullptr);
 // The exchange of a sharded COUNT(DISTINCT): fine bucket (c, sub) belongs to rank c % world.
 // counts64: the buckets' distinct-record counts in owner-major order (owner by owner, inside an
 // owner's block by j = (c / world) * n_sub + sub), one 64-bit word each; launch_scan_u64 turns them

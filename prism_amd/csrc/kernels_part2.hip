@@ -18,11 +18,13 @@
 //
 // Algorithmic bytes per row: 16 read (hist) + 16 read + 16 written (scatter) + 16 read (agg).
 #include <algorithm>
+#include <cstring>
 
 #include "agg_device.hpp"
 #include "context.hpp"
 #include "device_utils.hpp"
 #include "kernels.hpp"
+#include "part_device.hpp"
 
 namespace prism {
 
@@ -41,6 +43,7 @@ constexpr size_t kP2LdsBytes = 160 * 1024 - 1024;
 typedef const __attribute__((address_space(1))) unsigned long long* P2WordPtr;
 
 __device__ __forceinline__ uint32_t coarse_of(const Part2Params& q, uint64_t hi) {
+  if (q.direct) return (uint32_t)(hi >> (q.hi_bits - (int)q.p1_bits));
   if (q.compact) return (uint32_t)(bij_mix(hi, q.hi_bits) >> (q.hi_bits - (int)q.p1_bits));
   return q.p1_bits ? (uint32_t)(part_hash_hi(hi) >> (64 - q.p1_bits)) : 0u;
 }
@@ -91,6 +94,99 @@ __global__ __launch_bounds__(kP2Block) void k_part2_hist(Part2Params q) {
     const uint32_t c = c0 + i / n_sub;
     if (cnt[i] && c < n_coarse) atomicAdd(&q.fine_count[((uint64_t)c << q.p2_bits) | (i % n_sub)], cnt[i]);
   }
+}
+
+// The pairs of two scan tiles a trip, packed from the scan's columns.  NK > 0 (the plan's key
+// columns carry no validity bitmaps: part_keys_ahead): the column words of the next trip are
+// requested before this trip's are used, so the loads are in flight during the trip's LDS work.
+template <int NK>
+struct P2Columns {
+  static constexpr bool kAhead = NK > 0;
+  static constexpr int NA = NK > 0 ? NK : 1, R = (int)kP2TileRows;
+  unsigned long long raw[NA][R];
+  uint32_t live_next;
+  PartCursor<NA> cur;
+  PartSegPos pos;
+  __device__ __forceinline__ void init(const AggParams& p, uint64_t T0, uint64_t T1, uint32_t tid) {
+    live_next = 0;
+#pragma unroll
+    for (int k = 0; k < NA; ++k)
+#pragma unroll
+      for (int r = 0; r < R; ++r) raw[k][r] = 0;
+    if (T0 >= T1) return;
+    if constexpr (kAhead) {
+      part_cursor_init<NA, 0>(p, cur, T0);
+      part_issue<NA, 0, R>(p, cur, T0, T1, tid, raw, live_next);
+    } else {
+      part_seg_init(p, pos, T0);
+    }
+  }
+  __device__ __forceinline__ void next(const AggParams& p, uint64_t T, uint64_t T1, uint32_t tid, uint64_t (&lo)[R], uint64_t (&hi)[R],
+                                       uint32_t& live) {
+    if constexpr (kAhead) {
+      uint64_t rec[2][R];
+      part_finish<2, NA, 0, R>(p, raw, rec);
+#pragma unroll
+      for (int r = 0; r < R; ++r) { lo[r] = rec[0][r]; hi[r] = rec[1][r]; }
+      live = live_next;
+      if (T + 2 < T1) part_issue<NA, 0, R>(p, cur, T + 2, T1, tid, raw, live_next);
+    } else {
+      PartTile tl[2];
+      tl[0] = part_tile_next(p, pos, T, T1);
+      tl[1] = part_tile_next(p, pos, T + 1, T1);
+      uint32_t rowc[R];
+      part_load_keys<2, R, (int)kP2Block>(p, tl, tid, lo, hi, rowc, live);
+    }
+  }
+};
+
+// The same counts taken from the scan's columns (Part2Params::direct): a workgroup walks
+// slice_tiles scan tiles, two at a time.  The LDS counters start at the coarse bucket of the
+// slice's first rows (rows in time order move on by at most one bucket within a slice).
+template <int NK>
+__global__ __launch_bounds__(kP2Block) void k_part2_hist_direct(Part2Params q, AggParams p) {
+  __shared__ uint32_t cnt[kP2Counters];
+  __shared__ uint32_t c_first, n_stray;
+  const uint32_t n_sub = 1u << q.p2_bits, span = span_of(q), tid = threadIdx.x;
+  for (uint32_t i = tid; i < span * n_sub; i += kP2Block) cnt[i] = 0;
+  if (tid == 0) { c_first = ~0u; n_stray = 0; }
+  const uint64_t T0 = (uint64_t)blockIdx.x * q.slice_tiles;
+  const uint64_t T1 = T0 + q.slice_tiles < q.n_tiles ? T0 + q.slice_tiles : q.n_tiles;
+  P2Columns<NK> in;
+  in.init(p, T0, T1, tid);
+  __syncthreads();
+  uint32_t c0 = 0;
+  uint32_t strays = 0;
+  for (uint64_t T = T0; T < T1; T += 2) {
+    uint64_t lo[kP2TileRows], hi[kP2TileRows];
+    uint32_t live;
+    in.next(p, T, T1, tid, lo, hi, live);
+    if (T == T0) {
+      // (the smallest coarse bucket among the first rows)
+      uint32_t mine = ~0u;
+#pragma unroll
+      for (uint32_t r = 0; r < kP2TileRows; ++r)
+        if ((live >> r) & 1u) { const uint32_t c = coarse_of(q, hi[r]); mine = c < mine ? c : mine; }
+      if (mine != ~0u) atomicMin(&c_first, mine);
+      __syncthreads();
+      c0 = c_first == ~0u ? 0u : c_first;
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < kP2TileRows; ++r) {
+      if (!((live >> r) & 1u)) continue;
+      const uint32_t c = coarse_of(q, hi[r]), s = sub_of(q, lo[r], hi[r]);
+      if (c - c0 < span) atomicAdd(&cnt[(c - c0) * n_sub + s], 1u);
+      else { atomicAdd(&q.fine_count[((uint64_t)c << q.p2_bits) | s], 1u); ++strays; }
+    }
+  }
+  if (strays) atomicAdd(&n_stray, strays);
+  __syncthreads();
+  const uint32_t n_coarse = 1u << q.p1_bits;
+  for (uint32_t i = tid; i < span * n_sub; i += kP2Block) {
+    const uint32_t c = c0 + i / n_sub;
+    if (cnt[i] && c < n_coarse) atomicAdd(&q.fine_count[((uint64_t)c << q.p2_bits) | (i % n_sub)], cnt[i]);
+  }
+  if (tid == 0 && n_stray && q.strays) atomicAdd(q.strays, (unsigned long long)n_stray);
 }
 
 // counts -> exclusive offsets (and the cursors the scatter pass advances); one workgroup
@@ -170,7 +266,8 @@ __device__ __forceinline__ void p2_block_scan(uint32_t* a, uint32_t n, uint32_t*
 // The tile's records are put in fine-bucket order in LDS first and leave as runs: written
 // straight from the registers, 8 bytes at a time to places 32 rows apart, the pass wrote 3.6
 // times its payload (partial cache lines).
-__global__ __launch_bounds__(kP2Block) void k_part2_scatter(Part2Params q) {
+template <bool DIRECT, int NK>
+__global__ __launch_bounds__(kP2Block) void k_part2_scatter(Part2Params q, AggParams p) {
   extern __shared__ __align__(16) unsigned long long p2s_lds[];
   constexpr uint32_t kTile = kP2Block * kP2TileRows;
   unsigned long long* s_lo = p2s_lds;
@@ -179,31 +276,64 @@ __global__ __launch_bounds__(kP2Block) void k_part2_scatter(Part2Params q) {
   uint32_t* lstart = cnt + kP2Counters;                // [kP2Counters + 1]: where a counter's run starts in the tile
   uint32_t* base = lstart + kP2Counters + 1;           // [kP2Counters]: and in the output
   __shared__ uint32_t wave_tot[kP2Block / 64];
+  __shared__ uint32_t c_first;
   const uint32_t n_sub = 1u << q.p2_bits, span = span_of(q), n_cnt = span * n_sub;
   const uint32_t n_coarse = 1u << q.p1_bits;
-  const uint64_t r0 = (uint64_t)blockIdx.x * q.slice_rows;
-  const uint64_t r1 = r0 + q.slice_rows < q.n_rows ? r0 + q.slice_rows : q.n_rows;
+  // the workgroup's share: records [r0, r1) of the first level, or (DIRECT) scan tiles [T0, T1), two per trip
+  uint64_t r0 = 0, r1 = 0, T0 = 0, T1 = 0, trips = 0;
+  P2Columns<DIRECT ? NK : 0> in;
+  if (DIRECT) {
+    T0 = (uint64_t)blockIdx.x * q.slice_tiles;
+    T1 = T0 + q.slice_tiles < q.n_tiles ? T0 + q.slice_tiles : q.n_tiles;
+    in.init(p, T0, T1, threadIdx.x);
+    trips = T1 > T0 ? (T1 - T0 + 1) / 2 : 0;
+  } else {
+    r0 = (uint64_t)blockIdx.x * q.slice_rows;
+    r1 = r0 + q.slice_rows < q.n_rows ? r0 + q.slice_rows : q.n_rows;
+    trips = r1 > r0 ? (r1 - r0 + kTile - 1) / kTile : 0;
+  }
   // every thread makes the same number of trips (the barriers are inside)
-  for (uint64_t t0 = r0; t0 < r1; t0 += kTile) {
+  for (uint64_t trip = 0; trip < trips; ++trip) {
+    const uint64_t t0 = r0 + trip * kTile;
     for (uint32_t i = threadIdx.x; i < kP2Counters; i += kP2Block) cnt[i] = 0;
-    const uint32_t c0 = __builtin_amdgcn_readfirstlane(coarse_of(q, q.in_hi[t0]));
+    if (DIRECT && threadIdx.x == 0) c_first = ~0u;
+    uint32_t c0 = 0;
+    if (!DIRECT) c0 = __builtin_amdgcn_readfirstlane(coarse_of(q, q.in_hi[t0]));
     __syncthreads();
     uint64_t lo[kP2TileRows], hi[kP2TileRows];
     uint32_t where[kP2TileRows];  // LDS counter (low 12 bits) and rank in it; ~0: handled directly
+    uint32_t live = 0;
+    if (DIRECT) {
+      in.next(p, T0 + 2 * trip, T1, threadIdx.x, lo, hi, live);
+      // the LDS counters start at the smallest coarse bucket among the tile's rows
+      uint32_t mine = ~0u;
+#pragma unroll
+      for (uint32_t r = 0; r < kP2TileRows; ++r)
+        if ((live >> r) & 1u) { const uint32_t c = coarse_of(q, hi[r]); mine = c < mine ? c : mine; }
+      if (mine != ~0u) atomicMin(&c_first, mine);
+      __syncthreads();
+      c0 = c_first == ~0u ? 0u : c_first;
+    } else {
+#pragma unroll
+      for (uint32_t r = 0; r < kP2TileRows; ++r) {
+        const uint64_t i = t0 + (uint64_t)r * kP2Block + threadIdx.x;
+        const bool in = i < r1;
+        const uint64_t ic = in ? i : t0;
+        lo[r] = __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.in_lo + ic));
+        hi[r] = __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.in_hi + ic));
+        live |= (in ? 1u : 0u) << r;
+      }
+    }
 #pragma unroll
     for (uint32_t r = 0; r < kP2TileRows; ++r) {
-      const uint64_t i = t0 + (uint64_t)r * kP2Block + threadIdx.x;
-      const bool in = i < r1;
-      const uint64_t ic = in ? i : t0;
-      lo[r] = __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.in_lo + ic));
-      hi[r] = __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.in_hi + ic));
       where[r] = ~0u;
-      if (!in) continue;
+      if (!((live >> r) & 1u)) continue;
       uint32_t c, s;
       if (q.compact) {
         // from here on the record is its two mixed words: the copy-out then only shifts and masks
+        // (DIRECT: the high word stays as it is, its top bits are the coarse bucket)
         lo[r] = mixed_lo(q, lo[r], hi[r]);
-        hi[r] = bij_mix(hi[r], q.hi_bits);
+        if (!DIRECT) hi[r] = bij_mix(hi[r], q.hi_bits);
         c = (uint32_t)(hi[r] >> (q.hi_bits - (int)q.p1_bits));
         s = (uint32_t)(lo[r] >> (q.lo_bits - (int)q.p2_bits));
       } else {
@@ -587,7 +717,7 @@ __global__ __launch_bounds__(kP2AggBlock) void k_part2_agg_compact(Part2Params q
       if (c == 0) continue;
       gcnt[i] = 0;
       my_pairs += c;
-      const uint64_t hi = bij_unmix((coarse << hi_rest) | i, q.hi_bits);
+      const uint64_t hi = q.direct ? ((coarse << hi_rest) | i) : bij_unmix((coarse << hi_rest) | i, q.hi_bits);
       const uint64_t e = global_entry_raw(q.dense, q.capacity, q.g_keys, q.overflow, hi);
       if (e != ~0ull) {
         // (no NULL bit in x in this form: every pair counts towards the distinct values)
@@ -715,8 +845,10 @@ uint32_t part2_lds_entries(bool compact) {
   return (uint32_t)((kP2LdsBytes / kP2AggPerCu - kP2Groups * 16 - 256) / (compact ? 8 : 16)) & ~63u;
 }
 
-void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q) {
+void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q, const AggParams* scan) {
   if (q.n_rows == 0) return;
+  if (q.direct && (!scan || !q.compact || q.fine_limit || q.emit_out || q.n_tiles == 0 || q.slice_tiles == 0 || (q.slice_tiles & 1u)))
+    fail(PRISM_GPU_EINTERNAL, "bad shape for a second partition level that reads the scan's columns");
   const uint32_t n_fine = 1u << (q.p1_bits + q.p2_bits);
   if (q.p2_bits > 10 || q.p1_bits + q.p2_bits > 21 || q.n_rows >= (1ull << 32) || q.slice_rows == 0)
     fail(PRISM_GPU_EINTERNAL, "bad shape for the second partition level");
@@ -726,14 +858,25 @@ void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q) {
     fail(PRISM_GPU_EINTERNAL, "bad shape for one-word records");
   if (q.fine_limit ? (q.out_capacity < part2_fixed_capacity(q.n_rows, n_fine) || q.out_capacity >= (1ull << 32)) : q.out_capacity < q.n_rows)
     fail(PRISM_GPU_EINTERNAL, "the second partition level's output array is too short");
-  const uint32_t slices = (uint32_t)ceil_div(q.n_rows, q.slice_rows);
+  const uint32_t slices = q.direct ? (uint32_t)ceil_div(q.n_tiles, (uint64_t)q.slice_tiles) : (uint32_t)ceil_div(q.n_rows, q.slice_rows);
+  AggParams none;
+  std::memset(&none, 0, sizeof(none));
+  const AggParams& ap = scan ? *scan : none;
+  // (key columns without validity bitmaps, at most one more than the key has words: their loads run a trip ahead)
+  int ahead = q.direct ? part_keys_ahead(ap) : 0;
+  if (ahead != 2 && ahead != 3) ahead = 0;
   if (q.fine_limit) {
     KernelTimer timer(ctx, "part2_layout", 0);
     k_part2_layout<<<dim3((uint32_t)ceil_div(n_fine + 1, 256)), dim3(256), 0, ctx->stream>>>(q, n_fine);
     PRISM_HIP(hipGetLastError());
   } else {
     KernelTimer timer(ctx, "part2_hist", q.n_rows * 16);
-    k_part2_hist<<<dim3(slices), dim3(kP2Block), 0, ctx->stream>>>(q);
+    if (q.direct) {
+      auto kernel = ahead == 3 ? k_part2_hist_direct<3> : ahead == 2 ? k_part2_hist_direct<2> : k_part2_hist_direct<0>;
+      kernel<<<dim3(slices), dim3(kP2Block), 0, ctx->stream>>>(q, ap);
+    } else {
+      k_part2_hist<<<dim3(slices), dim3(kP2Block), 0, ctx->stream>>>(q);
+    }
     PRISM_HIP(hipGetLastError());
     k_part2_scan<<<dim3(1), dim3(1024), 0, ctx->stream>>>(q, n_fine);
     PRISM_HIP(hipGetLastError());
@@ -741,8 +884,10 @@ void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q) {
   {
     KernelTimer timer(ctx, "part2_scatter", q.n_rows * (q.compact ? 24 : 32));
     const size_t lds = (size_t)kP2Block * kP2TileRows * 16 + (size_t)(3 * kP2Counters + 1) * 4;
-    PRISM_HIP(hipFuncSetAttribute((const void*)k_part2_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    k_part2_scatter<<<dim3(slices), dim3(kP2Block), lds, ctx->stream>>>(q);
+    auto kernel = !q.direct ? k_part2_scatter<false, 0> : ahead == 3 ? k_part2_scatter<true, 3> : ahead == 2 ? k_part2_scatter<true, 2>
+                                                                                                          : k_part2_scatter<true, 0>;
+    PRISM_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    kernel<<<dim3(slices), dim3(kP2Block), lds, ctx->stream>>>(q, ap);
     PRISM_HIP(hipGetLastError());
   }
   {

@@ -207,6 +207,7 @@ def test_count_distinct_partitioned_twice(part_ctx, oracle):
     rows = 1_500_000
     # (and both ways of placing the fine buckets: regions of fixed size, the default, and exact
     # places from a histogram pass over the records)
+    part_ctx.set_option("part2_direct", 0)  # (the two levels: what rows in no particular order take)
     for compact, record_bytes, fixed in ((1, 8, 1), (0, 16, 1), (1, 8, 0), (0, 16, 0)):
         part_ctx.set_option("part2_compact", compact)
         part_ctx.set_option("part2_fixed", fixed)
@@ -219,6 +220,13 @@ def test_count_distinct_partitioned_twice(part_ctx, oracle):
         assert agg["algorithmic_bytes"] == agg["launches"] * rows * record_bytes
     part_ctx.set_option("part2_compact", 1)
     part_ctx.set_option("part2_fixed", 1)
+    # The generated rows are in time order and the group key starts with the hour: sorted by the
+    # group key's top bits already, so there is no first level -- the one partition pass reads the columns
+    part_ctx.set_option("part2_direct", 1)
+    part_ctx.reset_stats()
+    _synth_both(part_ctx, oracle, wl, rows, 4, [(wl.query, 2)])
+    ran = _kernels(part_ctx)
+    assert {"part2_hist", "part2_scatter", "part2_agg"} <= ran and not ({"part_scatter", "part_hist", "part2_layout"} & ran), ran
 
     rng = np.random.default_rng(21)
     n = 300_000
@@ -245,6 +253,59 @@ def test_count_distinct_partitioned_twice(part_ctx, oracle):
             else:
                 assert_tables_match(got, want, len(q.keys))
                 assert_tables_match(again, want, len(q.keys))
+    finally:
+        g.close()
+
+
+def test_count_distinct_over_rows_out_of_time_order(part_ctx, oracle):
+    """The same query over rows in no order at all: the pass that takes the rows as sorted by
+    the hour still counts right (rows outside its LDS counters go through global atomics), the
+    plan notices, and its next run sorts by the group key first."""
+    import numpy as np
+    import pyarrow as pa
+    from prism_amd.engine import Plan, Table
+
+    rng = np.random.default_rng(9)
+    n = 600_000
+    t = pa.table({"ts": pa.array(1_700_000_000_000 + rng.integers(0, 40 * 3_600_000, n), pa.timestamp("ms")),
+                  "svc": pa.array(rng.integers(0, 12, n).astype(np.int32)),
+                  "user": pa.array(rng.integers(0, 30_000, n).astype(np.int64) * (2**62 // 30_000) - 2**61)})  # (62-bit ids: the pair takes two words)
+    q = QueryPlan([count_distinct("user")], keys=[date_bin(3_600_000, "ts"), "svc"])
+    want = oracle.execute(t, q)
+    g = Table(part_ctx, t.schema)
+    g.append_table(t, 3)
+    try:
+        plan = Plan(part_ctx, t.schema, q)
+        try:
+            part_ctx.reset_stats()
+            first = plan.execute(g)
+            ran_first = _kernels(part_ctx)
+            part_ctx.reset_stats()
+            second = plan.execute(g)
+            ran_second = _kernels(part_ctx)
+        finally:
+            plan.close()
+        assert_tables_match(first, want, 2)
+        assert_tables_match(second, want, 2)
+        assert "part2_scatter" in ran_first and "part_scatter" not in ran_first, ran_first
+        assert "part_scatter" in ran_second, ran_second
+        # rows in time order within every partition: no first level, both times
+        ts = t.column("ts").cast(pa.int64()).to_numpy()
+        order = np.argsort(ts, kind="stable")
+        sorted_t = t.take(pa.array(order))
+        gs = Table(part_ctx, t.schema)
+        gs.append_table(sorted_t, 3)
+        try:
+            plan = Plan(part_ctx, t.schema, q)
+            try:
+                for _ in range(2):
+                    part_ctx.reset_stats()
+                    assert_tables_match(plan.execute(gs), want, 2)
+                    assert "part_scatter" not in _kernels(part_ctx)
+            finally:
+                plan.close()
+        finally:
+            gs.close()
     finally:
         g.close()
 
