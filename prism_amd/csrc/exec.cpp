@@ -1506,12 +1506,13 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggPar
   if (!compact) p2 = fine_bits(p1, part2_lds_entries(false));
   // ---- no first level at all? ----
   bool direct = false;
+  uint64_t coarse_used = 0;  // (direct) coarse buckets the scanned rows span
   if (!shard && time_bits > 0 && time_buckets > 0 && ctx->part2_direct.load(std::memory_order_relaxed) != 0 &&
       plan->part2_direct.load(std::memory_order_relaxed) >= 0 && ctx->part2_compact.load(std::memory_order_relaxed) != 0 &&
       layout.fields[0].null_bit < 0 && lo_bits <= 63 && ap.row_mode != kRowsSelvec) {
     const int d1 = std::min(time_bits, 11);
     // fine buckets of at most the rows the LDS set takes in one go, where the rows allow it
-    const uint64_t coarse_used = std::max<uint64_t>(1, time_buckets >> (time_bits - d1));
+    coarse_used = std::min<uint64_t>(1ull << d1, (time_buckets >> (time_bits - d1)) + 1);
     const uint64_t fine_rows = (uint64_t)part2_lds_entries(true) * 3 / 8 * rows_per_entry_x8 / 8;
     int d2 = 0;
     while (d2 < 10 && sizing / (coarse_used << d2) > fine_rows) ++d2;
@@ -1581,8 +1582,22 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggPar
   const uint64_t fixed_capacity = part2_fixed_capacity(selected, n_fine);
   bool fixed = !shard && !direct && ctx->part2_fixed.load(std::memory_order_relaxed) != 0 && plan->part2_fixed.load(std::memory_order_relaxed) >= 0 &&
                fixed_capacity < (1ull << 32);
+  // (no first level:) regions of one size for the fine buckets the rows can reach, half as large again as
+  // their even share, and a spill list for what does not fit them -- no histogram pass either
+  const uint32_t n_regions = direct ? (uint32_t)std::min<uint64_t>(n_fine, coarse_used << p2) : 0;
+  const uint32_t region_cap = direct ? (uint32_t)(((((selected / std::max<uint64_t>(1, coarse_used)) >> p2) * 3 / 2 + 64) + 15) & ~15ull) : 0;
+  const uint64_t spill_capacity = selected / 2 + 4096, region_records = (uint64_t)n_regions * region_cap;
+  bool spill = direct && ctx->part2_fixed.load(std::memory_order_relaxed) != 0 && plan->part2_fixed.load(std::memory_order_relaxed) >= 0 &&
+               region_records + spill_capacity < (1ull << 32);
+  Scratch spill_rec, spill_fine, spill_small;
+  if (spill) {
+    spill_rec = Scratch(ctx, spill_capacity * 8);
+    spill_fine = Scratch(ctx, spill_capacity * 4);
+    spill_small = Scratch(ctx, ((size_t)3 * (n_regions + 1) + (size_t)4 * n_regions) * 4 + 64);
+  }
   for (int w = 0; w < 2; ++w)
-    if (w == 0 || !compact) rec2[w] = Scratch(ctx, (fixed ? fixed_capacity : selected) * 8 + 256);
+    if (w == 0 || !compact)
+      rec2[w] = Scratch(ctx, std::max<uint64_t>(fixed ? fixed_capacity : selected, spill ? region_records + spill_capacity : 0) * 8 + 256);
   Scratch d_fine(ctx, (size_t)n_fine * 16 + 64);
   struct { uint32_t flags[2]; uint64_t pad[2]; unsigned long long pairs[8]; } h{};
   static_assert(sizeof(h) == 88, "layout of the small block from offset 40 on");
@@ -1627,18 +1642,45 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggPar
       q2.in_lo = q2.in_hi = nullptr;
       q2.coarse_base = nullptr;
       q2.n_tiles = ap.sd.n_tiles;
-      q2.slice_tiles = 16;
+      // A slice keeps the LDS counters where its first rows put them: it should not run through more
+      // coarse buckets than half of what the counters span (2048 counters, at most 8 coarse buckets).
+      const uint64_t span = std::min<uint64_t>(8, 2048u >> p2), rows_per_coarse = selected / std::max<uint64_t>(1, coarse_used);
+      const uint64_t slice_rows = std::max<uint64_t>(1, span / 2) * rows_per_coarse;
+      q2.slice_tiles = (uint32_t)std::max<uint64_t>(2, std::min<uint64_t>(32, (slice_rows / (2 * kTileRows)) * 2));
       q2.strays = (unsigned long long*)(d_small.as<uint8_t>() + 48);
+      if (spill) {
+        PRISM_HIP(hipMemsetAsync(spill_small.p, 0, ((size_t)3 * (n_regions + 1) + (size_t)4 * n_regions) * 4 + 64, ctx->stream));
+        q2.fine_limit = d_fine.as<uint32_t>() + 3 * (size_t)n_fine + 1;
+        q2.out_capacity = region_records + spill_capacity;
+        q2.spill_rec = spill_rec.as<uint64_t>();
+        q2.spill_fine = spill_fine.as<uint32_t>();
+        q2.spill_cursor = (unsigned long long*)(d_small.as<uint8_t>() + 56);
+        q2.spill_capacity = spill_capacity;
+        q2.n_regions = n_regions;
+        q2.region_cap = region_cap;
+        q2.spill_count = spill_small.as<uint32_t>();
+        q2.spill_base = q2.spill_count + (n_regions + 1);
+        q2.spill_cur = q2.spill_base + (n_regions + 1);
+        q2.seg_base_out = q2.spill_cur + (n_regions + 1);
+        q2.seg_cnt_out = q2.seg_base_out + 2 * (size_t)n_regions;
+      }
     }
     launch_distinct_second_level(ctx, q2, direct ? &ap : nullptr);
     PRISM_HIP(hipMemcpyAsync(&h, q2.flags, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     PRISM_HIP(hipStreamSynchronize(ctx->stream));
     collect_timings(ctx);
     if (std::getenv("PRISM_WC_DEBUG"))
-      std::fprintf(stderr, "[part2] p1 %d p2 %d compact %d fixed %d direct %d rows %llu: flags %u %u strays %llu\n", p1, p2, (int)compact, (int)fixed,
-                   (int)direct, (unsigned long long)selected, h.flags[0], h.flags[1], (unsigned long long)h.pad[0]);
+      std::fprintf(stderr, "[part2] p1 %d p2 %d compact %d fixed %d direct %d spill %d rows %llu: flags %u %u strays %llu spilled %llu\n", p1, p2,
+                   (int)compact, (int)fixed, (int)direct, (int)spill, (unsigned long long)selected, h.flags[0], h.flags[1],
+                   (unsigned long long)h.pad[0], (unsigned long long)h.pad[1]);
     // (rows out of time order: the next run sorts by the group key first again)
     if (direct && h.pad[0] > selected / 8) plan->part2_direct.store(-1, std::memory_order_relaxed);
+    if (spill && h.flags[1] != 0) {
+      // the spill list ran over (few distinct pairs that repeat a great deal): exact places from a histogram from now on
+      plan->part2_fixed.store(-1, std::memory_order_relaxed);
+      spill = false;
+      continue;
+    }
     if (fixed && h.flags[1] != 0) {
       // a fine bucket outgrew its region (few distinct values that repeat a lot): exact places from now on
       plan->part2_fixed.store(-1, std::memory_order_relaxed);

@@ -364,6 +364,20 @@ struct Part2Params {
   uint64_t n_tiles;
   uint32_t slice_tiles;
   unsigned long long* strays;
+  // spill_rec set (direct only): no histogram pass either.  The first n_regions fine buckets get
+  // regions of region_cap records each (fine_limit set by the library), and what does not fit a
+  // region goes to a spill list -- record and bucket number, one reservation in *spill_cursor
+  // per tile -- which is then sorted by bucket (spill_count / spill_base / spill_cur: n_regions
+  // + 1 words each, zero on entry) behind the regions in out_lo; the last pass takes a bucket
+  // as the two runs (seg_base / seg_cnt: 2 x n_regions words).  A spill list that runs over
+  // sets flags[1].
+  uint64_t* spill_rec;
+  uint32_t* spill_fine;
+  unsigned long long* spill_cursor;
+  uint64_t spill_capacity;
+  uint32_t n_regions, region_cap;
+  uint32_t *spill_count, *spill_base, *spill_cur;
+  uint32_t *seg_base_out, *seg_cnt_out;
 };
 uint32_t part2_lds_entries(bool compact);
 // Records the output arrays must hold when the fine buckets get regions of fixed size.

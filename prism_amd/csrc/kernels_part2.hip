@@ -242,6 +242,76 @@ __global__ __launch_bounds__(256) void k_part2_layout(Part2Params q, uint32_t n_
   q.fine_limit[f] = (uint32_t)(at + cap);
 }
 
+// Regions of one size for the first n_regions fine buckets (Part2Params::spill_rec).
+__global__ __launch_bounds__(256) void k_part2_layout_uniform(Part2Params q, uint32_t n_fine) {
+  const uint32_t f = blockIdx.x * 256 + threadIdx.x;
+  if (f > n_fine) return;
+  const uint32_t r = f < q.n_regions ? f : q.n_regions;
+  const uint32_t at = r * q.region_cap;
+  q.fine_base[f] = at;
+  if (f == n_fine) return;
+  q.fine_cursor[f] = at;
+  q.fine_limit[f] = f < q.n_regions ? at + q.region_cap : at;
+}
+
+// The spill list sorted by fine bucket: counts, a scan (k_part2_scan), places.  Neighbouring
+// records mostly share a bucket (a tile spills its buckets' surplus run by run): a wave takes 64
+// neighbouring records, finds the runs with a ballot, and the first lane of a run does the one
+// atomic for all of it -- the loads and the stores stay coalesced.
+__device__ __forceinline__ uint64_t spill_len(const Part2Params& q) {
+  const unsigned long long n = *q.spill_cursor;
+  return n < q.spill_capacity ? n : q.spill_capacity;
+}
+// lane's run among the wave's records: `head` lanes start one; returns the run's first lane and its length
+__device__ __forceinline__ void spill_run(bool in, uint32_t f, uint32_t lane, uint32_t& first, uint32_t& len) {
+  const uint32_t prev = __shfl_up(f, 1, 64);
+  const bool head = in && (lane == 0 || f != prev);
+  const uint64_t heads = __ballot(head), live = __ballot(in);
+  const uint64_t upto = heads & ((lane == 63 ? 0ull : (2ull << lane)) - 1ull);  // heads at or below this lane
+  first = upto ? 63u - (uint32_t)__builtin_clzll(upto) : 0u;
+  const uint64_t above = first == 63 ? 0ull : (heads & ~((2ull << first) - 1ull));  // the next run's head
+  const uint32_t end = above ? (uint32_t)__builtin_ctzll(above) : (uint32_t)__popcll(live);
+  len = end - first;
+}
+__global__ __launch_bounds__(256) void k_spill_count(Part2Params q) {
+  const uint64_t n = spill_len(q);
+  const uint32_t lane = threadIdx.x & 63u;
+  for (uint64_t i0 = (uint64_t)blockIdx.x * 256 + (threadIdx.x & ~63u); i0 < n; i0 += (uint64_t)gridDim.x * 256) {
+    const uint64_t i = i0 + lane;
+    const bool in = i < n;
+    const uint32_t f = in ? q.spill_fine[i] : ~0u;
+    uint32_t first, len;
+    spill_run(in, f, lane, first, len);
+    if (in && lane == first) atomicAdd(&q.spill_count[f], len);
+  }
+}
+__global__ __launch_bounds__(256) void k_spill_place(Part2Params q, uint64_t out_offset) {
+  const uint64_t n = spill_len(q);
+  const uint32_t lane = threadIdx.x & 63u;
+  for (uint64_t i0 = (uint64_t)blockIdx.x * 256 + (threadIdx.x & ~63u); i0 < n; i0 += (uint64_t)gridDim.x * 256) {
+    const uint64_t i = i0 + lane;
+    const bool in = i < n;
+    const uint32_t f = in ? q.spill_fine[i] : ~0u;
+    const uint64_t rec = in ? q.spill_rec[i] : 0ull;
+    uint32_t first, len;
+    spill_run(in, f, lane, first, len);
+    uint32_t at = 0;
+    if (in && lane == first) at = atomicAdd(&q.spill_cur[f], len);
+    at = __shfl(at, (int)first, 64);
+    if (in) q.out_lo[out_offset + at + (lane - first)] = rec;
+  }
+}
+// A fine bucket as two runs of out_lo: what its region took, and its part of the sorted spill list.
+__global__ __launch_bounds__(256) void k_spill_runs(Part2Params q, uint64_t out_offset) {
+  const uint32_t f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= q.n_regions) return;
+  const uint32_t b = q.fine_base[f], end = q.fine_cursor[f], lim = q.fine_limit[f];
+  q.seg_base_out[f] = b;
+  q.seg_cnt_out[f] = (end < lim ? end : lim) - b;
+  q.seg_base_out[q.n_regions + f] = (uint32_t)(out_offset + q.spill_base[f]);
+  q.seg_cnt_out[q.n_regions + f] = q.spill_count[f];
+}
+
 // Exclusive scan of n (<= 2 * kP2Block, even) LDS counters in place; a[n] receives the total.
 __device__ __forceinline__ void p2_block_scan(uint32_t* a, uint32_t n, uint32_t* wave_tot) {
   const uint32_t t = threadIdx.x, i0 = 2 * t;
@@ -277,10 +347,16 @@ __global__ __launch_bounds__(kP2Block) void k_part2_scatter(Part2Params q, AggPa
   uint32_t* base = lstart + kP2Counters + 1;           // [kP2Counters]: and in the output
   __shared__ uint32_t wave_tot[kP2Block / 64];
   __shared__ uint32_t c_first;
+  __shared__ uint32_t n_stray;                 // (DIRECT) rows beyond the tile's LDS counters: rows out of time order
+  __shared__ uint32_t spill_n;                 // records of the tile that go to the spill list
+  __shared__ unsigned long long spill_at;      // and where the tile's part of the list starts
+  const bool spills = DIRECT && q.spill_rec != nullptr;
   const uint32_t n_sub = 1u << q.p2_bits, span = span_of(q), n_cnt = span * n_sub;
   const uint32_t n_coarse = 1u << q.p1_bits;
   // the workgroup's share: records [r0, r1) of the first level, or (DIRECT) scan tiles [T0, T1), two per trip
   uint64_t r0 = 0, r1 = 0, T0 = 0, T1 = 0, trips = 0;
+  uint32_t strays = 0, c_slice = 0;
+  if (DIRECT && threadIdx.x == 0) { n_stray = 0; c_first = ~0u; }
   P2Columns<DIRECT ? NK : 0> in;
   if (DIRECT) {
     T0 = (uint64_t)blockIdx.x * q.slice_tiles;
@@ -296,7 +372,7 @@ __global__ __launch_bounds__(kP2Block) void k_part2_scatter(Part2Params q, AggPa
   for (uint64_t trip = 0; trip < trips; ++trip) {
     const uint64_t t0 = r0 + trip * kTile;
     for (uint32_t i = threadIdx.x; i < kP2Counters; i += kP2Block) cnt[i] = 0;
-    if (DIRECT && threadIdx.x == 0) c_first = ~0u;
+    if (DIRECT && threadIdx.x == 0) spill_n = 0;
     uint32_t c0 = 0;
     if (!DIRECT) c0 = __builtin_amdgcn_readfirstlane(coarse_of(q, q.in_hi[t0]));
     __syncthreads();
@@ -305,14 +381,19 @@ __global__ __launch_bounds__(kP2Block) void k_part2_scatter(Part2Params q, AggPa
     uint32_t live = 0;
     if (DIRECT) {
       in.next(p, T0 + 2 * trip, T1, threadIdx.x, lo, hi, live);
-      // the LDS counters start at the smallest coarse bucket among the tile's rows
-      uint32_t mine = ~0u;
+      // The LDS counters start at the smallest coarse bucket among the slice's first rows and stay
+      // there: rows in time order move on by at most a bucket or two within a slice, and a barrier
+      // per tile to follow them costs more than the few rows that then take the direct way.
+      if (trip == 0) {
+        uint32_t mine = ~0u;
 #pragma unroll
-      for (uint32_t r = 0; r < kP2TileRows; ++r)
-        if ((live >> r) & 1u) { const uint32_t c = coarse_of(q, hi[r]); mine = c < mine ? c : mine; }
-      if (mine != ~0u) atomicMin(&c_first, mine);
-      __syncthreads();
-      c0 = c_first == ~0u ? 0u : c_first;
+        for (uint32_t r = 0; r < kP2TileRows; ++r)
+          if ((live >> r) & 1u) { const uint32_t c = coarse_of(q, hi[r]); mine = c < mine ? c : mine; }
+        if (mine != ~0u) atomicMin(&c_first, mine);
+        __syncthreads();
+        c_slice = c_first == ~0u ? 0u : c_first;
+      }
+      c0 = c_slice;
     } else {
 #pragma unroll
       for (uint32_t r = 0; r < kP2TileRows; ++r) {
@@ -345,10 +426,23 @@ __global__ __launch_bounds__(kP2Block) void k_part2_scatter(Part2Params q, AggPa
         where[r] = li | (atomicAdd(&cnt[li], 1u) << 12);
       } else {
         // beyond the coarse buckets the counters cover: a place of its own
+        if (DIRECT) ++strays;
         const uint64_t ff = ((uint64_t)c << q.p2_bits) | s;
         const uint32_t g = atomicAdd(&q.fine_cursor[ff], 1u);
-        if (q.fine_limit && g >= q.fine_limit[ff]) q.flags[1] = 1u;
-        else if (g < q.out_capacity) {
+        if (q.fine_limit && g >= q.fine_limit[ff]) {
+          if (spills) {
+            const int lo_rest = q.lo_bits - (int)q.p2_bits, hi_rest = q.hi_bits - (int)q.p1_bits;
+            const unsigned long long at = atomicAdd(q.spill_cursor, 1ull);
+            if (at < q.spill_capacity) {
+              q.spill_rec[at] = ((hi[r] & ((1ull << hi_rest) - 1ull)) << lo_rest) | (lo[r] & ((1ull << lo_rest) - 1ull));
+              q.spill_fine[at] = (uint32_t)ff;
+            } else {
+              q.flags[1] = 1u;
+            }
+          } else {
+            q.flags[1] = 1u;
+          }
+        } else if (g < q.out_capacity) {
           if (q.compact) {
             const int lo_rest = q.lo_bits - (int)q.p2_bits, hi_rest = q.hi_bits - (int)q.p1_bits;
             q.out_lo[g] = ((hi[r] & ((1ull << hi_rest) - 1ull)) << lo_rest) | (lo[r] & ((1ull << lo_rest) - 1ull));
@@ -362,17 +456,28 @@ __global__ __launch_bounds__(kP2Block) void k_part2_scatter(Part2Params q, AggPa
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < kP2Counters; i += kP2Block) {
       const uint32_t c = c0 + i / n_sub;
-      lstart[i] = i < n_cnt ? cnt[i] : 0u;
-      uint32_t at = 0u;
-      if (i < n_cnt && cnt[i] && c < n_coarse) {
+      const uint32_t n_i = i < n_cnt ? cnt[i] : 0u;
+      lstart[i] = n_i;
+      uint32_t at = 0u, fit = n_i, spill_local = 0u;
+      if (n_i && c < n_coarse) {
         const uint64_t ff = ((uint64_t)c << q.p2_bits) | (i % n_sub);
-        at = atomicAdd(&q.fine_cursor[ff], cnt[i]);
-        // (regions of fixed size: a run that does not fit its bucket's region is dropped as a whole)
-        if (q.fine_limit && (uint64_t)at + cnt[i] > q.fine_limit[ff]) { q.flags[1] = 1u; at = ~0u; }
+        at = atomicAdd(&q.fine_cursor[ff], n_i);
+        if (spills) {
+          // what fits the bucket's region goes there, the rest of the run to the spill list
+          const uint32_t lim = q.fine_limit[ff];
+          fit = at >= lim ? 0u : (lim - at < n_i ? lim - at : n_i);
+          if (fit < n_i) spill_local = atomicAdd(&spill_n, n_i - fit);
+        } else if (q.fine_limit && (uint64_t)at + n_i > q.fine_limit[ff]) {
+          // (regions of fixed size without a spill list: a run that does not fit is dropped as a whole)
+          q.flags[1] = 1u;
+          at = ~0u;
+        }
       }
       base[i] = at;
+      if (spills) cnt[i] = fit | (spill_local << 16);  // (the tile's counts have been read: the array carries this from here on)
     }
     __syncthreads();
+    if (spills && threadIdx.x == 0 && spill_n) spill_at = atomicAdd(q.spill_cursor, (unsigned long long)spill_n);  // (read behind the scan's barriers)
     p2_block_scan(lstart, kP2Counters, wave_tot);
 #pragma unroll
     for (uint32_t r = 0; r < kP2TileRows; ++r) {
@@ -389,8 +494,20 @@ __global__ __launch_bounds__(kP2Block) void k_part2_scatter(Part2Params q, AggPa
       for (uint32_t i = threadIdx.x; i < n_live; i += kP2Block) {
         const uint64_t tl = s_lo[i], th = s_hi[i];  // (staged mixed)
         const uint32_t li = ((uint32_t)(th >> hi_rest) - c0) * n_sub + (uint32_t)(tl >> lo_rest);
-        const uint32_t g = base[li] + (i - lstart[li]);
-        if (base[li] != ~0u && g < q.out_capacity) q.out_lo[g] = ((th & ((1ull << hi_rest) - 1ull)) << lo_rest) | (tl & ((1ull << lo_rest) - 1ull));
+        const uint64_t rec = ((th & ((1ull << hi_rest) - 1ull)) << lo_rest) | (tl & ((1ull << lo_rest) - 1ull));
+        const uint32_t k = i - lstart[li];
+        if (spills && k >= (cnt[li] & 0xffffu)) {
+          const unsigned long long at = spill_at + (cnt[li] >> 16) + (k - (cnt[li] & 0xffffu));
+          if (at < q.spill_capacity) {
+            q.spill_rec[at] = rec;
+            q.spill_fine[at] = (uint32_t)((((uint64_t)c0 + li / n_sub) << q.p2_bits) | (li % n_sub));
+          } else {
+            q.flags[1] = 1u;
+          }
+          continue;
+        }
+        const uint32_t g = base[li] + k;
+        if (base[li] != ~0u && g < q.out_capacity) q.out_lo[g] = rec;
       }
     } else {
       for (uint32_t i = threadIdx.x; i < n_live; i += kP2Block) {
@@ -404,6 +521,11 @@ __global__ __launch_bounds__(kP2Block) void k_part2_scatter(Part2Params q, AggPa
       }
     }
     __syncthreads();
+  }
+  if (DIRECT && q.strays) {
+    if (strays) atomicAdd(&n_stray, strays);
+    __syncthreads();
+    if (threadIdx.x == 0 && n_stray) atomicAdd(q.strays, (unsigned long long)n_stray);
   }
 }
 
@@ -847,8 +969,15 @@ uint32_t part2_lds_entries(bool compact) {
 
 void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q, const AggParams* scan) {
   if (q.n_rows == 0) return;
-  if (q.direct && (!scan || !q.compact || q.fine_limit || q.emit_out || q.n_tiles == 0 || q.slice_tiles == 0 || (q.slice_tiles & 1u)))
+  if (q.direct && (!scan || !q.compact || (q.fine_limit && !q.spill_rec) || q.emit_out || q.n_tiles == 0 || q.slice_tiles == 0 || (q.slice_tiles & 1u)))
     fail(PRISM_GPU_EINTERNAL, "bad shape for a second partition level that reads the scan's columns");
+  if (q.spill_rec) {
+    const uint64_t regions = (uint64_t)q.n_regions * q.region_cap;
+    if (!q.direct || !q.fine_limit || !q.spill_fine || !q.spill_cursor || !q.spill_count || !q.spill_base || !q.spill_cur || !q.seg_base_out ||
+        !q.seg_cnt_out || q.n_regions == 0 || q.n_regions > (1u << (q.p1_bits + q.p2_bits)) || regions + q.spill_capacity >= (1ull << 32) ||
+        q.out_capacity < regions + q.spill_capacity)
+      fail(PRISM_GPU_EINTERNAL, "bad shape for fine buckets with a spill list");
+  }
   const uint32_t n_fine = 1u << (q.p1_bits + q.p2_bits);
   if (q.p2_bits > 10 || q.p1_bits + q.p2_bits > 21 || q.n_rows >= (1ull << 32) || q.slice_rows == 0)
     fail(PRISM_GPU_EINTERNAL, "bad shape for the second partition level");
@@ -856,7 +985,7 @@ void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q, cons
   if (q.compact && (q.hi_bits < (int)q.p1_bits || q.hi_bits - (int)q.p1_bits > 9 || q.lo_bits < (int)q.p2_bits || q.lo_bits > 63 ||
                     q.lo_bits - (int)q.p2_bits + q.hi_bits - (int)q.p1_bits > 63 || q.x_null_bit >= 0))
     fail(PRISM_GPU_EINTERNAL, "bad shape for one-word records");
-  if (q.fine_limit ? (q.out_capacity < part2_fixed_capacity(q.n_rows, n_fine) || q.out_capacity >= (1ull << 32)) : q.out_capacity < q.n_rows)
+  if (!q.spill_rec && (q.fine_limit ? (q.out_capacity < part2_fixed_capacity(q.n_rows, n_fine) || q.out_capacity >= (1ull << 32)) : q.out_capacity < q.n_rows))
     fail(PRISM_GPU_EINTERNAL, "the second partition level's output array is too short");
   const uint32_t slices = q.direct ? (uint32_t)ceil_div(q.n_tiles, (uint64_t)q.slice_tiles) : (uint32_t)ceil_div(q.n_rows, q.slice_rows);
   AggParams none;
@@ -865,7 +994,11 @@ void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q, cons
   // (key columns without validity bitmaps, at most one more than the key has words: their loads run a trip ahead)
   int ahead = q.direct ? part_keys_ahead(ap) : 0;
   if (ahead != 2 && ahead != 3) ahead = 0;
-  if (q.fine_limit) {
+  if (q.spill_rec) {
+    KernelTimer timer(ctx, "part2_layout", 0);
+    k_part2_layout_uniform<<<dim3((uint32_t)ceil_div(n_fine + 1, 256)), dim3(256), 0, ctx->stream>>>(q, n_fine);
+    PRISM_HIP(hipGetLastError());
+  } else if (q.fine_limit) {
     KernelTimer timer(ctx, "part2_layout", 0);
     k_part2_layout<<<dim3((uint32_t)ceil_div(n_fine + 1, 256)), dim3(256), 0, ctx->stream>>>(q, n_fine);
     PRISM_HIP(hipGetLastError());
@@ -889,6 +1022,36 @@ void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q, cons
     PRISM_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     kernel<<<dim3(slices), dim3(kP2Block), lds, ctx->stream>>>(q, ap);
     PRISM_HIP(hipGetLastError());
+  }
+  if (q.spill_rec) {
+    // the spill list sorted by bucket behind the regions; then every bucket as its two runs
+    const uint64_t out_offset = (uint64_t)q.n_regions * q.region_cap;
+    {
+      KernelTimer timer(ctx, "part2_spill", 0);
+      const uint32_t grid = ctx->n_cus * 16;
+      k_spill_count<<<dim3(grid), dim3(256), 0, ctx->stream>>>(q);
+      Part2Params sc = q;  // (the scan of the fine buckets' counts, over the spill list's)
+      sc.fine_count = q.spill_count;
+      sc.fine_base = q.spill_base;
+      sc.fine_cursor = q.spill_cur;
+      k_part2_scan<<<dim3(1), dim3(1024), 0, ctx->stream>>>(sc, q.n_regions);
+      k_spill_place<<<dim3(grid), dim3(256), 0, ctx->stream>>>(q, out_offset);
+      k_spill_runs<<<dim3((uint32_t)ceil_div(q.n_regions, 256)), dim3(256), 0, ctx->stream>>>(q, out_offset);
+      PRISM_HIP(hipGetLastError());
+    }
+    Part2Params m = q;
+    m.n_src = 2;
+    m.world = 1;
+    m.rank = 0;
+    m.seg_base = q.seg_base_out;
+    m.seg_cnt = q.seg_cnt_out;
+    KernelTimer timer(ctx, "part2_agg", q.n_rows * 8);
+    const size_t lds = (size_t)q.lds_entries * 8;
+    PRISM_HIP(hipFuncSetAttribute((const void*)k_part2_agg_compact<kP2Merge>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(q.n_regions, (uint64_t)ctx->n_cus * kP2AggPerCu);
+    k_part2_agg_compact<kP2Merge><<<dim3(grid), dim3(kP2AggBlock), lds, ctx->stream>>>(m, q.n_regions);
+    PRISM_HIP(hipGetLastError());
+    return;
   }
   {
     KernelTimer timer(ctx, "part2_agg", q.n_rows * (q.compact ? 8 : 16));

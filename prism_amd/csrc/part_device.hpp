@@ -29,6 +29,10 @@ __device__ __forceinline__ long long part_widen(unsigned long long raw, int widt
   return is_unsigned ? (long long)(uint16_t)raw : (long long)(int16_t)(uint16_t)raw;
 }
 
+// log2 of a column's width in bytes (2, 4 or 8): a row's byte offset is a shift, where a multiply
+// by the width -- a run-time value to the compiler -- is a quarter-rate instruction per row and column.
+__device__ __forceinline__ uint32_t part_width_shift(int width) { return width == 8 ? 3u : (width == 4 ? 2u : 1u); }
+
 // A key column's field of the packed key, before it is shifted into place: value - bias, or
 // for date_bin the bucket number - bias.  Keys whose values span less than 2^32 (KeySpec::
 // fast32) take the 32-bit form, (uint32)(value - base) / stride with a 32-bit multiply-high: the
@@ -158,7 +162,7 @@ __device__ __forceinline__ void part_load_keys(const AggParams& p, const PartTil
         const PartBytePtr base = (PartBytePtr)(uint64_t)c.values;
         // (a chunk's column is shorter than 4 GiB: the byte offset fits 32 bits, and the load takes
         // its base from scalar registers)
-        raw[i] = __builtin_nontemporal_load((const __attribute__((address_space(1))) part_unaligned_u64*)(base + rowc[r] * (uint32_t)ks.width));
+        raw[i] = __builtin_nontemporal_load((const __attribute__((address_space(1))) part_unaligned_u64*)(base + (rowc[r] << part_width_shift(ks.width))));
       }
       if (ks.null_bit >= 0) {
 #pragma unroll
@@ -246,17 +250,17 @@ __device__ __forceinline__ void part_issue_group(const AggParams& p, PartCursor<
 #pragma unroll
   for (int k = 0; k < NK; ++k) {
     if ((skip >> k) & 1u) continue;  // (wave uniform; the words keep what they held)
-    const uint32_t width = (uint32_t)p.keys[k].width;
+    const uint32_t sh = part_width_shift(p.keys[k].width);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      raw[k][4 * G + i] = __builtin_nontemporal_load((const __attribute__((address_space(1))) part_unaligned_u64*)(c.col[k] + rowc[i] * width));
+      raw[k][4 * G + i] = __builtin_nontemporal_load((const __attribute__((address_space(1))) part_unaligned_u64*)(c.col[k] + (rowc[i] << sh)));
   }
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
-    const uint32_t width = (uint32_t)p.vals[v].width;
+    const uint32_t sh = part_width_shift(p.vals[v].width);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      raw[NK + v][4 * G + i] = __builtin_nontemporal_load((const __attribute__((address_space(1))) part_unaligned_u64*)(c.col[NK + v] + rowc[i] * width));
+      raw[NK + v][4 * G + i] = __builtin_nontemporal_load((const __attribute__((address_space(1))) part_unaligned_u64*)(c.col[NK + v] + (rowc[i] << sh)));
   }
 }
 
@@ -334,7 +338,7 @@ __device__ __forceinline__ void part_load_vals(const AggParams& p, const PartTil
     for (int r = 0; r < R; ++r) {
       const ColPtr& c = p.cols[(uint64_t)vs.col * p.sd.n_segs + tl[r / RT].seg];
       const PartBytePtr base = (PartBytePtr)(uint64_t)c.values;
-      raw[r] = __builtin_nontemporal_load((const __attribute__((address_space(1))) part_unaligned_u64*)(base + rowc[r] * (uint32_t)vs.width));
+      raw[r] = __builtin_nontemporal_load((const __attribute__((address_space(1))) part_unaligned_u64*)(base + (rowc[r] << part_width_shift(vs.width))));
       if (VALID) validw[r] |= (valid_at(c.validity, rowc[r]) ? 1ull : 0ull) << v;
     }
 #pragma unroll

@@ -222,11 +222,17 @@ def test_count_distinct_partitioned_twice(part_ctx, oracle):
     part_ctx.set_option("part2_fixed", 1)
     # The generated rows are in time order and the group key starts with the hour: sorted by the
     # group key's top bits already, so there is no first level -- the one partition pass reads the columns
+    # (its fine buckets: regions of one size plus a spill list sorted afterwards, or exact places from a histogram)
     part_ctx.set_option("part2_direct", 1)
-    part_ctx.reset_stats()
-    _synth_both(part_ctx, oracle, wl, rows, 4, [(wl.query, 2)])
-    ran = _kernels(part_ctx)
-    assert {"part2_hist", "part2_scatter", "part2_agg"} <= ran and not ({"part_scatter", "part_hist", "part2_layout"} & ran), ran
+    for fixed in (1, 0):
+        part_ctx.set_option("part2_fixed", fixed)
+        part_ctx.reset_stats()
+        _synth_both(part_ctx, oracle, wl, rows, 4, [(wl.query, 2)])
+        ran = _kernels(part_ctx)
+        assert {"part2_scatter", "part2_agg"} <= ran and not ({"part_scatter", "part_hist"} & ran), ran
+        assert ({"part2_layout", "part2_spill"} <= ran and "part2_hist" not in ran) if fixed else \
+               ("part2_hist" in ran and not ({"part2_layout", "part2_spill"} & ran)), ran
+    part_ctx.set_option("part2_fixed", 1)
 
     rng = np.random.default_rng(21)
     n = 300_000
