@@ -218,6 +218,8 @@ void prism_gpu_ctx_free(prism_gpu_ctx* ctx);
  *                    group key first; 1 (default): when the group key starts with a time key, the rows are
  *                    taken to arrive in time order -- sorted by those bits already -- and the second level
  *                    reads the columns itself (a plan whose rows turn out not to goes back to two levels)
+ *   "part2_half_blocks" 1: the scatter pass of that one-level form runs two workgroups of 512 threads per CU
+ *                    (default 0: one of 1024, which measured faster)
  *   "part2_compact"  0: COUNT(DISTINCT) partitioned twice always keeps two-word records at the
  *                    second level; 1 (default): one-word records when the pairs allow it
  *   "contains_windows" 0: LIKE '%needle%' over a column without a dictionary always uses the

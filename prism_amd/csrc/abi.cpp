@@ -357,6 +357,7 @@ int prism_gpu_set_option(prism_gpu_ctx* ctx, const char* name, int64_t value) {
     else if (n == "part_wc") ctx->part_wc.store(value != 0 ? 1 : 0);
     else if (n == "part_wc_min_rows") { require(value >= 0, "part_wc_min_rows must not be negative"); ctx->part_wc_min_rows.store((uint64_t)value); }
     else if (n == "part2_fixed") ctx->part2_fixed.store(value != 0 ? 1 : 0);
+    else if (n == "part2_half_blocks") ctx->part2_half_blocks.store(value != 0 ? 1 : 0);
     else if (n == "part2_direct") ctx->part2_direct.store(value != 0 ? 1 : 0);
     else if (n == "part2_compact") ctx->part2_compact.store(value != 0 ? 1 : 0);
     else if (n == "part_half_blocks") ctx->part_half_blocks.store(value != 0 ? 1 : 0);

@@ -75,6 +75,7 @@ struct prism_gpu_ctx {
   std::atomic<int> part_wc{1};                       // 0: GROUP BY key -> COUNT(*) never takes the histogram-free path
   std::atomic<uint64_t> part_wc_min_rows{1ull << 23};  // fewer selected rows: the path with the histogram
   std::atomic<int> part2_fixed{1};                   // 0: the second partition level of COUNT(DISTINCT) always runs its histogram pass
+  std::atomic<int> part2_half_blocks{0};             // 1: the one-level COUNT(DISTINCT) scatter runs two workgroups of 512 threads per CU
   std::atomic<int> part2_direct{1};                  // 0: COUNT(DISTINCT) partitioned twice always sorts its pairs by the group key first, also when the rows arrive in time order
   std::atomic<int> part2_compact{1};                 // 0: the second partition level of COUNT(DISTINCT) always keeps two-word records
   std::atomic<int> contains_windows{1};              // 0: substring search always by the byte-wise prefilter

@@ -47,8 +47,8 @@ __device__ __forceinline__ uint32_t coarse_of(const Part2Params& q, uint64_t hi)
   if (q.compact) return (uint32_t)(bij_mix(hi, q.hi_bits) >> (q.hi_bits - (int)q.p1_bits));
   return q.p1_bits ? (uint32_t)(part_hash_hi(hi) >> (64 - q.p1_bits)) : 0u;
 }
-__device__ __forceinline__ uint32_t span_of(const Part2Params& q) {
-  const uint32_t s = kP2Counters >> q.p2_bits;
+__device__ __forceinline__ uint32_t span_of(const Part2Params& q, uint32_t counters = kP2Counters) {
+  const uint32_t s = counters >> q.p2_bits;
   return s < kP2MaxSpan ? s : kP2MaxSpan;
 }
 // Compact form: the low word times an odd constant (a bijection modulo 2^lo_bits whose top
@@ -99,10 +99,11 @@ __global__ __launch_bounds__(kP2Block) void k_part2_hist(Part2Params q) {
 // The pairs of two scan tiles a trip, packed from the scan's columns.  NK > 0 (the plan's key
 // columns carry no validity bitmaps: part_keys_ahead): the column words of the next trip are
 // requested before this trip's are used, so the loads are in flight during the trip's LDS work.
-template <int NK>
+template <int NK, int BLOCK = (int)kP2Block>
 struct P2Columns {
   static constexpr bool kAhead = NK > 0;
   static constexpr int NA = NK > 0 ? NK : 1, R = (int)kP2TileRows;
+  static constexpr int TPT = BLOCK * R / (int)kTileRows;  // scan tiles a trip
   unsigned long long raw[NA][R];
   uint32_t live_next;
   PartCursor<NA> cur;
@@ -116,7 +117,7 @@ struct P2Columns {
     if (T0 >= T1) return;
     if constexpr (kAhead) {
       part_cursor_init<NA, 0>(p, cur, T0);
-      part_issue<NA, 0, R>(p, cur, T0, T1, tid, raw, live_next);
+      part_issue<NA, 0, R, BLOCK>(p, cur, T0, T1, tid, raw, live_next);
     } else {
       part_seg_init(p, pos, T0);
     }
@@ -129,13 +130,13 @@ struct P2Columns {
 #pragma unroll
       for (int r = 0; r < R; ++r) { lo[r] = rec[0][r]; hi[r] = rec[1][r]; }
       live = live_next;
-      if (T + 2 < T1) part_issue<NA, 0, R>(p, cur, T + 2, T1, tid, raw, live_next);
+      if (T + TPT < T1) part_issue<NA, 0, R, BLOCK>(p, cur, T + TPT, T1, tid, raw, live_next);
     } else {
-      PartTile tl[2];
-      tl[0] = part_tile_next(p, pos, T, T1);
-      tl[1] = part_tile_next(p, pos, T + 1, T1);
+      PartTile tl[TPT];
+#pragma unroll
+      for (int j = 0; j < TPT; ++j) tl[j] = part_tile_next(p, pos, T + j, T1);
       uint32_t rowc[R];
-      part_load_keys<2, R, (int)kP2Block>(p, tl, tid, lo, hi, rowc, live);
+      part_load_keys<2, R, BLOCK>(p, tl, tid, lo, hi, rowc, live);
     }
   }
 };
@@ -312,7 +313,8 @@ __global__ __launch_bounds__(256) void k_spill_runs(Part2Params q, uint64_t out_
   q.seg_cnt_out[q.n_regions + f] = q.spill_count[f];
 }
 
-// Exclusive scan of n (<= 2 * kP2Block, even) LDS counters in place; a[n] receives the total.
+// Exclusive scan of n (<= 2 * BLOCK, even) LDS counters in place, by a workgroup of BLOCK threads; a[n] receives the total.
+template <uint32_t BLOCK = kP2Block>
 __device__ __forceinline__ void p2_block_scan(uint32_t* a, uint32_t n, uint32_t* wave_tot) {
   const uint32_t t = threadIdx.x, i0 = 2 * t;
   const uint32_t v0 = i0 < n ? a[i0] : 0u, v1 = i0 + 1 < n ? a[i0 + 1] : 0u;
@@ -329,40 +331,45 @@ __device__ __forceinline__ void p2_block_scan(uint32_t* a, uint32_t n, uint32_t*
   const uint32_t excl = before + incl - (v0 + v1);
   if (i0 < n) a[i0] = excl;
   if (i0 + 1 < n) a[i0 + 1] = excl + v0;
-  if (t == kP2Block - 1) a[n] = before + incl;
+  if (t == BLOCK - 1) a[n] = before + incl;
   __syncthreads();
 }
 
 // The tile's records are put in fine-bucket order in LDS first and leave as runs: written
 // straight from the registers, 8 bytes at a time to places 32 rows apart, the pass wrote 3.6
 // times its payload (partial cache lines).
-template <bool DIRECT, int NK>
-__global__ __launch_bounds__(kP2Block) void k_part2_scatter(Part2Params q, AggParams p) {
+// (BLOCK: 1024 threads, tiles of 8192 records and 2048 counters -- one workgroup a CU; or, for the
+// columns' form, 512 threads, 4096 records and 1024 counters -- two a CU, so that one's barriers and
+// waits overlap with the other's work.)
+template <bool DIRECT, int NK, uint32_t BLOCK>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_part2_scatter(Part2Params q, AggParams p) {
+  constexpr uint32_t NC = 2 * BLOCK;  // LDS counters
   extern __shared__ __align__(16) unsigned long long p2s_lds[];
-  constexpr uint32_t kTile = kP2Block * kP2TileRows;
+  constexpr uint32_t kTile = BLOCK * kP2TileRows;
   unsigned long long* s_lo = p2s_lds;
   unsigned long long* s_hi = p2s_lds + kTile;
-  uint32_t* cnt = (uint32_t*)(p2s_lds + 2 * kTile);  // [kP2Counters]: rows of the tile per counter
-  uint32_t* lstart = cnt + kP2Counters;                // [kP2Counters + 1]: where a counter's run starts in the tile
-  uint32_t* base = lstart + kP2Counters + 1;           // [kP2Counters]: and in the output
-  __shared__ uint32_t wave_tot[kP2Block / 64];
+  uint32_t* cnt = (uint32_t*)(p2s_lds + 2 * kTile);  // [NC]: rows of the tile per counter
+  uint32_t* lstart = cnt + NC;                // [NC + 1]: where a counter's run starts in the tile
+  uint32_t* base = lstart + NC + 1;           // [NC]: and in the output
+  __shared__ uint32_t wave_tot[BLOCK / 64];
   __shared__ uint32_t c_first;
   __shared__ uint32_t n_stray;                 // (DIRECT) rows beyond the tile's LDS counters: rows out of time order
   __shared__ uint32_t spill_n;                 // records of the tile that go to the spill list
   __shared__ unsigned long long spill_at;      // and where the tile's part of the list starts
   const bool spills = DIRECT && q.spill_rec != nullptr;
-  const uint32_t n_sub = 1u << q.p2_bits, span = span_of(q), n_cnt = span * n_sub;
+  const uint32_t n_sub = 1u << q.p2_bits, span = span_of(q, NC), n_cnt = span * n_sub;
   const uint32_t n_coarse = 1u << q.p1_bits;
   // the workgroup's share: records [r0, r1) of the first level, or (DIRECT) scan tiles [T0, T1), two per trip
   uint64_t r0 = 0, r1 = 0, T0 = 0, T1 = 0, trips = 0;
   uint32_t strays = 0, c_slice = 0;
   if (DIRECT && threadIdx.x == 0) { n_stray = 0; c_first = ~0u; }
-  P2Columns<DIRECT ? NK : 0> in;
+  P2Columns<DIRECT ? NK : 0, (int)BLOCK> in;
+  constexpr uint64_t TPT = kTile / kTileRows;  // scan tiles a trip
   if (DIRECT) {
     T0 = (uint64_t)blockIdx.x * q.slice_tiles;
     T1 = T0 + q.slice_tiles < q.n_tiles ? T0 + q.slice_tiles : q.n_tiles;
     in.init(p, T0, T1, threadIdx.x);
-    trips = T1 > T0 ? (T1 - T0 + 1) / 2 : 0;
+    trips = T1 > T0 ? (T1 - T0 + TPT - 1) / TPT : 0;
   } else {
     r0 = (uint64_t)blockIdx.x * q.slice_rows;
     r1 = r0 + q.slice_rows < q.n_rows ? r0 + q.slice_rows : q.n_rows;
@@ -371,7 +378,7 @@ __global__ __launch_bounds__(kP2Block) void k_part2_scatter(Part2Params q, AggPa
   // every thread makes the same number of trips (the barriers are inside)
   for (uint64_t trip = 0; trip < trips; ++trip) {
     const uint64_t t0 = r0 + trip * kTile;
-    for (uint32_t i = threadIdx.x; i < kP2Counters; i += kP2Block) cnt[i] = 0;
+    for (uint32_t i = threadIdx.x; i < NC; i += BLOCK) cnt[i] = 0;
     if (DIRECT && threadIdx.x == 0) spill_n = 0;
     uint32_t c0 = 0;
     if (!DIRECT) c0 = __builtin_amdgcn_readfirstlane(coarse_of(q, q.in_hi[t0]));
@@ -380,7 +387,7 @@ __global__ __launch_bounds__(kP2Block) void k_part2_scatter(Part2Params q, AggPa
     uint32_t where[kP2TileRows];  // LDS counter (low 12 bits) and rank in it; ~0: handled directly
     uint32_t live = 0;
     if (DIRECT) {
-      in.next(p, T0 + 2 * trip, T1, threadIdx.x, lo, hi, live);
+      in.next(p, T0 + TPT * trip, T1, threadIdx.x, lo, hi, live);
       // The LDS counters start at the smallest coarse bucket among the slice's first rows and stay
       // there: rows in time order move on by at most a bucket or two within a slice, and a barrier
       // per tile to follow them costs more than the few rows that then take the direct way.
@@ -397,7 +404,7 @@ __global__ __launch_bounds__(kP2Block) void k_part2_scatter(Part2Params q, AggPa
     } else {
 #pragma unroll
       for (uint32_t r = 0; r < kP2TileRows; ++r) {
-        const uint64_t i = t0 + (uint64_t)r * kP2Block + threadIdx.x;
+        const uint64_t i = t0 + (uint64_t)r * BLOCK + threadIdx.x;
         const bool in = i < r1;
         const uint64_t ic = in ? i : t0;
         lo[r] = __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.in_lo + ic));
@@ -454,7 +461,7 @@ __global__ __launch_bounds__(kP2Block) void k_part2_scatter(Part2Params q, AggPa
       }
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < kP2Counters; i += kP2Block) {
+    for (uint32_t i = threadIdx.x; i < NC; i += BLOCK) {
       const uint32_t c = c0 + i / n_sub;
       const uint32_t n_i = i < n_cnt ? cnt[i] : 0u;
       lstart[i] = n_i;
@@ -478,7 +485,7 @@ __global__ __launch_bounds__(kP2Block) void k_part2_scatter(Part2Params q, AggPa
     }
     __syncthreads();
     if (spills && threadIdx.x == 0 && spill_n) spill_at = atomicAdd(q.spill_cursor, (unsigned long long)spill_n);  // (read behind the scan's barriers)
-    p2_block_scan(lstart, kP2Counters, wave_tot);
+    p2_block_scan<BLOCK>(lstart, NC, wave_tot);
 #pragma unroll
     for (uint32_t r = 0; r < kP2TileRows; ++r) {
       if (where[r] == ~0u) continue;
@@ -488,10 +495,10 @@ __global__ __launch_bounds__(kP2Block) void k_part2_scatter(Part2Params q, AggPa
     }
     __syncthreads();
     // out: neighbouring lanes hold neighbouring records of one fine bucket
-    const uint32_t n_live = lstart[kP2Counters];
+    const uint32_t n_live = lstart[NC];
     if (q.compact) {
       const int lo_rest = q.lo_bits - (int)q.p2_bits, hi_rest = q.hi_bits - (int)q.p1_bits;
-      for (uint32_t i = threadIdx.x; i < n_live; i += kP2Block) {
+      for (uint32_t i = threadIdx.x; i < n_live; i += BLOCK) {
         const uint64_t tl = s_lo[i], th = s_hi[i];  // (staged mixed)
         const uint32_t li = ((uint32_t)(th >> hi_rest) - c0) * n_sub + (uint32_t)(tl >> lo_rest);
         const uint64_t rec = ((th & ((1ull << hi_rest) - 1ull)) << lo_rest) | (tl & ((1ull << lo_rest) - 1ull));
@@ -510,7 +517,7 @@ __global__ __launch_bounds__(kP2Block) void k_part2_scatter(Part2Params q, AggPa
         if (base[li] != ~0u && g < q.out_capacity) q.out_lo[g] = rec;
       }
     } else {
-      for (uint32_t i = threadIdx.x; i < n_live; i += kP2Block) {
+      for (uint32_t i = threadIdx.x; i < n_live; i += BLOCK) {
         const unsigned long long w0 = s_lo[i], w1 = s_hi[i];
         const uint32_t li = (coarse_of(q, w1) - c0) * n_sub + sub_of(q, w0, w1);
         const uint32_t g = base[li] + (i - lstart[li]);
@@ -1016,11 +1023,17 @@ void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q, cons
   }
   {
     KernelTimer timer(ctx, "part2_scatter", q.n_rows * (q.compact ? 24 : 32));
-    const size_t lds = (size_t)kP2Block * kP2TileRows * 16 + (size_t)(3 * kP2Counters + 1) * 4;
-    auto kernel = !q.direct ? k_part2_scatter<false, 0> : ahead == 3 ? k_part2_scatter<true, 3> : ahead == 2 ? k_part2_scatter<true, 2>
-                                                                                                          : k_part2_scatter<true, 0>;
+    // (the columns' form can run two workgroups of 512 threads a CU, option "part2_half_blocks"; measured
+    // slower at C5, 13.5-14.4 against 13.1-13.2 ms, and shorter runs spill more: off by default)
+    const bool halves = q.direct && ctx->part2_half_blocks.load(std::memory_order_relaxed) != 0;
+    const uint32_t block = halves ? 512u : kP2Block;
+    const size_t lds = (size_t)block * kP2TileRows * 16 + (size_t)(3 * 2 * block + 1) * 4;
+    auto kernel = !q.direct ? k_part2_scatter<false, 0, kP2Block>
+                  : halves  ? (ahead == 3 ? k_part2_scatter<true, 3, 512> : ahead == 2 ? k_part2_scatter<true, 2, 512> : k_part2_scatter<true, 0, 512>)
+                            : (ahead == 3 ? k_part2_scatter<true, 3, kP2Block> : ahead == 2 ? k_part2_scatter<true, 2, kP2Block>
+                                                                                         : k_part2_scatter<true, 0, kP2Block>);
     PRISM_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    kernel<<<dim3(slices), dim3(kP2Block), lds, ctx->stream>>>(q, ap);
+    kernel<<<dim3(slices), dim3(block), lds, ctx->stream>>>(q, ap);
     PRISM_HIP(hipGetLastError());
   }
   if (q.spill_rec) {

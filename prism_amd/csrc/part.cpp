@@ -28,6 +28,7 @@ void copy_options(prism_gpu_ctx* c, prism_gpu_ctx* parent) {
   c->part_wc.store(parent->part_wc.load());
   c->part2_fixed.store(parent->part2_fixed.load());
   c->part2_direct.store(parent->part2_direct.load());
+  c->part2_half_blocks.store(parent->part2_half_blocks.load());
   c->part_wc_min_rows.store(parent->part_wc_min_rows.load());
   c->contains_windows.store(parent->contains_windows.load());
   c->dict_expand_device.store(parent->dict_expand_device.load());

@@ -224,8 +224,9 @@ def test_count_distinct_partitioned_twice(part_ctx, oracle):
     # group key's top bits already, so there is no first level -- the one partition pass reads the columns
     # (its fine buckets: regions of one size plus a spill list sorted afterwards, or exact places from a histogram)
     part_ctx.set_option("part2_direct", 1)
-    for fixed in (1, 0):
+    for fixed, halves in ((1, 0), (0, 0), (1, 1)):
         part_ctx.set_option("part2_fixed", fixed)
+        part_ctx.set_option("part2_half_blocks", halves)
         part_ctx.reset_stats()
         _synth_both(part_ctx, oracle, wl, rows, 4, [(wl.query, 2)])
         ran = _kernels(part_ctx)
@@ -233,6 +234,7 @@ def test_count_distinct_partitioned_twice(part_ctx, oracle):
         assert ({"part2_layout", "part2_spill"} <= ran and "part2_hist" not in ran) if fixed else \
                ("part2_hist" in ran and not ({"part2_layout", "part2_spill"} & ran)), ran
     part_ctx.set_option("part2_fixed", 1)
+    part_ctx.set_option("part2_half_blocks", 0)
 
     rng = np.random.default_rng(21)
     n = 300_000
