@@ -220,6 +220,7 @@ struct DistinctShardRequest {
   uint64_t sizing_rows;
 };
 struct DistinctShard {
+  bool direct = false;  // the coarse bucket is the top p1 bits of the group word as it is (no first level ran)
   int p1 = 0, p2 = 0, lo_bits = 0, hi_bits = 0;
   uint32_t n_fine = 0, lds_entries = 0;
   Scratch records;  // fine bucket f: records[fine_base[f] .. + fine_count[f])

@@ -1507,8 +1507,9 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggPar
   // ---- no first level at all? ----
   bool direct = false;
   uint64_t coarse_used = 0;  // (direct) coarse buckets the scanned rows span
-  if (!shard && time_bits > 0 && time_buckets > 0 && ctx->part2_direct.load(std::memory_order_relaxed) != 0 &&
-      plan->part2_direct.load(std::memory_order_relaxed) >= 0 && ctx->part2_compact.load(std::memory_order_relaxed) != 0 &&
+  // (a sharded query: every rank must decide alike -- what this rank's plan has learnt about its rows stays out of it)
+  if (time_bits > 0 && time_buckets > 0 && ctx->part2_direct.load(std::memory_order_relaxed) != 0 &&
+      (shard || plan->part2_direct.load(std::memory_order_relaxed) >= 0) && ctx->part2_compact.load(std::memory_order_relaxed) != 0 &&
       layout.fields[0].null_bit < 0 && lo_bits <= 63 && ap.row_mode != kRowsSelvec) {
     const int d1 = std::min(time_bits, 11);
     // fine buckets of at most the rows the LDS set takes in one go, where the rows allow it
@@ -1532,6 +1533,7 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggPar
     const uint32_t nf = 1u << (p1 + p2);
     shard->p1 = p1;
     shard->p2 = p2;
+    shard->direct = direct;
     shard->lo_bits = lo_bits;
     shard->hi_bits = hi_bits;
     shard->n_fine = nf;
@@ -1587,7 +1589,9 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggPar
   const uint32_t n_regions = direct ? (uint32_t)std::min<uint64_t>(n_fine, coarse_used << p2) : 0;
   const uint32_t region_cap = direct ? (uint32_t)(((((selected / std::max<uint64_t>(1, coarse_used)) >> p2) * 3 / 2 + 64) + 15) & ~15ull) : 0;
   const uint64_t spill_capacity = selected / 2 + 4096, region_records = (uint64_t)n_regions * region_cap;
-  bool spill = direct && ctx->part2_fixed.load(std::memory_order_relaxed) != 0 && plan->part2_fixed.load(std::memory_order_relaxed) >= 0 &&
+  Scratch emitted;  // (a sharded query without a first level: where the last pass writes the buckets' distinct records)
+  if (direct && shard) emitted = Scratch(ctx, std::max<uint64_t>(1, selected) * 8 + 256);
+  bool spill = direct && !shard && ctx->part2_fixed.load(std::memory_order_relaxed) != 0 && plan->part2_fixed.load(std::memory_order_relaxed) >= 0 &&
                region_records + spill_capacity < (1ull << 32);
   Scratch spill_rec, spill_fine, spill_small;
   if (spill) {
@@ -1607,7 +1611,7 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggPar
     if (!shard) distinct_outer_alloc(ctx, layout, selected, outer);
     Part2Params q2;
     std::memset(&q2, 0, sizeof(q2));
-    q2.emit_out = shard ? rec[0].as<uint64_t>() : nullptr;  // (the first level's records are done with once the second has scattered them)
+    q2.emit_out = !shard ? nullptr : direct ? emitted.as<uint64_t>() : rec[0].as<uint64_t>();  // (the first level's records are done with once the second has scattered them)
     q2.in_lo = rec[0].as<uint64_t>();
     q2.in_hi = rec[1].as<uint64_t>();
     q2.out_lo = rec2[0].as<uint64_t>();
@@ -1674,7 +1678,7 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggPar
                    (int)compact, (int)fixed, (int)direct, (int)spill, (unsigned long long)selected, h.flags[0], h.flags[1],
                    (unsigned long long)h.pad[0], (unsigned long long)h.pad[1]);
     // (rows out of time order: the next run sorts by the group key first again)
-    if (direct && h.pad[0] > selected / 8) plan->part2_direct.store(-1, std::memory_order_relaxed);
+    if (direct && !shard && h.pad[0] > selected / 8) plan->part2_direct.store(-1, std::memory_order_relaxed);
     if (spill && h.flags[1] != 0) {
       // the spill list ran over (few distinct pairs that repeat a great deal): exact places from a histogram from now on
       plan->part2_fixed.store(-1, std::memory_order_relaxed);
@@ -1696,13 +1700,14 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggPar
   if (shard) {
     shard->p1 = p1;
     shard->p2 = p2;
+    shard->direct = direct;
     shard->lo_bits = lo_bits;
     shard->hi_bits = hi_bits;
     shard->n_fine = n_fine;
     shard->lds_entries = set_entries;
     shard->fine_count = d_fine.as<uint32_t>();
     shard->fine_base = d_fine.as<uint32_t>() + 2 * (size_t)n_fine;
-    shard->records = std::move(rec[0]);
+    shard->records = direct ? std::move(emitted) : std::move(rec[0]);
     shard->fine = std::move(d_fine);
     return true;
   }
@@ -2278,13 +2283,9 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
     // row; partitioned twice, the pairs are counted per group without the set ever being stored.
     GroupTable outer_q;
     bool outer_ready = false;
-    if (plan->distinct_plan && layout.words == 2 && !partial && !capture && part_ok && ap.n_pred == 0 &&
-        selected >= (part_forced(ctx) ? 1ull : (1ull << 24)) && plan->part_mode.load(std::memory_order_relaxed) >= 0) {
-      KernelTimer timer(ctx, "group_by", ss.rows * value_bytes);
-      // the group key's topmost field, when it is a time key: its bits and the buckets the scan spans
-      int time_bits = 0;
-      uint64_t time_buckets = 0;
-      for (size_t i = 0; i < keys.size(); ++i) {
+    // the group key's topmost field, when it is a time key without NULLs: its bits, and the time buckets the scan spans
+    auto leading_time_key = [&](int& time_bits, uint64_t& time_buckets) {
+      for (size_t i = 0; i < keys.size() && layout.fields.size() == keys.size() + 1; ++i) {
         const KeyField& kf = layout.fields[1 + i];
         const bool time_like = keys[i].date_bin || table->fields[keys[i].column].logical == PRISM_COL_TIMESTAMP;
         if (!time_like || kf.word != 1 || kf.bits == 0 || kf.null_bit >= 0 || kf.bit_pos + kf.bits != layout.word_bits[1]) continue;
@@ -2295,6 +2296,13 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
         time_bits = kf.bits;
         time_buckets = (uint64_t)hi_b - (uint64_t)lo_b + 1;
       }
+    };
+    if (plan->distinct_plan && layout.words == 2 && !partial && !capture && part_ok && ap.n_pred == 0 &&
+        selected >= (part_forced(ctx) ? 1ull : (1ull << 24)) && plan->part_mode.load(std::memory_order_relaxed) >= 0) {
+      KernelTimer timer(ctx, "group_by", ss.rows * value_bytes);
+      int time_bits = 0;
+      uint64_t time_buckets = 0;
+      leading_time_key(time_bits, time_buckets);
       outer_ready = partitioned_distinct(ctx, plan, ap, selected, key_bytes, layout, outer_q, nullptr, nullptr, time_bits, time_buckets);
       if (!outer_ready) plan->part_mode.store(-1, std::memory_order_relaxed);  // uneven data: the one-table way from now on
     }
@@ -2309,7 +2317,11 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
         if (ch->rows >= (1ull << 29)) fail(PRISM_GPU_EUNSUPPORTED, "a sharded COUNT(DISTINCT) takes chunks of fewer than 2^29 rows");
       shard = std::make_unique<DistinctShard>();
       KernelTimer timer(ctx, "group_by", ss.rows * value_bytes);
-      if (!partitioned_distinct(ctx, plan, ap, selected, key_bytes, layout, outer_q, shard_req, shard.get()))
+      // (the statistics are the ranks' agreed ones: every rank finds the same time key and the same span)
+      int time_bits = 0;
+      uint64_t time_buckets = 0;
+      leading_time_key(time_bits, time_buckets);
+      if (!partitioned_distinct(ctx, plan, ap, selected, key_bytes, layout, outer_q, shard_req, shard.get(), time_bits, time_buckets))
         fail(PRISM_GPU_EINTERNAL, "the distinct pairs of this rank's partitions do not fit the fine buckets");
       outer_ready = true;
     }
@@ -2999,6 +3011,7 @@ prism_gpu_state* distinct_shard_merge(prism_gpu_state* local, const uint64_t* re
   q.hi_bits = sh->hi_bits;
   q.p1_bits = (uint32_t)sh->p1;
   q.p2_bits = (uint32_t)sh->p2;
+  q.direct = sh->direct ? 1 : 0;  // (only tells the kernel how a bucket's number and a record's bits make the group key)
   q.n_rows = n_records;
   q.lds_entries = sh->lds_entries;
   q.x_null_bit = -1;

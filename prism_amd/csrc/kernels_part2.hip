@@ -976,7 +976,7 @@ uint32_t part2_lds_entries(bool compact) {
 
 void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q, const AggParams* scan) {
   if (q.n_rows == 0) return;
-  if (q.direct && (!scan || !q.compact || (q.fine_limit && !q.spill_rec) || q.emit_out || q.n_tiles == 0 || q.slice_tiles == 0 || (q.slice_tiles & 1u)))
+  if (q.direct && (!scan || !q.compact || (q.fine_limit && !q.spill_rec) || (q.emit_out && q.spill_rec) || q.n_tiles == 0 || q.slice_tiles == 0 || (q.slice_tiles & 1u)))
     fail(PRISM_GPU_EINTERNAL, "bad shape for a second partition level that reads the scan's columns");
   if (q.spill_rec) {
     const uint64_t regions = (uint64_t)q.n_regions * q.region_cap;
