@@ -283,7 +283,19 @@ void fill_array(BatchOwner* owner, OutColumn& col, ArrowArray& a) {
           for (size_t v = 0; v < d.size(); ++v) std::memcpy(&flat[v * w], d[v].data(), len[v]);
           data = owner->block((size_t)n * max_len + w, false);
           uint32_t pos = 0;
-          if (w == 16) {
+          bool uniform = nulls == 0;
+          for (uint32_t l : len) uniform = uniform && l == max_len;
+          if (uniform) {
+            // Values of one length and no NULL: a row's place is its number times the length, so the
+            // copies do not wait for one another (with running positions every row's store address
+            // hangs on the row before: code -> length -> sum, some five cycles a row).
+            if (w == 16) {
+              for (size_t i = 0; i < n; ++i) std::memcpy(data + i * max_len, &flat[(size_t)col.code_at(i) * 16], 16);
+            } else {
+              for (size_t i = 0; i < n; ++i) std::memcpy(data + i * max_len, &flat[(size_t)col.code_at(i) * 32], 32);
+            }
+            for (size_t i = 0; i < n; ++i) off[i + 1] = (int32_t)((i + 1) * max_len);
+          } else if (w == 16) {
             for (size_t i = 0; i < n; ++i) {
               const uint32_t code = valid[i] ? col.code_at(i) : 0u;
               std::memcpy(data + pos, &flat[(size_t)code * 16], 16);
