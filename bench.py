@@ -333,7 +333,7 @@ def parquet_feed(args) -> int:
     ctx.close()
     load = sorted(load_s)[len(load_s) // 2]
     line = {
-        "metric": "rows/sec Parquet files in host memory -> HBM-resident columns (pages decoded on host threads, dictionary strings expanded on the device)",
+        "metric": "rows/sec Parquet files in host memory -> HBM-resident columns (pages decoded on host threads; dictionary indices stay RLE / bit-packed and are expanded, with their strings, on the device)",
         "value": rows / load, "unit": "rows/s", "n_gpus": 1, "steps": len(load_s), "warmup": 1, "ms_per_step": load * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
         "config": {"workload": "C2 schema (timestamp ms, service Utf8 dictionary-encoded, value Int64) as prism-ingest writes it: "

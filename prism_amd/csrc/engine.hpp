@@ -287,6 +287,20 @@ uint64_t state_leading_rows(prism_gpu_state* st, struct Scratch& out_keys, struc
 // Parquet (parquet.cpp): decode on the host; append row groups as chunks.
 void parquet_read(const void* file, size_t len, ArrowSchema* out_schema, ArrowArray* out);
 void table_append_parquet(prism_gpu_table* table, uint32_t partition_id, const void* file, size_t len);
+// Dictionary indices as a Parquet file holds them: the runs of the RLE / bit-packed hybrid, not
+// yet expanded.  The library's own reader hands such a column to table_append (inside a
+// dictionary-encoded ArrowArray without an index buffer), and a kernel expands the runs in HBM.
+// (PackedRun: kernels.hpp)
+struct PackedIndices {
+  const uint8_t* bytes;  // (8 bytes of padding behind the last run's values)
+  size_t n_bytes;
+  const PackedRun* runs;
+  size_t n_runs;
+};
+// Null unless `a` is such an array.
+const PackedIndices* parquet_packed_indices(const ArrowArray* a);
+// The same expansion on the host (n indices).
+void packed_indices_expand(const PackedIndices& pk, int64_t n, std::vector<int32_t>& out);
 
 // FNV-1a over the dictionary values of a string column, in code order.
 void table_dictionary_digest(prism_gpu_table* table, int column, uint64_t* digest, uint32_t* n_values);

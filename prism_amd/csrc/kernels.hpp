@@ -587,6 +587,21 @@ struct DictExpand {
 void launch_dict_codes(prism_gpu_ctx* ctx, uint32_t* codes, const uint64_t* validity, uint64_t rows, const uint32_t* seg_row,
                        const uint32_t* seg_base, uint32_t n_segs, const uint32_t* remap, hipStream_t stream);
 size_t dict_expand_blocks(uint64_t rows);
+// The two halves of launch_dict_expand for a caller that does not know the bytes' total yet: the
+// first writes offsets[rows] (the total) and the workgroups' sums, the second, given `bytes`, the rest.
+void launch_dict_lens(prism_gpu_ctx* ctx, const DictExpand& q, hipStream_t stream);
+void launch_dict_fill(prism_gpu_ctx* ctx, const DictExpand& q, hipStream_t stream);
+// One run of a Parquet RLE / bit-packed hybrid, as the library's reader keeps dictionary indices.
+struct PackedRun {
+  uint32_t first;    // row (of the batch) the run starts at
+  uint32_t count;    // rows it covers
+  uint32_t kind;     // bit 31: bit-packed (else one repeated value); low bits: the bit width
+  uint32_t value;    // the repeated value, or the byte offset of the packed values in `bytes`
+};
+// out[r] = add + the r-th value of the runs; *flag = 1 when a value is not below dict_len or a row
+// lies beyond its run.  8 readable bytes must lie behind the last run's values.
+void launch_rle_expand(prism_gpu_ctx* ctx, const PackedRun* runs, uint32_t n_runs, const uint8_t* bytes, uint64_t rows, uint32_t add,
+                       uint32_t dict_len, uint32_t* out, uint32_t* flag, hipStream_t stream);
 void launch_dict_expand(prism_gpu_ctx* ctx, const DictExpand& q, hipStream_t stream);
 
 // ---- a dictionary built on the device (kernels_strdict.hip) ----

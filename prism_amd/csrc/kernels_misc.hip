@@ -150,7 +150,67 @@ __global__ __launch_bounds__(kBlock) void k_dict_codes(uint32_t* codes, const ui
   }
 }
 
+// Runs of the RLE / bit-packed hybrid -> one index per row (plus `add`, the place of the batch's
+// dictionary among the dictionaries laid end to end).  A row finds its run by bisection over the
+// runs' first rows; an index beyond the dictionary raises *flag.
+__global__ __launch_bounds__(kBlock) void k_rle_expand(const PackedRun* runs, uint32_t n_runs, const uint8_t* bytes, uint64_t rows,
+                                                      uint32_t add, uint32_t dict_len, uint32_t* out, uint32_t* flag) {
+  for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < rows; r += (uint64_t)gridDim.x * kBlock) {
+    uint32_t lo = 0, hi = n_runs;
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (runs[mid].first <= r) lo = mid; else hi = mid;
+    }
+    const PackedRun run = runs[lo];
+    uint32_t v = run.value;
+    if (run.kind & 0x80000000u) {
+      const uint32_t bw = run.kind & 63u;
+      const uint64_t bitpos = (r - run.first) * bw;
+      const uint8_t* p = bytes + run.value + (bitpos >> 3);
+      uint64_t word = 0;
+#pragma unroll
+      for (int b = 0; b < 8; ++b) word |= (uint64_t)p[b] << (8 * b);
+      v = (uint32_t)((word >> (bitpos & 7)) & ((1ull << bw) - 1ull));
+    }
+    if (r - run.first >= run.count || v >= dict_len) {
+      *flag = 1u;
+      v = 0;
+    }
+    out[r] = add + v;
+  }
+}
+
 }  // namespace
+
+void launch_rle_expand(prism_gpu_ctx* ctx, const PackedRun* runs, uint32_t n_runs, const uint8_t* bytes, uint64_t rows, uint32_t add,
+                       uint32_t dict_len, uint32_t* out, uint32_t* flag, hipStream_t stream) {
+  if (rows == 0 || n_runs == 0) return;
+  {  // (counted, not timed: the launch is on the caller's stream, among its copies)
+    std::lock_guard<std::mutex> g(ctx->mu);
+    const int i = stat_index(ctx, "rle_expand");
+    if (i >= 0) {
+      ctx->stats.kernels[i].launches += 1;
+      ctx->stats.kernels[i].algorithmic_bytes += rows * 4;
+    }
+  }
+  uint32_t grid = (uint32_t)std::min<uint64_t>(ceil_div(rows, (uint64_t)kBlock * 4), (uint64_t)ctx->n_cus * 8);
+  k_rle_expand<<<dim3(std::max(1u, grid)), dim3(kBlock), 0, stream>>>(runs, n_runs, bytes, rows, add, dict_len, out, flag);
+  PRISM_HIP(hipGetLastError());
+}
+
+void launch_dict_lens(prism_gpu_ctx* ctx, const DictExpand& q, hipStream_t stream) {
+  if (q.rows == 0) return;
+  const uint32_t n_blocks = (uint32_t)dict_expand_blocks(q.rows);
+  k_dict_lens<<<dim3(n_blocks), dim3(kDictThreads), 0, stream>>>(q);
+  k_dict_scan<<<dim3(1), dim3(kDictThreads), 0, stream>>>(q, n_blocks);
+  PRISM_HIP(hipGetLastError());
+}
+
+void launch_dict_fill(prism_gpu_ctx* ctx, const DictExpand& q, hipStream_t stream) {
+  if (q.rows == 0) return;
+  k_dict_expand<<<dim3((uint32_t)dict_expand_blocks(q.rows)), dim3(kDictThreads), 0, stream>>>(q);
+  PRISM_HIP(hipGetLastError());
+}
 
 void launch_dict_codes(prism_gpu_ctx* ctx, uint32_t* codes, const uint64_t* validity, uint64_t rows, const uint32_t* seg_row,
                        const uint32_t* seg_base, uint32_t n_segs, const uint32_t* remap, hipStream_t stream) {
@@ -164,11 +224,8 @@ size_t dict_expand_blocks(uint64_t rows) { return (size_t)ceil_div(rows, (uint64
 
 void launch_dict_expand(prism_gpu_ctx* ctx, const DictExpand& q, hipStream_t stream) {
   if (q.rows == 0) return;
-  const uint32_t n_blocks = (uint32_t)dict_expand_blocks(q.rows);
-  k_dict_lens<<<dim3(n_blocks), dim3(kDictThreads), 0, stream>>>(q);
-  k_dict_scan<<<dim3(1), dim3(kDictThreads), 0, stream>>>(q, n_blocks);
-  k_dict_expand<<<dim3(n_blocks), dim3(kDictThreads), 0, stream>>>(q);
-  PRISM_HIP(hipGetLastError());
+  launch_dict_lens(ctx, q, stream);
+  launch_dict_fill(ctx, q, stream);
 }
 
 void launch_synth_url(prism_gpu_ctx* ctx, const int32_t* offsets, uint8_t* bytes, uint64_t n_rows, uint64_t first_row,

@@ -360,6 +360,48 @@ void rle_decode(const uint8_t* p, const uint8_t* end, int bit_width, size_t coun
   }
 }
 
+// The runs of `count` values at [p, end) without expanding them: appended to `runs` (rows from
+// first_row on), the bit-packed values' bytes to `packed`.  A repeated value is checked against the
+// dictionary here; bit-packed ones are by whoever expands them.
+void rle_runs(const uint8_t* p, const uint8_t* end, int bit_width, size_t count, uint64_t first_row, size_t dict_size,
+              std::vector<PackedRun>& runs, std::vector<uint8_t>& packed) {
+  if (bit_width > 32) bad("bit width above 32");
+  if (first_row + count > 0xffffffffull) unsupported("more than 2^32 rows in one row group");
+  if (bit_width == 0) {
+    if (count && dict_size == 0) bad("dictionary index out of range");
+    if (count) runs.push_back({(uint32_t)first_row, (uint32_t)count, 0u, 0u});
+    return;
+  }
+  size_t n = 0;
+  Thrift v{p, end};
+  const int value_bytes = (bit_width + 7) / 8;
+  while (n < count) {
+    const uint64_t h = v.varint();
+    if (h & 1) {
+      const uint64_t groups = h >> 1;
+      if (groups == 0) bad("empty bit-packed run");
+      if (groups > (uint64_t)(v.end - v.p) / (uint64_t)bit_width) bad("bit-packed run beyond the page");
+      const uint64_t bytes = groups * (uint64_t)bit_width, values = std::min<uint64_t>(groups * 8, count - n);
+      if (packed.size() + bytes > 0xfffffff0ull) unsupported("more than 4 GiB of packed indices in one column chunk");
+      runs.push_back({(uint32_t)(first_row + n), (uint32_t)values, 0x80000000u | (uint32_t)bit_width, (uint32_t)packed.size()});
+      packed.insert(packed.end(), v.p, v.p + bytes);
+      v.p += bytes;
+      n += (size_t)values;
+    } else {
+      const uint64_t run = h >> 1;
+      if (run == 0) bad("empty RLE run");
+      if (v.end - v.p < value_bytes) bad("RLE run beyond the page");
+      uint32_t value = 0;
+      std::memcpy(&value, v.p, value_bytes);
+      v.p += value_bytes;
+      if (value >= dict_size) bad("dictionary index out of range");
+      const uint64_t take = std::min<uint64_t>(run, count - n);
+      runs.push_back({(uint32_t)(first_row + n), (uint32_t)take, (uint32_t)bit_width, value});
+      n += (size_t)take;
+    }
+  }
+}
+
 // ---- one column of one row group ----------------------------------------------------------------
 struct PqColumn {
   FieldType type;
@@ -373,6 +415,12 @@ struct PqColumn {
   // table loader, which expands it on the device): one index per row (0 where the row is NULL)
   // and the chunk's dictionary, instead of offsets and bytes.
   bool dict_form = false;
+  // ... and, for the loader that expands them on the device, the indices may stay the runs of
+  // the file's RLE / bit-packed hybrid (chunks without NULLs): `index` is empty then.
+  bool packed_form = false;
+  std::vector<uint8_t> packed;
+  std::vector<PackedRun> runs;
+  PackedIndices packed_view{};
   std::vector<int32_t> index;
   std::vector<int32_t> dict_offsets;  // entries + 1
   std::vector<uint8_t> dict_bytes;
@@ -441,7 +489,8 @@ void set_bits(std::vector<uint8_t>& bits, int64_t from, int64_t n) {
   for (; i < end; ++i) bits[(size_t)i >> 3] |= (uint8_t)(1u << (i & 7));
 }
 
-void decode_chunk(const uint8_t* file, size_t len, const Leaf& leaf, const ChunkMeta& cm, int64_t rows, PqColumn& col, bool keep_dict = false) {
+void decode_chunk(const uint8_t* file, size_t len, const Leaf& leaf, const ChunkMeta& cm, int64_t rows, PqColumn& col, bool keep_dict = false,
+                  bool keep_packed = false) {
   if (cm.codec != 0 && cm.codec != 1) unsupported("column `" + leaf.name + "` uses a codec other than UNCOMPRESSED / SNAPPY");
   if (cm.physical != leaf.physical) bad("column chunk and schema disagree on the type of `" + leaf.name + "`");
   const bool strings = leaf.physical == kByteArray;
@@ -456,6 +505,18 @@ void decode_chunk(const uint8_t* file, size_t len, const Leaf& leaf, const Chunk
   std::vector<uint32_t> def, idx;
   int64_t seen = 0;
   bool as_index = strings && keep_dict;  // until a data page turns out not to be dictionary encoded
+  bool as_packed = as_index && keep_packed;  // ... and, while no page holds a NULL, not even expanded
+  int64_t seen_rows = 0;
+  // (a page that cannot stay packed: what was kept as runs becomes indices, and the chunk goes on that way)
+  auto unpack = [&]() {
+    if (!as_packed) return;
+    as_packed = false;
+    col.packed.insert(col.packed.end(), 8, (uint8_t)0);
+    const PackedIndices view{col.packed.data(), col.packed.size(), col.runs.data(), col.runs.size()};
+    packed_indices_expand(view, seen_rows, col.index);
+    col.packed.clear();
+    col.runs.clear();
+  };
   const int w = col.type.width;
   const int64_t divisor = strings ? 1 : timestamp_divisor(leaf);
   if (strings) {
@@ -557,11 +618,18 @@ void decode_chunk(const uint8_t* file, size_t len, const Leaf& leaf, const Chunk
     }
     const bool by_dict = h.encoding == 2 || h.encoding == 8;
     if (!by_dict && h.encoding != 0) unsupported("encoding " + std::to_string(h.encoding) + " in column `" + leaf.name + "`");
+    seen_rows = seen;
+    const bool pack_page = as_packed && by_dict && present == n;
+    if (!pack_page) unpack();
     if (by_dict) {
       if (vals_end - vals < 1) bad("dictionary-encoded page without a bit width");
-      rle_decode(vals + 1, vals_end, vals[0], present, idx);
-      for (uint32_t k : idx)
-        if (k >= dict.size()) bad("dictionary index out of range in `" + leaf.name + "`");
+      if (pack_page) {
+        rle_runs(vals + 1, vals_end, vals[0], present, (uint64_t)seen, dict.size(), col.runs, col.packed);
+      } else {
+        rle_decode(vals + 1, vals_end, vals[0], present, idx);
+        for (uint32_t k : idx)
+          if (k >= dict.size()) bad("dictionary index out of range in `" + leaf.name + "`");
+      }
     }
     if (present == n) set_bits(col.validity, seen, (int64_t)n);
     else {
@@ -586,7 +654,9 @@ void decode_chunk(const uint8_t* file, size_t len, const Leaf& leaf, const Chunk
         col.index.shrink_to_fit();
         as_index = false;
       }
-      if (as_index) {
+      if (pack_page) {
+        // (nothing to do: the page's runs were kept)
+      } else if (as_index) {
         const size_t at = col.index.size();
         col.index.resize(at + n);
         int32_t* out = col.index.data() + at;
@@ -632,6 +702,10 @@ void decode_chunk(const uint8_t* file, size_t len, const Leaf& leaf, const Chunk
   }
   if (seen != rows) bad("column `" + leaf.name + "` holds " + std::to_string(seen) + " values for " + std::to_string(rows) + " rows");
   col.rows = rows;
+  if (as_packed) {
+    col.packed_form = true;
+    col.packed.insert(col.packed.end(), 8, (uint8_t)0);  // (whoever expands the runs reads 8 bytes at a time)
+  }
   if (as_index) {
     col.dict_form = true;
     col.dict_offsets.reserve(dict.spans.size() + 1);
@@ -656,6 +730,8 @@ void release_pq(ArrowArray* a) {
   a->release = nullptr;
 }
 void release_pq_child(ArrowArray* a) { a->release = nullptr; }
+// (the release function of a child whose indices are still packed: what parquet_packed_indices tells such a child by)
+void release_pq_packed(ArrowArray* a) { a->release = nullptr; }
 
 void export_columns(std::vector<PqColumn>&& cols, int64_t rows, ArrowArray* out) {
   auto owner = std::make_unique<PqOwner>();
@@ -673,7 +749,8 @@ void export_columns(std::vector<PqColumn>&& cols, int64_t rows, ArrowArray* out)
     b.push_back(col.nulls ? (const void*)col.validity.data() : nullptr);
     if (col.dict_form) {
       // Int32 indices; the values are the dictionary child (a Utf8 / Binary array without NULLs)
-      b.push_back(col.index.empty() ? (const void*)"" : (const void*)col.index.data());
+      b.push_back(col.packed_form ? nullptr : col.index.empty() ? (const void*)"" : (const void*)col.index.data());
+      if (col.packed_form) col.packed_view = PackedIndices{col.packed.data(), col.packed.size(), col.runs.data(), col.runs.size()};
       ArrowArray& d = owner->dictionaries[c];
       std::memset(&d, 0, sizeof(d));
       auto& db = owner->buffers[n + c];
@@ -696,6 +773,10 @@ void export_columns(std::vector<PqColumn>&& cols, int64_t rows, ArrowArray* out)
     a.n_buffers = (int64_t)b.size();
     a.buffers = b.data();
     a.release = release_pq_child;
+    if (col.packed_form) {
+      a.release = release_pq_packed;
+      a.private_data = &col.packed_view;
+    }
     owner->child_ptrs[c] = &a;
   }
   std::memset(out, 0, sizeof(*out));
@@ -732,6 +813,32 @@ void append_column(PqColumn& dst, PqColumn&& src) {
 }
 
 }  // namespace
+
+const PackedIndices* parquet_packed_indices(const ArrowArray* a) {
+  return a && a->release == release_pq_packed ? (const PackedIndices*)a->private_data : nullptr;
+}
+
+void packed_indices_expand(const PackedIndices& pk, int64_t n, std::vector<int32_t>& out) {
+  out.assign((size_t)n, 0);
+  for (size_t r = 0; r < pk.n_runs; ++r) {
+    const PackedRun& run = pk.runs[r];
+    if ((uint64_t)run.first + run.count > (uint64_t)n) fail(PRISM_GPU_EINTERNAL, "packed index runs beyond their rows");
+    int32_t* dst = out.data() + run.first;
+    if (!(run.kind & 0x80000000u)) {
+      std::fill(dst, dst + run.count, (int32_t)run.value);
+      continue;
+    }
+    const uint32_t bw = run.kind & 63u;
+    const uint64_t mask = (1ull << bw) - 1ull;
+    const uint8_t* b = pk.bytes + run.value;
+    uint64_t bitpos = 0;
+    for (uint32_t i = 0; i < run.count; ++i, bitpos += bw) {
+      uint64_t word;
+      std::memcpy(&word, b + (bitpos >> 3), 8);  // (the buffer is padded by 8 bytes)
+      dst[i] = (int32_t)((word >> (bitpos & 7)) & mask);
+    }
+  }
+}
 
 void parquet_read(const void* file_, size_t len, ArrowSchema* out_schema, ArrowArray* out) {
   const uint8_t* file = (const uint8_t*)file_;
@@ -797,7 +904,8 @@ void table_append_parquet(prism_gpu_table* table, uint32_t partition_id, const v
           if (leaf_of[f] >= 0) {
             // (string chunks stay dictionary encoded where the file has them so: table_append maps
             // a dictionary's values to the table's codes once, and the rows are expanded on the device)
-            decode_chunk(file, len, fm.leaves[leaf_of[f]], rg.chunks[leaf_of[f]], rg.num_rows, col, /*keep_dict=*/true);
+            decode_chunk(file, len, fm.leaves[leaf_of[f]], rg.chunks[leaf_of[f]], rg.num_rows, col, /*keep_dict=*/true,
+                         /*keep_packed=*/table->ctx->dict_expand_device.load(std::memory_order_relaxed) != 0);
           } else {
             col.rows = rg.num_rows;
             col.nulls = rg.num_rows;

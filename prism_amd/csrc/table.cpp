@@ -380,6 +380,11 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
     // staged as they are, and a kernel maps them through the dictionaries' codes.
     const bool device_codes = codes_only && ctx->dict_expand_device.load(std::memory_order_relaxed) != 0;
     std::vector<uint32_t> seg_row, seg_base;
+    // Batches of the library's Parquet reader whose indices are still the file's RLE / bit-packed
+    // runs (device_expand): runs and packed bytes are staged, and a kernel writes the indices.
+    struct PackedBatch { const PackedIndices* pk; uint64_t row0, rows; uint32_t base, dict_len; };
+    std::vector<PackedBatch> packed_batches;
+    uint64_t packed_bound = 0;  // no more bytes than this come out of the packed batches
     const ArrowArray* seg_dict = nullptr;  // the dictionary of the last segment: batches that share it extend the segment
     if (dict.alive && !device_expand && !device_codes) codes.resize((size_t)n);
     std::vector<int32_t> offs(codes_only || device_expand ? 1 : (size_t)n + 1);
@@ -399,14 +404,22 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
         // Int32 indices into a Utf8 / Binary dictionary (the schema declares the index type
         // when the column is declared dictionary encoded; other index widths are not accepted)
         const ArrowArray* d = a->dictionary;
-        if (a->n_buffers < 2 || !a->buffers[1] || d->n_buffers < 3 || !d->buffers[1])
+        const PackedIndices* pk = parquet_packed_indices(a);
+        if (a->n_buffers < 2 || (!a->buffers[1] && !pk) || d->n_buffers < 3 || !d->buffers[1])
           fail(PRISM_GPU_EINVAL, "dictionary-encoded column " + f.name + " lacks a buffer");
-        const int32_t* idx = (const int32_t*)a->buffers[1] + a->offset;
+        const int32_t* idx = pk ? nullptr : (const int32_t*)a->buffers[1] + a->offset;
+        std::vector<int32_t> unpacked;
+        auto need_idx = [&]() {  // (packed indices that no kernel will expand)
+          if (idx) return;
+          packed_indices_expand(*pk, a->offset + nb, unpacked);
+          idx = unpacked.data() + a->offset;
+        };
         const int32_t* doff = (const int32_t*)d->buffers[1] + d->offset;
         const char* dbytes = (const char*)d->buffers[2];
         const uint8_t* dvalid = (d->null_count != 0 && d->n_buffers > 0) ? (const uint8_t*)d->buffers[0] : nullptr;
         if (dvalid) fail(PRISM_GPU_EUNSUPPORTED, "NULL entries inside a dictionary are not supported (column " + f.name + ")");
         if (device_codes) {
+          need_idx();
           const bool same = seg_dict && seg_dict->length == d->length && seg_dict->offset == d->offset &&
                             seg_dict->buffers[1] == d->buffers[1] && seg_dict->buffers[2] == d->buffers[2];
           if (!same) {
@@ -437,14 +450,25 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
           if (cat_off.empty()) { cat_off.push_back(0); index.resize((size_t)n); }
           const uint64_t base = cat_off.size() - 1;
           if (base + (uint64_t)d->length >= 0xffffffffull) fail(PRISM_GPU_EUNSUPPORTED, "the dictionaries of one chunk of " + f.name + " hold 2^32 entries or more");
+          uint64_t longest = 0;
           for (int64_t k = 0; k < d->length; ++k) {
             if (doff[k + 1] < doff[k]) fail(PRISM_GPU_EINVAL, "dictionary offsets of " + f.name + " decrease");
+            longest = std::max<uint64_t>(longest, (uint64_t)(doff[k + 1] - doff[k]));
             const uint64_t end = (uint64_t)cat_off.back() + (uint64_t)(doff[k + 1] - doff[k]);
             if (end > 0x7fffffffull) fail(PRISM_GPU_EUNSUPPORTED, "the dictionaries of one chunk of " + f.name + " exceed 2 GiB");
             cat_off.push_back((uint32_t)end);
           }
           if (d->length > 0 && doff[d->length] > doff[0]) pieces.push_back({(const uint8_t*)dbytes + doff[0], (size_t)(doff[d->length] - doff[0])});
           remap_all.insert(remap_all.end(), remap.begin(), remap.end());
+          // (the kernels sum the lengths in 32 bits: the packed batches stay packed while their
+          // bytes cannot pass the chunk's limit whatever the indices are)
+          if (pk && !vbits && a->offset == 0 && total + packed_bound + (uint64_t)nb * longest <= 0x7fffffffull) {
+            packed_bound += (uint64_t)nb * longest;
+            packed_batches.push_back({pk, (uint64_t)row0, (uint64_t)nb, (uint32_t)base, (uint32_t)d->length});
+            row0 += nb;
+            continue;
+          }
+          need_idx();
           const uint32_t* len_at = cat_off.data() + base;
           for (int64_t i = 0; i < nb; ++i) {
             const bool valid = !vbits || bit_at(vbits, a->offset + i);
@@ -454,10 +478,11 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
             index[(size_t)(row0 + i)] = (uint32_t)(base + (uint64_t)k);
             total += len_at[k + 1] - len_at[k];
           }
-          if (total > 0x7fffffffull) fail(PRISM_GPU_EUNSUPPORTED, "string data of one chunk exceeds 2 GiB");
+          if (total + packed_bound > 0x7fffffffull) fail(PRISM_GPU_EUNSUPPORTED, "string data of one chunk exceeds 2 GiB");
           row0 += nb;
           continue;
         }
+        need_idx();
         if (codes_only) {
           // a streaming chunk whose input is dictionary encoded: the codes are all the kernels
           // need (no per-row expansion of the strings on the host)
@@ -544,13 +569,21 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
       // (pieces holds the dictionaries' bytes here, total the bytes of the expanded column)
       const size_t n_ent = cat_off.size() - 1, n_blocks = dict_expand_blocks((uint64_t)n);
       auto pad = [](size_t v) { return (v + 15) & ~(size_t)15; };
+      size_t packed_need = 16;  // (a flag and the bytes' total; then every packed batch's runs and bytes)
+      uint64_t packed_rows = 0;
+      for (const PackedBatch& pb : packed_batches) {
+        packed_need += pad(pb.pk->n_runs * sizeof(PackedRun)) + pad(pb.pk->n_bytes);
+        packed_rows += pb.rows;
+      }
       const size_t off_at = 0, remap_at = off_at + pad(cat_off.size() * 4), sums_at = remap_at + pad(n_ent * 4),
                    dbytes_at = sums_at + pad(n_blocks * 4), index_at = dbytes_at + pad((size_t)cat_off.back()),
-                   need = index_at + (dict.alive ? 0 : (size_t)n * 4);
+                   packed_at = index_at + pad(dict.alive ? 0 : (size_t)n * 4), need = packed_at + packed_need;
       uint8_t* tmp = (uint8_t*)load_scratch(ctx, need);
       dc.values = dev_alloc(t, ((size_t)n + 1) * 4);
-      dc.bytes = (uint8_t*)dev_alloc(t, (size_t)total);
-      dc.n_bytes = total;
+      if (packed_batches.empty()) {
+        dc.bytes = (uint8_t*)dev_alloc(t, (size_t)total);
+        dc.n_bytes = total;
+      }
       if (dict.alive) dc.codes = (uint32_t*)dev_alloc(t, (size_t)n * 4);
       w.begin(tmp + off_at);
       w.write(cat_off.data(), cat_off.size() * 4);
@@ -561,9 +594,30 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
       w.begin(tmp + dbytes_at);
       for (const Piece& pc : pieces) w.write(pc.p, pc.n);
       uint32_t* d_index = dict.alive ? dc.codes : (uint32_t*)(tmp + index_at);
-      w.begin(d_index);
-      w.write(index.data(), (size_t)n * 4);
+      if (packed_rows < (uint64_t)n) {
+        w.begin(d_index);
+        w.write(index.data(), (size_t)n * 4);
+      }
+      size_t at = packed_at + 16;
+      std::vector<size_t> runs_at;
+      for (const PackedBatch& pb : packed_batches) {
+        runs_at.push_back(at);
+        w.begin(tmp + at);
+        w.write(pb.pk->runs, pb.pk->n_runs * sizeof(PackedRun));
+        at += pad(pb.pk->n_runs * sizeof(PackedRun));
+        w.begin(tmp + at);
+        w.write(pb.pk->bytes, pb.pk->n_bytes);
+        at += pad(pb.pk->n_bytes);
+      }
       w.flush();
+      uint32_t* d_flag = (uint32_t*)(tmp + packed_at);
+      if (!packed_batches.empty()) PRISM_HIP(hipMemsetAsync(d_flag, 0, 16, ctx->copy_stream));
+      for (size_t k = 0; k < packed_batches.size(); ++k) {
+        const PackedBatch& pb = packed_batches[k];
+        const uint8_t* d_runs = tmp + runs_at[k];
+        launch_rle_expand(ctx, (const PackedRun*)d_runs, (uint32_t)pb.pk->n_runs, d_runs + pad(pb.pk->n_runs * sizeof(PackedRun)), pb.rows,
+                          pb.base, pb.dict_len, d_index + pb.row0, d_flag, ctx->copy_stream);
+      }
       DictExpand q;
       q.index = d_index;
       q.rows = (uint64_t)n;
@@ -574,7 +628,22 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
       q.offsets = (int32_t*)dc.values;
       q.bytes = dc.bytes;
       q.block_sums = (uint32_t*)(tmp + sums_at);
-      launch_dict_expand(ctx, q, ctx->copy_stream);
+      if (packed_batches.empty()) {
+        launch_dict_expand(ctx, q, ctx->copy_stream);
+      } else {
+        // the bytes' total is only known on the device: it sizes the column's buffer
+        launch_dict_lens(ctx, q, ctx->copy_stream);
+        PRISM_HIP(hipMemcpyAsync(d_flag + 1, (const int32_t*)dc.values + n, 4, hipMemcpyDeviceToDevice, ctx->copy_stream));
+        uint32_t back[2] = {0, 0};
+        PRISM_HIP(hipMemcpyAsync(back, d_flag, 8, hipMemcpyDeviceToHost, ctx->copy_stream));
+        PRISM_HIP(hipStreamSynchronize(ctx->copy_stream));
+        if (back[0]) fail(PRISM_GPU_EINVAL, "dictionary index out of range in " + f.name);
+        total = back[1];
+        dc.bytes = (uint8_t*)dev_alloc(t, (size_t)total);
+        dc.n_bytes = total;
+        q.bytes = dc.bytes;
+        launch_dict_fill(ctx, q, ctx->copy_stream);
+      }
       launch_col_stats(ctx, dict.alive ? (const void*)dc.codes : dc.values, dc.validity, 4, true, (uint64_t)n, &ch.d_stats[ci], ctx->copy_stream);
       continue;
     }

@@ -198,8 +198,16 @@ def test_every_writer_configuration_lands_in_hbm_as_the_host_reader_decodes_it(g
     t = parquet_read(data)
     g = Table(gpu_ctx, t.schema)
     try:
+        gpu_ctx.reset_stats()
         g.append_parquet(0, data)
         assert g.num_rows == t.num_rows
+        # chunks without NULLs that are dictionary encoded throughout leave the reader as the
+        # file's RLE / bit-packed runs: a kernel makes the indices
+        expanded = gpu_ctx.stats()["kernels"].get("rle_expand", {"launches": 0})["launches"]
+        if case in ("like_prism_ingest", "v1_snappy_dict", "v2_row_groups") and not nulls:
+            assert expanded > 0
+        if not CASES[case]["use_dictionary"]:
+            assert expanded == 0
         for q, n_keys in [
             (QueryPlan([count_star(), sum_("small64"), max_("i32")], keys=["method"]), 1),
             (QueryPlan([count_star()], predicate=col("url").like("%host7%") & (col("method") != "GET")), 0),
@@ -212,5 +220,37 @@ def test_every_writer_configuration_lands_in_hbm_as_the_host_reader_decodes_it(g
             finally:
                 plan.close()
             assert_tables_match(got, pyoracle.execute(t, q), n_keys)
+    finally:
+        g.close()
+
+
+def test_packed_indices_beyond_the_dictionary_are_refused(gpu_ctx):
+    """A bit-packed dictionary index that points past the dictionary: the host reader refuses
+    the file, and so does the loader, whose kernel expands the runs (the range check is the
+    kernel's there)."""
+    import io
+
+    from prism_amd.engine import PrismGpuError, Table, parquet_read
+
+    n = 3000
+    t = pa.table({"s": pa.array([["a", "bb", "ccc"][i % 3] for i in range(n)]), "v": pa.array(range(n), pa.int64())})
+    sink = io.BytesIO()
+    pq.write_table(t, sink, compression="none", use_dictionary=True, data_page_version="1.0", write_statistics=False)
+    data = bytearray(sink.getvalue())
+    # indices 0,1,2,0,1,2,.. at two bits each, least significant first: 0x24 0x49 0x92 over and over
+    at = bytes(data).find(b"\x24\x49\x92" * 4)
+    assert at > 0
+    g = Table(gpu_ctx, t.schema)
+    try:
+        g.append_parquet(0, bytes(data))
+        assert g.num_rows == n
+        data[at + 300] |= 0x03  # (the fourth entry of a dictionary of three)
+        with pytest.raises(PrismGpuError) as e:
+            parquet_read(bytes(data))
+        assert "index" in e.value.msg
+        with pytest.raises(PrismGpuError) as e:
+            g.append_parquet(1, bytes(data))
+        assert e.value.code == -1 and "index out of range" in e.value.msg
+        assert g.num_rows == n and g.num_partitions == 1
     finally:
         g.close()
