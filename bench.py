@@ -137,6 +137,24 @@ def price_dominant_kernel(wl, rows, parts, stats, groups, world):
     return roofline
 
 
+def pass_breakdown(ctx, step, stats, steps: int = 3):
+    """The timed steps run with events around whole launches only (profiling level 2: an event
+    between two passes of a partitioned GROUP BY delays the second pass by some microseconds).
+    The per-pass durations come from a few more steps, untimed, with every event on; `stats`
+    (of the timed steps) gets those passes' figures added under their names."""
+    ctx.reset_stats()
+    ctx.set_profiling(1)
+    for _ in range(steps):
+        step()
+    ctx.set_profiling(0)
+    detail = ctx.stats()["kernels"]
+    for name, v in detail.items():
+        have = stats["kernels"].get(name)
+        if (have is None or not have["total_ms"]) and v["total_ms"]:
+            stats["kernels"][name] = dict(v, breakdown_pass=True)
+    return stats
+
+
 def extra_workloads(ctx, steps: int, warmup: int, sample_rows_cap: int = 16_000_000):
     """The other configurations, a few steps each, for the same record as the headline: per
     workload the step time, the dominant kernel's HIP-event time, the roofline fraction on
@@ -180,14 +198,14 @@ def extra_workloads(ctx, steps: int, warmup: int, sample_rows_cap: int = 16_000_
                 for _ in range(warmup):
                     plan.execute(table)
                 ctx.reset_stats()
-                ctx.set_profiling(True)
+                ctx.set_profiling(2)
                 t0 = time.perf_counter()
                 result = None
                 for _ in range(steps):
                     result = plan.execute(table)
                 elapsed = time.perf_counter() - t0
                 ctx.set_profiling(False)
-                stats = ctx.stats()
+                stats = pass_breakdown(ctx, lambda: plan.execute(table), ctx.stats())
                 roof = price_dominant_kernel(wl, rows, parts, stats, result.num_rows if wl.n_keys else 1, 1)
                 entry.update({"steps": steps, "ms_per_step": elapsed / steps * 1e3, "rows_per_s": rows / (elapsed / steps),
                               "groups": result.num_rows})
@@ -532,7 +550,7 @@ def main() -> int:
     for _ in range(args.warmup):
         step()
     ctx.reset_stats()
-    ctx.set_profiling(True)
+    ctx.set_profiling(2)
     barrier()
     t0 = time.perf_counter()
     result = None
@@ -546,8 +564,10 @@ def main() -> int:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    stats = ctx.stats()
+    if not grouped:
+        stats = pass_breakdown(ctx, step, stats)
     if rank == 0:
-        stats = ctx.stats()
         # full-size, size-independent checks: every row lands in exactly one group
         if args.workload in ("C2",):
             assert sum(result.column("COUNT(*)").to_pylist()) == total_rows, "COUNT(*) does not add up to the rows scanned"
@@ -576,7 +596,9 @@ def main() -> int:
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "exchange": comm.stats() if comm is not None and exchange == "state" else None,
-            "kernels": {n: {"launches": v["launches"], "avg_ms": v["total_ms"] / max(1, v["launches"])}
+            # (entries with `breakdown_pass`: single passes of a composite launch, from a few untimed steps after the timed ones)
+            "kernels": {n: dict({"launches": v["launches"], "avg_ms": v["total_ms"] / max(1, v["launches"])},
+                                **({"breakdown_pass": True} if v.get("breakdown_pass") else {}))
                         for n, v in stats["kernels"].items()},
         }
         if world == 1 and not grouped and args.workload == "C2" and not args.rows and not args.no_extra_workloads:

@@ -211,6 +211,10 @@ void prism_gpu_ctx_free(prism_gpu_ctx* ctx);
  *                    histogram pass; 1 (default): without one (hot keys counted in LDS, fixed
  *                    segments per workgroup and bucket), falling back when a segment overflows
  *   "part_wc_min_rows" fewer selected rows never take that path (default 8388608)
+ *   "part_wc_leading" 0: that path lists every group; 1 (default): under ORDER BY COUNT(*) DESC LIMIT n
+ *                    (n <= 1024) only the groups whose count reaches the n-th largest total among the
+ *                    keys counted in LDS -- exact totals, known before the aggregation pass -- are
+ *                    listed, and the selection of the first n runs over those few
  *   "part2_fixed"    0: the second partition level of COUNT(DISTINCT) always counts the rows of its
  *                    fine buckets first; 1 (default): fine buckets get regions of fixed size, and the counting
  *                    pass only runs when one overflows
@@ -551,6 +555,10 @@ typedef struct prism_gpu_stats {
   uint64_t chunks_pruned; /* chunks skipped because their min/max rule the predicate out */
 } prism_gpu_stats;
 
+/* 0: launches are counted, not timed.  1: every timed launch is bracketed by events on the library's
+ * stream (total_ms).  2: the same, except for the separate passes of a partitioned GROUP BY /
+ * COUNT(DISTINCT) -- the launch as a whole is still timed under "group_by"; an event between two
+ * passes delays the second by some microseconds. */
 int prism_gpu_set_profiling(prism_gpu_ctx* ctx, int enabled);
 int prism_gpu_get_stats(prism_gpu_ctx* ctx, prism_gpu_stats* out);
 int prism_gpu_reset_stats(prism_gpu_ctx* ctx);

@@ -355,6 +355,7 @@ int prism_gpu_set_option(prism_gpu_ctx* ctx, const char* name, int64_t value) {
     if (n == "part_min_rows") { require(value >= 0, "part_min_rows must not be negative"); ctx->part_min_rows.store((uint64_t)value); }
     else if (n == "part_force") ctx->part_force.store(value != 0 ? 1 : 0);
     else if (n == "part_wc") ctx->part_wc.store(value != 0 ? 1 : 0);
+    else if (n == "part_wc_leading") ctx->part_wc_leading.store(value != 0 ? 1 : 0);
     else if (n == "part_wc_min_rows") { require(value >= 0, "part_wc_min_rows must not be negative"); ctx->part_wc_min_rows.store((uint64_t)value); }
     else if (n == "part2_fixed") ctx->part2_fixed.store(value != 0 ? 1 : 0);
     else if (n == "part2_half_blocks") ctx->part2_half_blocks.store(value != 0 ? 1 : 0);
@@ -377,7 +378,7 @@ int prism_gpu_set_profiling(prism_gpu_ctx* ctx, int enabled) {
   return guarded([&] {
     require(ctx != nullptr, "ctx is null");
     std::lock_guard<std::mutex> g(ctx->mu);
-    ctx->profiling = enabled != 0;
+    ctx->profiling = enabled == 2 ? 2 : enabled != 0 ? 1 : 0;
   });
 }
 

@@ -73,6 +73,7 @@ struct prism_gpu_ctx {
   std::atomic<int> part_force{0};                    // 1: partition whenever the plan shape allows it
   std::atomic<int> part_half_blocks{1};              // 0: the scatter pass of a partitioned GROUP BY always runs one 1024-thread workgroup per CU
   std::atomic<int> part_wc{1};                       // 0: GROUP BY key -> COUNT(*) never takes the histogram-free path
+  std::atomic<int> part_wc_leading{1};               // 0: that path lists every group, whatever the plan's ORDER BY .. LIMIT
   std::atomic<uint64_t> part_wc_min_rows{1ull << 23};  // fewer selected rows: the path with the histogram
   std::atomic<int> part2_fixed{1};                   // 0: the second partition level of COUNT(DISTINCT) always runs its histogram pass
   std::atomic<int> part2_half_blocks{0};             // 1: the one-level COUNT(DISTINCT) scatter runs two workgroups of 512 threads per CU
@@ -88,7 +89,7 @@ struct prism_gpu_ctx {
   std::atomic<int> sharded_fail_phase{0};            // tests: prism_gpu_execute_sharded fails on purpose in this local phase (1..5) on this context's rank
 
   // ---- profiling ----
-  bool profiling = false;
+  int profiling = 0;  // 0: off; 1: every timed launch; 2: not the passes inside a composite launch (KernelTimer::detail)
   struct Pending {
     int stat;
     hipEvent_t a, b;
@@ -203,14 +204,17 @@ struct KernelTimer {
   prism_gpu_ctx* ctx;
   int stat;
   hipEvent_t a = nullptr;
-  KernelTimer(prism_gpu_ctx* c, const char* name, uint64_t algorithmic_bytes) : ctx(c) {
+  // detail: one pass of a launch that a timer of its own brackets as a whole (the passes of a
+  // partitioned GROUP BY inside "group_by").  An event between two kernels of a stream keeps
+  // the second from starting for some microseconds; profiling level 2 leaves those out.
+  KernelTimer(prism_gpu_ctx* c, const char* name, uint64_t algorithmic_bytes, bool detail = false) : ctx(c) {
     std::lock_guard<std::mutex> g(ctx->mu);
     stat = stat_index(ctx, name);
     if (stat >= 0) {
       ctx->stats.kernels[stat].launches += 1;
       ctx->stats.kernels[stat].algorithmic_bytes += algorithmic_bytes;
     }
-    if (ctx->profiling && stat >= 0) {
+    if (ctx->profiling && !(detail && ctx->profiling == 2) && stat >= 0) {
       a = take_event(ctx);
       PRISM_HIP(hipEventRecord(a, ctx->stream));
     }

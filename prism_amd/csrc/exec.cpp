@@ -1114,9 +1114,12 @@ bool part_forced(const prism_gpu_ctx* ctx) { return ctx->part_force != 0; }
 // overflowed (nothing usable was produced; the plan remembers, and the caller partitions with
 // the histogram).
 bool wc_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggParams& ap, uint64_t selected, uint64_t key_bytes,
-                 const std::vector<int>& slot_ops, GroupTable& gt, uint64_t* groups_out) {
+                 const std::vector<int>& slot_ops, GroupTable& gt, uint64_t* groups_out, uint32_t leading, GroupRows* lead) {
+  // (with `leading`: the few listed groups are fetched along with the counters -- `lead`, and no table in `gt`)
+  constexpr uint64_t kLeadFetch = 2048;
   WcParams w;
   std::memset(&w, 0, sizeof(w));
+  w.leading = leading;
   const uint64_t per = std::max<uint64_t>(1, ceil_div(ap.sd.n_tiles, (uint64_t)ctx->n_cus));
   w.tiles_per_wg = (uint32_t)per;
   w.n_wg = (uint32_t)std::max<uint64_t>(1, ceil_div(ap.sd.n_tiles, per));
@@ -1144,13 +1147,17 @@ bool wc_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggParams& ap, 
   w.hot_keys = hot.as<uint64_t>();
   // what starts at zero lies in one block behind the sample's keys and is cleared in one go: the
   // sample's counts, the hot keys' rows, and a small block -- [0] the list cursor (8 bytes),
-  // [8] the candidates, [16] four flags, [32] the hot keys' rows in total
+  // [8] the candidates, [16] four flags, [32] the hot keys' rows in total, [40] the groups outside the
+  // hot table, [48] the count a listed group reaches (ORDER BY COUNT(*) DESC LIMIT)
   w.hot_count = (unsigned long long*)(w.s_cnt + n_cm);
   uint8_t* const d_small = (uint8_t*)(w.hot_count + wc_hot_slots());
   w.list_cursor = (unsigned long long*)d_small;
   w.n_cand = (uint32_t*)(d_small + 8);
   w.flags = (uint32_t*)(d_small + 16);
   w.hot_rows = (unsigned long long*)(d_small + 32);
+  w.groups_total = (unsigned long long*)(d_small + 40);
+  w.cut = (uint32_t*)(d_small + 48);
+  if (w.lds_entries < wc_hot_slots() || leading > wc_hot_slots()) w.leading = 0;
   uint64_t groups_est = plan->part_groups.load(std::memory_order_relaxed);
   if (!groups_est) groups_est = plan->groups_hint;
   uint64_t list_cap = groups_est ? groups_est + groups_est / 16 + 1024 : std::min<uint64_t>(selected, 1ull << 25);
@@ -1174,9 +1181,16 @@ bool wc_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggParams& ap, 
       KernelTimer timer(ctx, "group_by", selected * key_bytes);
       launch_wc_group_by(ctx, ap, w, key_bytes);
     }
-    struct { unsigned long long cursor; uint32_t n_cand, pad; uint32_t flags[4]; unsigned long long hot_rows; } h{};
+    struct { unsigned long long cursor; uint32_t n_cand, pad; uint32_t flags[4]; unsigned long long hot_rows, groups_total; uint32_t cut, pad2; } h{};
     HostTimer ht_wait(ctx, "host:part_wait");
     PRISM_HIP(hipMemcpyAsync(&h, d_small, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    std::shared_ptr<void> lead_pin;
+    const uint64_t lead_fetch = std::min<uint64_t>(kLeadFetch, list_cap);
+    if (w.leading && lead) {
+      lead_pin = lease_pinned(ctx, (size_t)kLeadFetch * 16);
+      PRISM_HIP(hipMemcpyAsync(lead_pin.get(), list.keys.p, lead_fetch * 8, hipMemcpyDeviceToHost, ctx->stream));
+      PRISM_HIP(hipMemcpyAsync((uint64_t*)lead_pin.get() + kLeadFetch, list.state.p, lead_fetch * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
     PRISM_HIP(hipStreamSynchronize(ctx->stream));
     if (std::getenv("PRISM_WC_DEBUG"))
       std::fprintf(stderr, "[wc] n_wg %u tiles/wg %u cap 2^%u entries %u sample %u thr %u: groups %llu cand %u flags %u %u %u\n", w.n_wg,
@@ -1193,12 +1207,24 @@ bool wc_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggParams& ap, 
       list_cap = groups + 1024;
       continue;
     }
+    if (h.cut && lead_pin && groups <= lead_fetch) {
+      // the groups that can lead the order are on the host already
+      const uint64_t* k = (const uint64_t*)lead_pin.get();
+      lead->keys.assign(k, k + groups);
+      lead->state.assign((const int64_t*)(k + kLeadFetch), (const int64_t*)(k + kLeadFetch) + groups);
+      lead->n = groups;
+      *groups_out = groups;
+      plan->part_groups.store(std::max<uint64_t>(1, h.groups_total + wc_hot_slots()), std::memory_order_relaxed);
+      return true;
+    }
+    // (only the groups that can lead the order were listed: the list ends behind them)
+    if (h.cut) list.capacity = list_cap = groups;
     const uint64_t tail = list_cap + 1 - groups;  // the entries past the groups, and the extra entry
     PRISM_HIP(hipMemsetAsync(list.keys.as<uint64_t>() + groups, 0xff, tail * 8, ctx->stream));
     PRISM_HIP(hipMemsetAsync(list.state.as<int64_t>() + groups, 0, tail * 8, ctx->stream));
     gt = std::move(list);
     *groups_out = groups;
-    plan->part_groups.store(std::max<uint64_t>(1, groups), std::memory_order_relaxed);
+    plan->part_groups.store(std::max<uint64_t>(1, h.cut ? h.groups_total + wc_hot_slots() : groups), std::memory_order_relaxed);
     return true;
   }
 }
@@ -1207,14 +1233,14 @@ bool wc_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggParams& ap, 
 // predicate) through partitioning.  `gt` becomes a list of the groups; returns their number.
 uint64_t partitioned_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, AggParams ap, uint64_t selected, uint64_t scan_rows,
                               uint64_t key_bytes, uint64_t value_bytes, bool vals_nullable, const std::vector<int>& slot_ops,
-                              GroupTable& gt) {
+                              GroupTable& gt, uint32_t leading = 0, GroupRows* lead = nullptr) {
   const int words = part_record_words(ap, vals_nullable);
   if (words <= 0) fail(PRISM_GPU_EINTERNAL, "plan shape cannot be partitioned");
   // one-word keys and COUNT(*) alone: the path without a histogram, unless it overflowed before
   if (ctx->part_wc.load(std::memory_order_relaxed) != 0 && plan->wc_mode.load(std::memory_order_relaxed) >= 0 && wc_plan_fits(ap) &&
       selected >= ctx->part_wc_min_rows.load(std::memory_order_relaxed) && selected < (1ull << 32) - wc_hot_slots()) {
     uint64_t n = 0;
-    if (wc_group_by(ctx, plan, ap, selected, key_bytes, slot_ops, gt, &n)) return n;
+    if (wc_group_by(ctx, plan, ap, selected, key_bytes, slot_ops, gt, &n, leading, lead)) return n;
   }
   const uint32_t p_max = part_max_buckets(words);
   const uint32_t lds_entries = part_lds_entries(ap);
@@ -2233,6 +2259,7 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
     uint64_t bound = selected;
     if (total_bits < 63) bound = std::min<uint64_t>(bound, 1ull << total_bits);
     GroupTable gt;
+    GroupRows lead;  // ORDER BY COUNT(*) DESC LIMIT: the leading groups, when the aggregation pass already picked them
     // ---- can, and should, the rows be partitioned by key first? ----
     bool vals_nullable = false;
     for (int j = 0; j < ap.n_vals; ++j)
@@ -2326,7 +2353,16 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       outer_ready = true;
     }
     if (use_part && !outer_ready) {
-      partitioned_group_by(ctx, plan, ap, selected, ss.rows, key_bytes, value_bytes, vals_nullable, slot_ops, gt);
+      // ORDER BY COUNT(*) DESC LIMIT n, the whole answer made here: the aggregation pass may list only
+      // the groups that can be among the first n (ClickBench's GROUP BY "UserID" ... LIMIT 10)
+      uint32_t leading = 0;
+      if (!capture && !partial && !merge_input && !plan->distinct_plan && ctx->part_wc_leading.load(std::memory_order_relaxed) != 0 &&
+          plan->order_by >= 0 && plan->descending && plan->limit >= 1 && plan->limit <= 1024 && (size_t)plan->order_by >= keys.size() &&
+          (size_t)plan->order_by - keys.size() < low.rules.size()) {
+        const AggRule& r = low.rules[(size_t)plan->order_by - keys.size()];
+        if ((r.func == PRISM_AGG_COUNT_STAR || r.func == PRISM_AGG_COUNT) && r.count_slot < 0 && r.main_slot == 0) leading = (uint32_t)plan->limit;
+      }
+      partitioned_group_by(ctx, plan, ap, selected, ss.rows, key_bytes, value_bytes, vals_nullable, slot_ops, gt, leading, &lead);
       dense = false;
     }
     while (!use_part && !outer_ready) {
@@ -2389,7 +2425,11 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       *capture = st.release();
       return;
     }
-    if (!plan->distinct_plan) {
+    if (lead.n) {
+      append_key_columns(table, keys, layout, 0, lead, cols, 0);
+      append_agg_columns(low, lead, false, cols, keys.size());
+      groups_out = lead.n;
+    } else if (!plan->distinct_plan) {
       if (!merge_input) gt.rows_bound = ss.rows;  // (merged counts add up over states: no such bound)
       groups_out = emit_groups(ctx, plan, table, keys, layout, low, gt, partial, cols);
     } else if (partial) {

@@ -299,6 +299,14 @@ struct WcParams {
   uint64_t list_capacity;
   unsigned long long* list_cursor;  // zero on entry
   uint32_t* flags;              // [0] the list overflowed, [1] a segment overflowed, [2] an LDS table overflowed; zero on entry
+  // ORDER BY COUNT(*) DESC LIMIT leading (0: the list takes every group).  The hot keys' totals
+  // are exact once the scatter pass is done; when at least `leading` of them are in use, the
+  // smallest of the `leading` largest is a count that the last group of the answer reaches, and
+  // only groups that reach it join the list: *cut is that count (0: every group was listed),
+  // *groups_total the groups outside the hot table either way.  Both zero on entry.
+  uint32_t leading;
+  uint32_t* cut;
+  unsigned long long* groups_total;
 };
 bool wc_plan_fits(const AggParams& p);
 uint32_t wc_lds_entries(uint32_t n_wg);

@@ -786,7 +786,7 @@ void launch_partitioned_group_by(prism_gpu_ctx* ctx, const AggParams& p_scan, co
   allow_lds(halves ? k.scatter_half : k.scatter, scatter_lds);
   allow_lds(k.agg, agg_lds);
   {
-    KernelTimer timer(ctx, "part_hist", hist_bytes);
+    KernelTimer timer(ctx, "part_hist", hist_bytes, true);
     if (q.by_hi && p_scan.key_words == 2) {
       // The buckets follow from the high word alone: the histogram runs as a one-word plan over
       // that word's columns (its packed value is the group key), with their loads requested
@@ -809,20 +809,20 @@ void launch_partitioned_group_by(prism_gpu_ctx* ctx, const AggParams& p_scan, co
     PRISM_HIP(hipGetLastError());
   }
   {
-    KernelTimer timer(ctx, "part_plan", 0);
+    KernelTimer timer(ctx, "part_plan", 0, true);
     k_part_offsets<<<dim3((uint32_t)ceil_div(P, kBlock)), dim3(kBlock), 0, ctx->stream>>>(q);
     PRISM_HIP(hipGetLastError());
     k_part_plan<<<dim3(1), dim3(kPartBlock), 0, ctx->stream>>>(q);  // (the bucket starts; the work items go unused when scatter_only)
     PRISM_HIP(hipGetLastError());
   }
   {
-    KernelTimer timer(ctx, "part_scatter", scatter_bytes);
+    KernelTimer timer(ctx, "part_scatter", scatter_bytes, true);
     (halves ? k.scatter_half : k.scatter)<<<dim3(q.n_wg), dim3(scatter_block), scatter_lds, ctx->stream>>>(p_scan, q);
     PRISM_HIP(hipGetLastError());
   }
   if (scatter_only) return;
   {
-    KernelTimer timer(ctx, "part_agg", agg_bytes);
+    KernelTimer timer(ctx, "part_agg", agg_bytes, true);
     const uint32_t grid = (uint32_t)std::min<uint64_t>(q.max_items, (uint64_t)ctx->n_cus);
     k.agg<<<dim3(grid), dim3(kPartBlock), agg_lds, ctx->stream>>>(p_table, q);
     PRISM_HIP(hipGetLastError());

@@ -1002,15 +1002,15 @@ void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q, cons
   int ahead = q.direct ? part_keys_ahead(ap) : 0;
   if (ahead != 2 && ahead != 3) ahead = 0;
   if (q.spill_rec) {
-    KernelTimer timer(ctx, "part2_layout", 0);
+    KernelTimer timer(ctx, "part2_layout", 0, true);
     k_part2_layout_uniform<<<dim3((uint32_t)ceil_div(n_fine + 1, 256)), dim3(256), 0, ctx->stream>>>(q, n_fine);
     PRISM_HIP(hipGetLastError());
   } else if (q.fine_limit) {
-    KernelTimer timer(ctx, "part2_layout", 0);
+    KernelTimer timer(ctx, "part2_layout", 0, true);
     k_part2_layout<<<dim3((uint32_t)ceil_div(n_fine + 1, 256)), dim3(256), 0, ctx->stream>>>(q, n_fine);
     PRISM_HIP(hipGetLastError());
   } else {
-    KernelTimer timer(ctx, "part2_hist", q.n_rows * 16);
+    KernelTimer timer(ctx, "part2_hist", q.n_rows * 16, true);
     if (q.direct) {
       auto kernel = ahead == 3 ? k_part2_hist_direct<3> : ahead == 2 ? k_part2_hist_direct<2> : k_part2_hist_direct<0>;
       kernel<<<dim3(slices), dim3(kP2Block), 0, ctx->stream>>>(q, ap);
@@ -1022,7 +1022,7 @@ void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q, cons
     PRISM_HIP(hipGetLastError());
   }
   {
-    KernelTimer timer(ctx, "part2_scatter", q.n_rows * (q.compact ? 24 : 32));
+    KernelTimer timer(ctx, "part2_scatter", q.n_rows * (q.compact ? 24 : 32), true);
     // (the columns' form can run two workgroups of 512 threads a CU, option "part2_half_blocks"; measured
     // slower at C5, 13.5-14.4 against 13.1-13.2 ms, and shorter runs spill more: off by default)
     const bool halves = q.direct && ctx->part2_half_blocks.load(std::memory_order_relaxed) != 0;
@@ -1040,7 +1040,7 @@ void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q, cons
     // the spill list sorted by bucket behind the regions; then every bucket as its two runs
     const uint64_t out_offset = (uint64_t)q.n_regions * q.region_cap;
     {
-      KernelTimer timer(ctx, "part2_spill", 0);
+      KernelTimer timer(ctx, "part2_spill", 0, true);
       const uint32_t grid = ctx->n_cus * 16;
       k_spill_count<<<dim3(grid), dim3(256), 0, ctx->stream>>>(q);
       Part2Params sc = q;  // (the scan of the fine buckets' counts, over the spill list's)
@@ -1058,7 +1058,7 @@ void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q, cons
     m.rank = 0;
     m.seg_base = q.seg_base_out;
     m.seg_cnt = q.seg_cnt_out;
-    KernelTimer timer(ctx, "part2_agg", q.n_rows * 8);
+    KernelTimer timer(ctx, "part2_agg", q.n_rows * 8, true);
     const size_t lds = (size_t)q.lds_entries * 8;
     PRISM_HIP(hipFuncSetAttribute((const void*)k_part2_agg_compact<kP2Merge>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint32_t grid = (uint32_t)std::min<uint64_t>(q.n_regions, (uint64_t)ctx->n_cus * kP2AggPerCu);
@@ -1067,7 +1067,7 @@ void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q, cons
     return;
   }
   {
-    KernelTimer timer(ctx, "part2_agg", q.n_rows * (q.compact ? 8 : 16));
+    KernelTimer timer(ctx, "part2_agg", q.n_rows * (q.compact ? 8 : 16), true);
     const size_t lds = (size_t)q.lds_entries * (q.compact ? 8 : 16);
     if (q.emit_out && !q.compact) fail(PRISM_GPU_EINTERNAL, "distinct records are emitted in the one-word form only");
     auto kernel = q.compact ? (q.emit_out ? k_part2_agg_compact<kP2Emit> : k_part2_agg_compact<kP2Count>) : k_part2_agg;

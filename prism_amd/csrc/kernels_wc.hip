@@ -427,13 +427,14 @@ __device__ __forceinline__ int wc_entry(unsigned long long* keys, uint32_t nb, u
 // The hot keys' totals join the list (one workgroup; run by the aggregation pass' first
 // workgroup once its buckets are done: the list has no order, and a launch of its own for a
 // thousand entries cost more than the work).
-__device__ __forceinline__ void wc_hot_emit(const WcParams& w) {
+__device__ __forceinline__ void wc_hot_emit(const WcParams& w, uint32_t cut) {
   const uint32_t i = threadIdx.x, lane = i & 63u;
   const unsigned long long k = i < kWcHotSlots ? w.hot_keys[i] : kWcEmpty;
   const unsigned long long c = i < kWcHotSlots ? w.hot_count[i] : 0ull;
-  const bool occ = k != kWcEmpty && c != 0ull;
+  const bool used = k != kWcEmpty && c != 0ull;
+  const bool occ = used && c >= (unsigned long long)cut;
   // (the rows the hot keys took: the caller sizes the next run's segments for the rest)
-  const unsigned long long wave_rows = wave_sum_u64(occ ? c : 0ull);
+  const unsigned long long wave_rows = wave_sum_u64(used ? c : 0ull);
   if (lane == 0 && wave_rows) atomicAdd(w.hot_rows, wave_rows);
   const uint64_t m = __ballot(occ);
   unsigned long long wave_first = 0;
@@ -451,12 +452,37 @@ __device__ __forceinline__ void wc_hot_emit(const WcParams& w) {
 
 __global__ __launch_bounds__(kWcBlock) void k_wc_agg(AggParams p, WcParams w) {
   extern __shared__ __align__(16) unsigned long long wc_lds[];
-  __shared__ uint32_t n_entries, wg_pos;
+  __shared__ uint32_t n_entries, wg_pos, cut_found;
   __shared__ unsigned long long out_base;
   const uint32_t E = w.lds_entries, nb = E / 2, tid = threadIdx.x, lane = tid & 63u;
   unsigned long long* keys = wc_lds;              // [E]
   uint32_t* cnt = (uint32_t*)(keys + E);          // [E]
   uint32_t* segcnt = cnt + E;                     // [n_wg]
+  // The count a group must reach to be listed (see WcParams::leading): every workgroup ranks the
+  // hot keys' totals itself -- a thousand numbers, each thread its own against all of them --
+  // and all arrive at the same one.
+  uint32_t cut = 0;
+  if (w.leading) {
+    static_assert(kWcHotSlots == kWcBlock, "one hot entry per thread");
+    uint32_t* hc = (uint32_t*)keys;  // (the table's place, before the first bucket needs it)
+    const uint32_t mine = w.hot_keys[tid] != kWcEmpty ? (uint32_t)w.hot_count[tid] : 0u;  // (fewer than 2^32 rows in a scan)
+    hc[tid] = mine;
+    if (tid == 0) cut_found = 0;
+    __syncthreads();
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < kWcHotSlots; j += 4) {
+      const uint4 o = *(const uint4*)&hc[j];
+      rank += (o.x > mine || (o.x == mine && j + 0 < tid)) ? 1u : 0u;
+      rank += (o.y > mine || (o.y == mine && j + 1 < tid)) ? 1u : 0u;
+      rank += (o.z > mine || (o.z == mine && j + 2 < tid)) ? 1u : 0u;
+      rank += (o.w > mine || (o.w == mine && j + 3 < tid)) ? 1u : 0u;
+    }
+    if (rank == w.leading - 1) cut_found = mine;  // (zero when fewer hot keys are in use)
+    __syncthreads();
+    cut = cut_found;
+    __syncthreads();
+    if (blockIdx.x == 0 && tid == 0) *w.cut = cut;
+  }
   // 32 lanes a segment and five rows a lane: a step covers 160 records of each of the wave's two
   // segments -- a segment of the usual 100 to 130 records in one step with a quarter of the
   // lanes idle (16 lanes x 8 rows covered 128, and most waves went round a second time for the
@@ -538,7 +564,28 @@ __global__ __launch_bounds__(kWcBlock) void k_wc_agg(AggParams p, WcParams w) {
     if (lost) w.flags[2] = 1u;
     __syncthreads();
     const uint32_t n = n_entries;
-    if (tid == 0) out_base = atomicAdd(w.list_cursor, (unsigned long long)n);
+    if (cut) {
+      // only the few groups that reach the cut are listed: a place each from the list's cursor
+      if (tid == 0) atomicAdd(w.groups_total, (unsigned long long)n);
+      for (uint32_t i0 = 0; i0 < E; i0 += kWcBlock) {
+        const uint32_t i = i0 + tid;
+        const uint32_t c = i < E ? cnt[i] : 0u;
+        if (c < cut) continue;
+        const unsigned long long at = atomicAdd(w.list_cursor, 1ull);
+        if (at < w.list_capacity) {
+          w.list_keys[at] = keys[i];
+          w.list_state[at] = (long long)c;
+        } else {
+          w.flags[0] = 1u;
+        }
+      }
+      __syncthreads();
+      continue;
+    }
+    if (tid == 0) {
+      out_base = atomicAdd(w.list_cursor, (unsigned long long)n);
+      atomicAdd(w.groups_total, (unsigned long long)n);
+    }
     __syncthreads();
     const uint64_t first = out_base;
     const bool fits = first + n <= w.list_capacity;
@@ -558,7 +605,7 @@ __global__ __launch_bounds__(kWcBlock) void k_wc_agg(AggParams p, WcParams w) {
     }
     __syncthreads();
   }
-  if (blockIdx.x == 0) wc_hot_emit(w);
+  if (blockIdx.x == 0) wc_hot_emit(w, cut);
 }
 
 void wc_allow_lds(const void* k, size_t bytes) {
@@ -582,18 +629,18 @@ uint64_t wc_sample_counters() { return 1ull << kWcCmBits; }
 void launch_wc_group_by(prism_gpu_ctx* ctx, const AggParams& p, const WcParams& w, uint64_t key_bytes) {
   if (!wc_plan_fits(p)) fail(PRISM_GPU_EINTERNAL, "plan shape does not fit the histogram-free GROUP BY");
   if (w.n_wg == 0 || (uint64_t)w.n_wg * w.tiles_per_wg < p.sd.n_tiles || w.cap_shift < 3 || w.cap_shift > 28 ||
-      w.lds_entries > wc_lds_entries(w.n_wg) || w.lds_entries < 64 || w.sample_tiles == 0 || w.sample_tiles > p.sd.n_tiles)
+      w.lds_entries > wc_lds_entries(w.n_wg) || w.lds_entries < 64 || (w.leading && (w.lds_entries < kWcHotSlots || w.leading > kWcHotSlots)) || w.sample_tiles == 0 || w.sample_tiles > p.sd.n_tiles)
     fail(PRISM_GPU_EINTERNAL, "bad work split for the histogram-free GROUP BY");
   const uint64_t rows = p.sd.n_tiles * kTileRows;
   {
-    KernelTimer timer(ctx, "wc_sample", (uint64_t)w.sample_tiles * kTileRows * key_bytes);
+    KernelTimer timer(ctx, "wc_sample", (uint64_t)w.sample_tiles * kTileRows * key_bytes, true);
     k_wc_sample<<<dim3(w.sample_tiles), dim3(kWcBlock), 0, ctx->stream>>>(p, w);
     PRISM_HIP(hipGetLastError());
     k_wc_build<<<dim3(1), dim3(kWcBlock), 0, ctx->stream>>>(w);
     PRISM_HIP(hipGetLastError());
   }
   {
-    KernelTimer timer(ctx, "wc_scatter", rows * (key_bytes + 8));
+    KernelTimer timer(ctx, "wc_scatter", rows * (key_bytes + 8), true);
     const size_t lds = (size_t)kWcBuckets * kWcStage * 8 + (size_t)kWcBuckets * 8 + (size_t)kWcHotSlots * 12;
     const int ahead = part_keys_ahead(p);
     const bool plain8 = ahead == 1 && p.n_keys == 1 && p.keys[0].width == 8 && !p.keys[0].date_bin && p.row_mode == kRowsAll;
@@ -603,7 +650,7 @@ void launch_wc_group_by(prism_gpu_ctx* ctx, const AggParams& p, const WcParams& 
     PRISM_HIP(hipGetLastError());
   }
   {
-    KernelTimer timer(ctx, "wc_agg", rows * 8);
+    KernelTimer timer(ctx, "wc_agg", rows * 8, true);
     const size_t lds = (size_t)w.lds_entries * 12 + (size_t)w.n_wg * 4;
     wc_allow_lds((const void*)k_wc_agg, lds);
     const uint32_t grid = std::min<uint32_t>(kWcBuckets, (uint32_t)ctx->n_cus);

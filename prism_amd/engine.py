@@ -142,8 +142,9 @@ class Context:
     def set_option(self, name: str, value: int) -> None:
         _check(self._lib.prism_gpu_set_option(self._h, name.encode(), int(value)))
 
-    def set_profiling(self, on: bool) -> None:
-        _check(self._lib.prism_gpu_set_profiling(self._h, 1 if on else 0))
+    def set_profiling(self, on) -> None:
+        """False / 0: off; True / 1: every timed launch; 2: composite launches as a whole only."""
+        _check(self._lib.prism_gpu_set_profiling(self._h, int(on)))
 
     def reset_stats(self) -> None:
         _check(self._lib.prism_gpu_reset_stats(self._h))

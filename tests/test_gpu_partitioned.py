@@ -508,6 +508,56 @@ def test_histogram_free_count_by_key_small_tables(wc_ctx, oracle):
             g.close()
 
 
+def test_order_by_count_limit_lists_only_the_groups_that_can_lead(wc_ctx, oracle):
+    """ORDER BY COUNT(*) DESC LIMIT n on the histogram-free path: the n-th largest total among the
+    keys counted in LDS is known before the aggregation pass, and only groups that reach it are
+    listed (no selection pass over millions of groups afterwards).  Same answer as with the
+    option off and as the oracle's, for limits the hot keys cover and for one they do not."""
+    from prism_amd.engine import Plan
+
+    wl = workloads.c3(id_bits=20)
+    rows, parts = 6_000_000, 6
+    table = workloads.build_gpu_table(wc_ctx, wl, 0, rows, rows, parts)
+    st = oracle.SynthTable(wl.schema, wl.make_cols(), wl.seed, 0, rows, rows, n_parts=parts, threads=8)
+    try:
+        full, _ = st.execute(QueryPlan([count_star()], keys=["UserID"]), threads=8)
+        count_of = dict(zip(full.column(0).to_pylist(), full.column(1).to_pylist()))
+        for limit in (1, 10, 100, 1024):
+            q = QueryPlan([count_star()], keys=["UserID"], order_by=1, descending=True, limit=limit)
+            want, _ = st.execute(q, threads=8)
+            for leading in (1, 0):
+                wc_ctx.set_option("part_wc_leading", leading)
+                wc_ctx.reset_stats()
+                plan = Plan(wc_ctx, wl.schema, q)
+                try:
+                    runs = [plan.execute(table), plan.execute(table)]
+                finally:
+                    plan.close()
+                ran = _kernels(wc_ctx)
+                assert "wc_agg" in ran and "part_hist" not in ran
+                if limit <= 10:
+                    assert ("topk_select" in ran) == (leading == 0), (limit, leading, sorted(ran))
+                for got in runs:
+                    assert got.num_rows == limit
+                    assert_topk_match(got, want, q.order_by)
+                    ids = got.column(0).to_pylist()
+                    assert len(set(ids)) == limit and [count_of[i] for i in ids] == got.column(1).to_pylist()
+        # ascending order, and an order by the key: every group is listed as before
+        for q in [QueryPlan([count_star()], keys=["UserID"], order_by=1, descending=False, limit=5),
+                  QueryPlan([count_star()], keys=["UserID"], order_by=0, descending=True, limit=5)]:
+            want, _ = st.execute(q, threads=8)
+            plan = Plan(wc_ctx, wl.schema, q)
+            try:
+                got = plan.execute(table)
+            finally:
+                plan.close()
+            assert_topk_match(got, want, q.order_by)
+    finally:
+        wc_ctx.set_option("part_wc_leading", 1)
+        st.close()
+        table.close()
+
+
 def test_histogram_free_path_hot_keys_and_many_groups(wc_ctx, oracle):
     """Log-uniform ids: the frequent ids are found in the sample and counted in LDS (they would
     overflow any segment: one id alone holds 1/20 of the rows), the rest goes through the
