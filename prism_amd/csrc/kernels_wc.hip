@@ -309,6 +309,7 @@ __global__ __launch_bounds__(kWcBlock) __attribute__((amdgpu_waves_per_eu(4))) v
       hot = hc1[r].y == key[r] ? (int)(2 * wc_hot_b1(mix[r]) + 1) : hot;
       hot = hc1[r].x == key[r] ? (int)(2 * wc_hot_b1(mix[r])) : hot;
       if (hot < 0 && hc1[r].y != kWcEmpty) {  // the first home bucket is full of other keys: the key may sit in its second
+        // (taken row by row: gathering a lane's rows that need it for one look-up measured slower)
         const uint32_t b2 = wc_hot_b2(mix[r]);
         const ulonglong2 hc2 = *(const ulonglong2*)&hot_keys[2 * b2];
         hot = hc2.y == key[r] ? (int)(2 * b2 + 1) : hot;
@@ -546,17 +547,33 @@ __global__ __launch_bounds__(kWcBlock) void k_wc_agg(AggParams p, WcParams w) {
           if (claim[u])
             old[u] = atomicCAS(&keys[2 * h1[u] + (c1[u].x == kWcEmpty ? 0u : 1u)], kWcEmpty, (unsigned long long)key[u]);
         }
-        uint32_t n_new = 0;
+        uint32_t n_new = 0, miss = 0;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          bool ins = claim[u] && old[u] == kWcEmpty;
+          const bool ins = claim[u] && old[u] == kWcEmpty;
           if (claim[u] && (old[u] == kWcEmpty || old[u] == key[u])) e[u] = (int)(2 * h1[u] + (c1[u].x == kWcEmpty ? 0u : 1u));
-          if (in[u] && e[u] < 0) {
-            e[u] = wc_entry(keys, nb, key[u], ins);
-            if (e[u] < 0) lost = true;
-          }
+          if (in[u] && e[u] < 0) miss |= 1u << u;
           n_new += (uint32_t)__popcll(__ballot(ins));
           if (in[u] && e[u] >= 0) atomicAdd(&cnt[e[u]], 1u);
+        }
+        // The rows whose first home bucket held two other keys, or whose claim another lane won:
+        // a few lanes of the wave, seldom two rows of one lane.  The walk along the probe path is
+        // taken once for all the step's rows (a lane's first such row, then its next while any lane
+        // has one): taken row by row, nearly every row of the step had some lane in it, and the
+        // whole wave went through the walk five times.
+        while (__ballot(miss != 0u) != 0ull) {
+          bool ins = false;
+          if (miss != 0u) {
+            const int u = __ffs((int)miss) - 1;
+            miss &= miss - 1u;
+            uint64_t k = key[0];
+#pragma unroll
+            for (int v = 1; v < U; ++v) k = u == v ? key[v] : k;
+            const int at = wc_entry(keys, nb, k, ins);
+            if (at < 0) lost = true;
+            else atomicAdd(&cnt[at], 1u);
+          }
+          n_new += (uint32_t)__popcll(__ballot(ins));
         }
         if (n_new && lane == 0) atomicAdd(&n_entries, n_new);
       }
