@@ -222,6 +222,10 @@ void prism_gpu_ctx_free(prism_gpu_ctx* ctx);
  *                    group key first; 1 (default): when the group key starts with a time key, the rows are
  *                    taken to arrive in time order -- sorted by those bits already -- and the second level
  *                    reads the columns itself (a plan whose rows turn out not to goes back to two levels)
+ *   "part2_lines"    0: that one-level form sorts every tile of rows by fine bucket in LDS and writes the runs;
+ *                    1 (default): a workgroup takes a stretch of rows of ONE time bucket (found by bisection),
+ *                    keeps a staging line of 8 records per fine bucket in LDS and copies full lines out as 64
+ *                    aligned bytes into its own part of the bucket's region (no barrier, no partial cache lines)
  *   "part2_half_blocks" 1: the scatter pass of that one-level form runs two workgroups of 512 threads per CU
  *                    (default 0: one of 1024, which measured faster)
  *   "part2_compact"  0: COUNT(DISTINCT) partitioned twice always keeps two-word records at the

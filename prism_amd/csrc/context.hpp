@@ -73,6 +73,7 @@ struct prism_gpu_ctx {
   std::atomic<int> part_force{0};                    // 1: partition whenever the plan shape allows it
   std::atomic<int> part_half_blocks{1};              // 0: the scatter pass of a partitioned GROUP BY always runs one 1024-thread workgroup per CU
   std::atomic<int> part_wc{1};                       // 0: GROUP BY key -> COUNT(*) never takes the histogram-free path
+  std::atomic<int> part2_lines{1};                   // 0: the one-level COUNT(DISTINCT) scatters tile by tile (sort in LDS, runs out)
   std::atomic<int> part_wc_leading{1};               // 0: that path lists every group, whatever the plan's ORDER BY .. LIMIT
   std::atomic<uint64_t> part_wc_min_rows{1ull << 23};  // fewer selected rows: the path with the histogram
   std::atomic<int> part2_fixed{1};                   // 0: the second partition level of COUNT(DISTINCT) always runs its histogram pass

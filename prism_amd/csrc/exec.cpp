@@ -1619,11 +1619,23 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggPar
   if (direct && shard) emitted = Scratch(ctx, std::max<uint64_t>(1, selected) * 8 + 256);
   bool spill = direct && !shard && ctx->part2_fixed.load(std::memory_order_relaxed) != 0 && plan->part2_fixed.load(std::memory_order_relaxed) >= 0 &&
                region_records + spill_capacity < (1ull << 32);
-  Scratch spill_rec, spill_fine, spill_small;
+  Scratch spill_rec, spill_fine, spill_small, d_pieces;
+  // (the scatter pass by staging lines: a workgroup per piece of a coarse bucket's stretch of tiles; about three pieces a CU)
+  const int ahead_keys = part2_keys_ahead(ap);
+  const bool lines_wanted = spill && ctx->part2_lines.load(std::memory_order_relaxed) != 0 && (ahead_keys == 2 || ahead_keys == 3) && ap.sd.n_tiles < (1ull << 32) &&
+                     // (the rows of the tiles where the coarse bucket changes take the spill list: a coarse bucket should run through many tiles)
+                     ap.sd.n_tiles >= 64 * std::max<uint64_t>(1, coarse_used);
+  const uint32_t piece_tiles = (uint32_t)std::max<uint64_t>(8, ceil_div(ap.sd.n_tiles, (uint64_t)ctx->n_cus * 3));
+  const uint32_t piece_max = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, ceil_div(ceil_div(ap.sd.n_tiles, std::max<uint64_t>(1, coarse_used)), (uint64_t)piece_tiles)));
+  const uint32_t max_pieces = (uint32_t)(P1 + ap.sd.n_tiles / piece_tiles + 2);
+  const bool lines = lines_wanted && part2_lines_fit((uint32_t)p2, piece_tiles);
+  const size_t n_runs = lines ? piece_max + 1 : 2;
+  const size_t spill_small_bytes = ((size_t)3 * (n_regions + 1) + 2 * n_runs * n_regions) * 4 + 64;
   if (spill) {
-    spill_rec = Scratch(ctx, spill_capacity * 8);
-    spill_fine = Scratch(ctx, spill_capacity * 4);
-    spill_small = Scratch(ctx, ((size_t)3 * (n_regions + 1) + (size_t)4 * n_regions) * 4 + 64);
+    spill_rec = Scratch(ctx, spill_capacity * 8 + 64);
+    spill_fine = Scratch(ctx, spill_capacity * 4 + 64);
+    spill_small = Scratch(ctx, spill_small_bytes);
+    if (lines) d_pieces = Scratch(ctx, (size_t)max_pieces * sizeof(P2Piece) + (size_t)(P1 + 1) * 4 + 64);
   }
   for (int w = 0; w < 2; ++w)
     if (w == 0 || !compact)
@@ -1679,7 +1691,7 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggPar
       q2.slice_tiles = (uint32_t)std::max<uint64_t>(2, std::min<uint64_t>(32, (slice_rows / (2 * kTileRows)) * 2));
       q2.strays = (unsigned long long*)(d_small.as<uint8_t>() + 48);
       if (spill) {
-        PRISM_HIP(hipMemsetAsync(spill_small.p, 0, ((size_t)3 * (n_regions + 1) + (size_t)4 * n_regions) * 4 + 64, ctx->stream));
+        PRISM_HIP(hipMemsetAsync(spill_small.p, 0, spill_small_bytes, ctx->stream));
         q2.fine_limit = d_fine.as<uint32_t>() + 3 * (size_t)n_fine + 1;
         q2.out_capacity = region_records + spill_capacity;
         q2.spill_rec = spill_rec.as<uint64_t>();
@@ -1692,7 +1704,17 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggPar
         q2.spill_base = q2.spill_count + (n_regions + 1);
         q2.spill_cur = q2.spill_base + (n_regions + 1);
         q2.seg_base_out = q2.spill_cur + (n_regions + 1);
-        q2.seg_cnt_out = q2.seg_base_out + 2 * (size_t)n_regions;
+        q2.seg_cnt_out = q2.seg_base_out + n_runs * (size_t)n_regions;
+        if (lines) {
+          q2.lines = 1;
+          q2.piece_tiles = piece_tiles;
+          q2.piece_max = piece_max;
+          q2.max_pieces = max_pieces;
+          q2.piece_chunks = part2_piece_chunks(piece_tiles);
+          q2.pieces = d_pieces.as<P2Piece>();
+          q2.bounds = (uint32_t*)(d_pieces.as<P2Piece>() + max_pieces);
+          q2.n_pieces = (uint32_t*)(d_small.as<uint8_t>() + 128);
+        }
       }
     }
     launch_distinct_second_level(ctx, q2, direct ? &ap : nullptr);
@@ -1700,8 +1722,8 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggPar
     PRISM_HIP(hipStreamSynchronize(ctx->stream));
     collect_timings(ctx);
     if (std::getenv("PRISM_WC_DEBUG"))
-      std::fprintf(stderr, "[part2] p1 %d p2 %d compact %d fixed %d direct %d spill %d rows %llu: flags %u %u strays %llu spilled %llu\n", p1, p2,
-                   (int)compact, (int)fixed, (int)direct, (int)spill, (unsigned long long)selected, h.flags[0], h.flags[1],
+      std::fprintf(stderr, "[part2] p1 %d p2 %d compact %d fixed %d direct %d spill %d lines %d (%u tiles a piece, %u pieces a bucket) rows %llu: flags %u %u strays %llu spilled %llu\n", p1, p2,
+                   (int)compact, (int)fixed, (int)direct, (int)spill, (int)lines, piece_tiles, piece_max, (unsigned long long)selected, h.flags[0], h.flags[1],
                    (unsigned long long)h.pad[0], (unsigned long long)h.pad[1]);
     // (rows out of time order: the next run sorts by the group key first again)
     if (direct && !shard && h.pad[0] > selected / 8) plan->part2_direct.store(-1, std::memory_order_relaxed);

@@ -321,6 +321,13 @@ void launch_wc_group_by(prism_gpu_ctx* ctx, const AggParams& p, const WcParams& 
 // sorted once more, inside every coarse bucket, by a hash of the whole pair; each fine bucket
 // is then deduplicated in LDS and its pairs are counted per group straight into the outer
 // table (slot 0: pairs, slot 1: pairs whose x is not NULL) -- the set itself is never stored.
+struct P2Piece {
+  uint32_t t0, t1;     // scan tiles [t0, t1)
+  uint32_t coarse;     // the coarse bucket its rows belong to
+  uint32_t src;        // which of the bucket's pieces it is: the run it fills
+  uint32_t seg_first;  // its part of a fine bucket's region: first record and records
+  uint32_t seg_cap;
+};
 struct Part2Params {
   const uint64_t* in_lo;        // records sorted by coarse bucket
   const uint64_t* in_hi;
@@ -386,8 +393,28 @@ struct Part2Params {
   uint32_t n_regions, region_cap;
   uint32_t *spill_count, *spill_base, *spill_cur;
   uint32_t *seg_base_out, *seg_cnt_out;
+  // lines (with spill_rec): the scatter pass without tiles, sorting and barriers.  The scan tiles
+  // where the coarse bucket of the first row changes are found by bisection (rows in time order),
+  // every coarse bucket's stretch of tiles is cut into at most piece_max pieces of about
+  // piece_tiles tiles, and a workgroup takes one piece: its rows belong to ONE coarse bucket, so a
+  // staging line of 8 records in LDS per sub-bucket is all it needs, and piece j of a coarse bucket
+  // owns the j-th part of each of its fine buckets' regions -- a full line is copied out as 64
+  // contiguous, aligned bytes to a place that follows from a counter in LDS.  Lines beyond the part
+  // and rows of another coarse bucket go to the spill list.  A fine bucket then is piece_max runs of
+  // its region and one of the sorted spill list (seg_base_out / seg_cnt_out: piece_max + 1 runs).
+  uint32_t lines, piece_tiles, piece_max, max_pieces;
+  uint32_t piece_chunks;  // entries of a workgroup's table of spill chunks (part2_piece_chunks)
+  uint32_t* bounds;       // [2^p1_bits + 1] first tile of every coarse bucket's stretch
+  P2Piece* pieces;        // [max_pieces]
+  uint32_t* n_pieces;
 };
 uint32_t part2_lds_entries(bool compact);
+// Key columns of the scan whose loads the second level can request a tile ahead (0: some key is nullable, or too many).
+int part2_keys_ahead(const AggParams& p);
+// Spill chunks a piece of at most 2 * piece_tiles scan tiles can need (all of its rows spilled).
+uint32_t part2_piece_chunks(uint32_t piece_tiles);
+// Whether the scatter pass by staging lines fits LDS with these shapes.
+bool part2_lines_fit(uint32_t p2_bits, uint32_t piece_tiles);
 // Records the output arrays must hold when the fine buckets get regions of fixed size.
 uint64_t part2_fixed_capacity(uint64_t n_rows, uint32_t n_fine);
 void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q, const AggParams* scan = nullptr);

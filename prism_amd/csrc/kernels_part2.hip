@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void k_spill_count(Part2Params q) {
     const uint32_t f = in ? q.spill_fine[i] : ~0u;
     uint32_t first, len;
     spill_run(in, f, lane, first, len);
-    if (in && lane == first) atomicAdd(&q.spill_count[f], len);
+    if (in && lane == first && f != 0xffffffffu) atomicAdd(&q.spill_count[f], len);  // (all ones: an unused place of a workgroup's chunk)
   }
 }
 __global__ __launch_bounds__(256) void k_spill_place(Part2Params q, uint64_t out_offset) {
@@ -297,9 +297,9 @@ __global__ __launch_bounds__(256) void k_spill_place(Part2Params q, uint64_t out
     uint32_t first, len;
     spill_run(in, f, lane, first, len);
     uint32_t at = 0;
-    if (in && lane == first) at = atomicAdd(&q.spill_cur[f], len);
+    if (in && lane == first && f != 0xffffffffu) at = atomicAdd(&q.spill_cur[f], len);
     at = __shfl(at, (int)first, 64);
-    if (in) q.out_lo[out_offset + at + (lane - first)] = rec;
+    if (in && f != 0xffffffffu) q.out_lo[out_offset + at + (lane - first)] = rec;
   }
 }
 // A fine bucket as two runs of out_lo: what its region took, and its part of the sorted spill list.
@@ -536,6 +536,324 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
   }
 }
 
+// ---- the scatter pass by staging lines (Part2Params::lines) ------------------------------------
+
+// The coarse bucket of the first row of scan tile t (key columns without NULLs: the caller checked).
+__device__ __forceinline__ uint32_t p2_tile_coarse(const Part2Params& q, const AggParams& p, uint64_t t) {
+  const uint32_t seg = find_seg(p.sd, t);
+  const uint64_t row0 = (t - p.sd.segs[seg].tile_base) * kTileRows;
+  uint64_t hi = 0;
+  for (int k = 0; k < p.n_keys; ++k) {
+    const KeySpec& ks = p.keys[k];
+    if (!ks.word) continue;
+    const PartBytePtr base = (PartBytePtr)(uint64_t)p.cols[(uint64_t)ks.col * p.sd.n_segs + seg].values;
+    const unsigned long long raw = *(const __attribute__((address_space(1))) part_unaligned_u64*)(base + (row0 << part_width_shift(ks.width)));
+    hi |= part_field(ks, raw) << ks.bit_pos;
+  }
+  return (uint32_t)(hi >> (q.hi_bits - (int)q.p1_bits));
+}
+
+// bounds[b] = the first scan tile whose first row lies in coarse bucket b or a later one (rows in
+// time order: the coarse bucket is the top of the time key and never falls).  A wave per bound,
+// sixty-four probes a step.  Rows that are not in order only cost places in the spill list: a
+// piece sends the rows of other coarse buckets there.
+__global__ __launch_bounds__(64) void k_part2_bounds(Part2Params q, AggParams p) {
+  const uint32_t b = blockIdx.x, lane = threadIdx.x, n_coarse = 1u << q.p1_bits;
+  const uint64_t n_tiles = q.n_tiles;
+  uint64_t lo = 0, hi = n_tiles;  // the answer lies in [lo, hi]
+  if (b == 0) hi = 0;
+  if (b >= n_coarse) lo = n_tiles;
+  while (hi > lo) {
+    const uint64_t step = (hi - lo + 63) / 64;
+    const uint64_t t = lo + (uint64_t)lane * step;
+    const bool reached = t >= hi ? true : p2_tile_coarse(q, p, t) >= b;
+    const uint64_t m = __ballot(reached);
+    if (m == 0ull) {  // (no probe reached the bucket: it starts behind the last one)
+      lo = lo + 63 * step + 1;
+      if (lo > hi) lo = hi;
+      continue;
+    }
+    const uint32_t first = (uint32_t)__builtin_ctzll(m);
+    const uint64_t at = lo + (uint64_t)first * step;
+    hi = at < hi ? at : hi;
+    if (first == 0) hi = lo;
+    else lo = lo + (uint64_t)(first - 1) * step + 1;
+    if (lo > hi) lo = hi;
+  }
+  if (lane == 0) q.bounds[b] = (uint32_t)lo;
+}
+
+// The pieces: coarse bucket c's stretch of tiles, [bounds[c], bounds[c + 1]), in k = 1 .. piece_max
+// parts of about piece_tiles tiles; part j fills records [j * cap, (j + 1) * cap) of its fine
+// buckets' regions, cap = region_cap / k rounded down to whole lines.  One workgroup.
+__global__ __launch_bounds__(1024) void k_part2_pieces(Part2Params q) {
+  __shared__ uint32_t wave_tot[16];
+  __shared__ uint32_t carry;
+  const uint32_t n_coarse = 1u << q.p1_bits, tid = threadIdx.x;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t c0 = 0; c0 < n_coarse; c0 += 1024) {
+    const uint32_t c = c0 + tid;
+    uint32_t t0 = 0, t1 = 0, k = 0;
+    if (c < n_coarse) {
+      t0 = q.bounds[c];
+      t1 = q.bounds[c + 1];
+      if (t1 > t0) {
+        k = (t1 - t0 + q.piece_tiles - 1) / q.piece_tiles;
+        k = k < 1 ? 1u : (k > q.piece_max ? q.piece_max : k);
+      }
+    }
+    uint32_t incl = k;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t o = __shfl_up(incl, off, 64);
+      if ((int)(tid & 63) >= off) incl += o;
+    }
+    if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t before = carry;
+    for (uint32_t w = 0; w < (tid >> 6); ++w) before += wave_tot[w];
+    const uint32_t first = before + incl - k;
+    const bool has_region = (((uint64_t)c << q.p2_bits) < q.n_regions);
+    const uint32_t cap = k && has_region ? (q.region_cap / k) & ~7u : 0u;
+    for (uint32_t j = 0; j < k; ++j) {
+      if (first + j >= q.max_pieces) { q.flags[1] = 1u; break; }
+      P2Piece pc;
+      pc.t0 = t0 + (uint32_t)((uint64_t)(t1 - t0) * j / k);
+      pc.t1 = t0 + (uint32_t)((uint64_t)(t1 - t0) * (j + 1) / k);
+      // (a coarse bucket with far more rows than the others: its pieces would outgrow the workgroup's table of spill chunks)
+      if (pc.t1 - pc.t0 > 2 * q.piece_tiles) q.flags[1] = 1u;
+      pc.coarse = c;
+      pc.src = j;
+      pc.seg_first = j * cap;
+      pc.seg_cap = cap;
+      q.pieces[first + j] = pc;
+    }
+    __syncthreads();
+    if (tid == 1023) carry = before + incl;
+    __syncthreads();
+  }
+  if (tid == 0) *q.n_pieces = carry < q.max_pieces ? carry : q.max_pieces;
+}
+
+constexpr uint32_t kP2Stage = 8;  // records of a staging line (64 bytes)
+// The spill list is handed out to the workgroups in chunks of this many records: one addition to
+// the list's cursor per chunk (an addition per spilled line -- millions to one address, carried
+// out one after the other -- made the pass four times as long).  Inside its chunks a workgroup
+// counts in LDS; what it leaves unused of its last chunk is marked (spill_fine = all ones).
+constexpr uint32_t kP2SpillChunk = 1024;
+constexpr uint32_t kP2NoChunk = 0xffffffffu, kP2BadChunk = 0xfffffffeu;
+constexpr uint32_t kP2Recent = 4;
+constexpr size_t p2_lines_lds(uint32_t p2_bits, uint32_t chunks) {
+  return (((size_t)kP2Stage * 8 + 8 + (size_t)kP2Recent * 8) << p2_bits) + (size_t)chunks * 4;
+}
+typedef unsigned long long __attribute__((ext_vector_type(2), aligned(8))) p2_u64x2;
+typedef uint32_t __attribute__((ext_vector_type(4), aligned(4))) p2_u32x4;
+
+// A workgroup per piece.  Per sub-bucket: `fill` hands out tickets (ticket t: place t % 8 of
+// generation t / 8 of the sub-bucket's line), `prog` holds the records of the current generation
+// already in place (low half) and the generations copied out so far (high half, modulo 2^16);
+// whoever puts a generation's eighth record in place copies the line out and opens the next
+// generation.  No tile, no sort, no barrier inside the loop (the protocol of the histogram-free
+// GROUP BY's scatter pass, kernels_wc.hip).
+template <int NK>
+__global__ __launch_bounds__(kP2Block) __attribute__((amdgpu_waves_per_eu(4))) void k_part2_lines(Part2Params q, AggParams p) {
+  constexpr int R = 4;
+  extern __shared__ __align__(16) unsigned long long p2l_lds[];
+  __shared__ uint32_t n_stray;
+  if (blockIdx.x >= *q.n_pieces) return;
+  const uint32_t n_sub = 1u << q.p2_bits, tid = threadIdx.x;
+  unsigned long long* stage = p2l_lds;                                  // [n_sub][kP2Stage]
+  uint32_t* fill = (uint32_t*)(stage + (size_t)n_sub * kP2Stage);       // [n_sub]
+  uint32_t* prog = fill + n_sub;                                        // [n_sub]
+  // Records the piece has staged lately, four per sub-bucket: a row that repeats one of them is
+  // dropped where it stands -- a pair counts once however often it comes, and the pairs that come
+  // tens of thousands of times (a crawler's id in one hour) are what overflows the regions.
+  unsigned long long* recent = (unsigned long long*)(prog + n_sub);     // [n_sub][kP2Recent]
+  uint32_t* chunk = (uint32_t*)(recent + (size_t)n_sub * kP2Recent);    // [q.piece_chunks] where the piece's spill chunks start
+  __shared__ uint32_t sp_pos;                                           // records the piece has spilled
+  const uint32_t t0 = __builtin_amdgcn_readfirstlane(q.pieces[blockIdx.x].t0), t1 = __builtin_amdgcn_readfirstlane(q.pieces[blockIdx.x].t1);
+  const uint32_t coarse = __builtin_amdgcn_readfirstlane(q.pieces[blockIdx.x].coarse), src = __builtin_amdgcn_readfirstlane(q.pieces[blockIdx.x].src);
+  const uint32_t seg_first = __builtin_amdgcn_readfirstlane(q.pieces[blockIdx.x].seg_first);
+  const uint32_t seg_cap = __builtin_amdgcn_readfirstlane(q.pieces[blockIdx.x].seg_cap);
+  for (uint32_t i = tid; i < n_sub; i += kP2Block) { fill[i] = 0; prog[i] = 0; }
+  for (uint32_t i = tid; i < q.piece_chunks; i += kP2Block) chunk[i] = kP2NoChunk;
+  for (uint32_t i = tid; i < n_sub * kP2Recent; i += kP2Block) recent[i] = kP2Empty;
+  if (tid == 0) { n_stray = 0; sp_pos = 0; }
+  __syncthreads();
+  const int lo_rest = q.lo_bits - (int)q.p2_bits, hi_rest = q.hi_bits - (int)q.p1_bits;
+  const uint64_t lo_mask = (1ull << lo_rest) - 1ull, hi_mask = (1ull << hi_rest) - 1ull;
+  // record r of sub-bucket s of this piece lies at out_lo[(coarse << p2 | s) * region_cap + seg_first + r]
+  const uint64_t piece_base = ((uint64_t)coarse << q.p2_bits) * q.region_cap + seg_first;
+  // The place of the piece's spilled record number `pos` in the list (all ones: none).  Whoever
+  // holds the first record of a chunk fetches the chunk (sp_chunk) BEFORE anybody of its wave
+  // asks for a place in it; lanes of other waves wait here for the chunk's start to appear.
+  auto sp_chunk = [&](uint32_t ci) {
+    if (ci >= q.piece_chunks) { q.flags[1] = 1u; return; }
+    const unsigned long long at = atomicAdd(q.spill_cursor, (unsigned long long)kP2SpillChunk);
+    const bool fits = at + kP2SpillChunk <= q.spill_capacity;
+    if (!fits) q.flags[1] = 1u;
+    __hip_atomic_store(&chunk[ci], fits ? (uint32_t)at : kP2BadChunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  auto sp_place = [&](uint32_t pos) -> uint32_t {
+    const uint32_t ci = pos / kP2SpillChunk;
+    if (ci >= q.piece_chunks) return kP2NoChunk;
+    uint32_t base;
+    do {
+      base = __hip_atomic_load(&chunk[ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } while (base == kP2NoChunk);
+    return base == kP2BadChunk ? kP2NoChunk : base + pos % kP2SpillChunk;
+  };
+  auto spill_one = [&](uint64_t rec, uint32_t ff) {
+    if (ff >= q.n_regions) { q.flags[0] = 1u; return; }  // (a bucket the columns' statistics rule out: the result is void)
+    const uint32_t pos = atomicAdd(&sp_pos, 1u);
+    if (pos % kP2SpillChunk == 0) sp_chunk(pos / kP2SpillChunk);
+    const uint32_t at = sp_place(pos);
+    if (at != kP2NoChunk) { q.spill_rec[at] = rec; q.spill_fine[at] = ff; }
+  };
+  unsigned long long raw[NK][R];
+  uint32_t live = 0, live_next = 0, strays = 0;
+  PartCursor<NK> cur;
+  if (t0 < t1) {
+    part_cursor_init<NK, 0>(p, cur, t0);
+    part_issue<NK, 0, R>(p, cur, t0, t1, tid, raw, live_next);
+  }
+  for (uint64_t t = t0; t < t1; ++t) {
+    uint64_t rec2[2][R], key[R];
+    part_finish<2, NK, 0, R>(p, raw, rec2);
+    live = live_next;
+    if (t + 1 < t1) part_issue<NK, 0, R>(p, cur, t + 1, t1, tid, raw, live_next);
+    uint32_t bkt[R], tk[R], needw = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const uint64_t hi = rec2[1][r], lo = mixed_lo(q, rec2[0][r], hi);
+      const uint32_t c = (uint32_t)(hi >> hi_rest);
+      bkt[r] = (uint32_t)(lo >> lo_rest);
+      key[r] = ((hi & hi_mask) << lo_rest) | (lo & lo_mask);
+      tk[r] = 0;
+      if (!((live >> r) & 1u)) continue;
+      if (c == coarse) {
+        unsigned long long* seen = &recent[bkt[r] * kP2Recent + ((uint32_t)key[r] & (kP2Recent - 1))];
+        if (*seen == key[r]) continue;  // (a record is less than 2^63: never the empty entry)
+        *seen = key[r];
+        tk[r] = atomicAdd(&fill[bkt[r]], 1u);
+        needw |= 1u << r;
+      } else {
+        // a row of another coarse bucket (the tiles where the bucket changes; rows out of time order)
+        ++strays;
+        spill_one(key[r], (c << q.p2_bits) | bkt[r]);
+      }
+    }
+    for (;;) {
+      uint32_t pr[R], before[R], ok = 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) pr[r] = __hip_atomic_load(&prog[bkt[r]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t gen = tk[r] / kP2Stage, place = tk[r] % kP2Stage;
+        if (((needw >> r) & 1u) && (pr[r] >> 16) == (gen & 0xffffu)) {  // (else the line still holds the generation before)
+          ok |= 1u << r;
+          __hip_atomic_store(&stage[(size_t)bkt[r] * kP2Stage + place], (unsigned long long)key[r], __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        before[r] = 0;
+        if ((ok >> r) & 1u) before[r] = __hip_atomic_fetch_add(&prog[bkt[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      needw &= ~ok;
+      uint32_t fl = 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (((ok >> r) & 1u) && (before[r] & 0xffffu) == kP2Stage - 1) fl |= 1u << r;
+      // (the copy-out is issued once per lane and round, for the lane's first full line, and again only while some lane has another)
+      while (__ballot(fl != 0u) != 0ull) {
+        if (fl != 0u) {
+          const int r = __ffs((int)fl) - 1;
+          fl &= fl - 1u;
+          const uint32_t fb = r == 0 ? bkt[0] : r == 1 ? bkt[1] : r == 2 ? bkt[2] : bkt[3];
+          const uint32_t ft = r == 0 ? tk[0] : r == 1 ? tk[1] : r == 2 ? tk[2] : tk[3];
+          const ulonglong2* sl = (const ulonglong2*)&stage[(size_t)fb * kP2Stage];
+          asm volatile("" ::: "memory");
+          const ulonglong2 a = sl[0], b = sl[1], c = sl[2], d = sl[3];
+          asm volatile("" ::: "memory");
+          // the records are on their way to registers: the next generation may come (-8 records, +1 generation)
+          __hip_atomic_fetch_add(&prog[fb], 0x10000u - kP2Stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const uint32_t off = (ft / kP2Stage) * kP2Stage;
+          if (off + kP2Stage <= seg_cap) {
+            ulonglong2* dst = (ulonglong2*)(q.out_lo + (piece_base + (uint64_t)fb * q.region_cap + off));
+            dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = d;
+          } else {
+            // beyond the piece's part of the region: the line goes to the spill list
+            const uint32_t pos = atomicAdd(&sp_pos, kP2Stage);
+            const uint32_t c0 = pos / kP2SpillChunk, c1 = (pos + kP2Stage - 1) / kP2SpillChunk;
+            if (pos % kP2SpillChunk == 0) sp_chunk(c0);
+            if (c1 != c0) sp_chunk(c1);  // (the line holds the first record of the next chunk)
+            const uint32_t ff = (coarse << q.p2_bits) | fb;
+            if (c1 == c0) {
+              const uint32_t at = sp_place(pos);
+              if (at != kP2NoChunk) {
+                p2_u64x2* dr = (p2_u64x2*)(q.spill_rec + at);
+                dr[0] = p2_u64x2{a.x, a.y}; dr[1] = p2_u64x2{b.x, b.y}; dr[2] = p2_u64x2{c.x, c.y}; dr[3] = p2_u64x2{d.x, d.y};
+                p2_u32x4* df = (p2_u32x4*)(q.spill_fine + at);
+                df[0] = p2_u32x4{ff, ff, ff, ff}; df[1] = p2_u32x4{ff, ff, ff, ff};
+              }
+            } else {
+              const unsigned long long w[kP2Stage] = {a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
+#pragma unroll
+              for (uint32_t j = 0; j < kP2Stage; ++j) {
+                const uint32_t at = sp_place(pos + j);
+                if (at != kP2NoChunk) { q.spill_rec[at] = w[j]; q.spill_fine[at] = ff; }
+              }
+            }
+          }
+        }
+      }
+      if (__ballot(needw != 0u) == 0ull) break;
+    }
+  }
+  __syncthreads();
+  // what is left in the lines, and how many records of every fine bucket the piece's part of the region got
+  for (uint32_t b = tid; b < n_sub; b += kP2Block) {
+    const uint32_t n = fill[b], rem = n % kP2Stage, off = (n / kP2Stage) * kP2Stage;
+    const uint32_t ff = (coarse << q.p2_bits) | b;
+    uint32_t in_region = off < seg_cap ? off : seg_cap;
+    if (rem) {
+      if (off + kP2Stage <= seg_cap) {
+        unsigned long long* dst = (unsigned long long*)q.out_lo + (piece_base + (uint64_t)b * q.region_cap + off);
+        for (uint32_t j = 0; j < rem; ++j) dst[j] = stage[(size_t)b * kP2Stage + j];
+        in_region += rem;
+      } else {
+        for (uint32_t j = 0; j < rem; ++j) spill_one(stage[(size_t)b * kP2Stage + j], ff);
+      }
+    }
+    if (ff < q.n_regions) {
+      q.seg_base_out[(uint64_t)src * q.n_regions + ff] = (uint32_t)(piece_base + (uint64_t)b * q.region_cap);
+      q.seg_cnt_out[(uint64_t)src * q.n_regions + ff] = in_region;
+    }
+  }
+  if (strays) atomicAdd(&n_stray, strays);
+  __syncthreads();
+  if (tid == 0 && n_stray && q.strays) atomicAdd(q.strays, (unsigned long long)n_stray);
+  // the rest of the piece's last spill chunk holds no records
+  const uint32_t spilled = sp_pos;
+  if (spilled % kP2SpillChunk != 0 && spilled / kP2SpillChunk < q.piece_chunks) {
+    const uint32_t base = chunk[spilled / kP2SpillChunk];
+    if (base != kP2NoChunk && base != kP2BadChunk)
+      for (uint32_t i = spilled % kP2SpillChunk + tid; i < kP2SpillChunk; i += kP2Block) q.spill_fine[base + i] = 0xffffffffu;
+  }
+}
+
+// (lines) the spill list's part of every fine bucket as its last run
+__global__ __launch_bounds__(256) void k_spill_runs_lines(Part2Params q, uint64_t out_offset) {
+  const uint32_t f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= q.n_regions) return;
+  q.seg_base_out[(uint64_t)q.piece_max * q.n_regions + f] = (uint32_t)(out_offset + q.spill_base[f]);
+  q.seg_cnt_out[(uint64_t)q.piece_max * q.n_regions + f] = q.spill_count[f];
+}
+
 // One past the last record of fine bucket f: where the next bucket starts, or (regions of fixed
 // size) as far as the scatter pass' cursor got.
 __device__ __forceinline__ uint32_t p2_bucket_end(const Part2Params& q, uint32_t f) {
@@ -698,35 +1016,59 @@ __global__ __launch_bounds__(kP2AggBlock) void k_part2_agg_compact(Part2Params q
   if (tid == 0) emit_n = 0;
   constexpr uint32_t kBatch = 8;  // rows a thread requests together
   const uint32_t n_src = MODE == kP2Merge ? q.n_src : 1u;
+  // kP2Merge: the bucket's runs (at most 64) are taken as ONE sequence of records -- record i lies
+  // in the run r with run_off[r] <= i < run_off[r + 1], at run_base[r] + i - run_off[r] -- so that
+  // a batch of loads is full whatever the runs' lengths (run by run, six runs of a thousand records
+  // left three quarters of every batch of 8 x 512 empty).  The first wave keeps the runs of the
+  // workgroup's next bucket in registers (lane = run), fetched while this bucket is counted.
+  __shared__ uint32_t run_off[65], run_base[64];
+  uint32_t nx_base = 0, nx_cnt = 0;
+  auto fetch_runs = [&](uint32_t f2) {
+    nx_base = 0;
+    nx_cnt = 0;
+    if (MODE == kP2Merge && tid < n_src && f2 < n_fine) {
+      nx_base = q.seg_base[(uint64_t)tid * n_fine + f2];
+      nx_cnt = q.seg_cnt[(uint64_t)tid * n_fine + f2];
+    }
+  };
+  fetch_runs(blockIdx.x);
   for (uint32_t f = blockIdx.x; f < n_fine; f += gridDim.x) {
     __syncthreads();
-    // the bucket's runs of records: one, or (kP2Merge) one per sending rank
-    auto run_of = [&](uint32_t src, uint32_t& r0, uint32_t& r1) {
-      if (MODE == kP2Merge) {
-        r0 = q.seg_base[(uint64_t)src * n_fine + f];
-        r1 = r0 + q.seg_cnt[(uint64_t)src * n_fine + f];
-      } else {
-        r0 = q.fine_base[f];
-        r1 = p2_bucket_end(q, f);
+    uint32_t b0 = 0, n = 0;  // (other modes: the bucket is records [b0, b0 + n))
+    if (MODE == kP2Merge) {
+      if (tid < 64) {
+        uint32_t incl = nx_cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const uint32_t o = __shfl_up(incl, off, 64);
+          if ((int)tid >= off) incl += o;
+        }
+        if (tid < n_src) { run_base[tid] = nx_base; run_off[tid] = incl - nx_cnt; }
+        if (tid == 63) run_off[n_src] = incl;
       }
-    };
-    uint32_t n = 0;
-    for (uint32_t src = 0; src < n_src; ++src) {
-      uint32_t r0, r1;
-      run_of(src, r0, r1);
-      n += r1 - r0;
+      fetch_runs(f + gridDim.x);
+      __syncthreads();
+      n = run_off[n_src];
+    } else {
+      b0 = q.fine_base[f];
+      n = p2_bucket_end(q, f) - b0;
     }
     if (n == 0) {
       if (MODE == kP2Emit && tid == 0) q.fine_count[f] = 0;
       continue;
     }
-    uint32_t b0, b1;  // the first run: its leading rows stay in registers for all the passes
-    run_of(0, b0, b1);
-    uint64_t b[kBatch];
+    // where record i of the bucket lies in q.out_lo (i < n)
+    auto at_of = [&](uint32_t i) -> uint32_t {
+      if (MODE != kP2Merge) return b0 + i;
+      uint32_t r = 0;
+      while (r + 1 < n_src && i >= run_off[r + 1]) ++r;
+      return run_base[r] + (i - run_off[r]);
+    };
+    uint64_t b[kBatch];  // the leading rows stay in registers for all the passes
 #pragma unroll
     for (uint32_t j = 0; j < kBatch; ++j) {
-      const uint32_t i = b0 + tid + j * kP2AggBlock, ic = i < b1 ? i : b0;
-      b[j] = b1 > b0 ? __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.out_lo + ic)) : 0ull;
+      const uint32_t i = tid + j * kP2AggBlock;
+      b[j] = __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.out_lo + at_of(i < n ? i : 0u)));
     }
     // A bucket of more rows than the set is sure to take (n > S / 2) is first tried in one go
     // all the same: what makes a bucket large is, as a rule, one very frequent pair, and rows
@@ -801,25 +1143,17 @@ __global__ __launch_bounds__(kP2AggBlock) void k_part2_agg_compact(Part2Params q
         for (uint32_t i = tid; i < Sb; i += kP2AggBlock) keys[i] = kP2Empty;
         if (tid == 0) crowded = 0;
         __syncthreads();
-        for (uint32_t src = 0; src < n_src; ++src) {
-          uint32_t r0, r1;
-          run_of(src, r0, r1);
-          uint32_t base = r0;
-          if (src == 0) {
-            take_batch(b, r0, r1, pass);
-            base = r0 + kBatch * kP2AggBlock;
-          }
-          // (what lies beyond the first rows is fetched once per pass, again a batch at a time so
-          // that a thread waits for memory once per batch)
-          for (; base < r1; base += kBatch * kP2AggBlock) {
-            uint64_t more[kBatch];
+        take_batch(b, 0, n, pass);
+        // (what lies beyond the first rows is fetched once per pass, again a batch at a time so
+        // that a thread waits for memory once per batch)
+        for (uint32_t base = kBatch * kP2AggBlock; base < n; base += kBatch * kP2AggBlock) {
+          uint64_t more[kBatch];
 #pragma unroll
-            for (uint32_t j = 0; j < kBatch; ++j) {
-              const uint32_t i = base + tid + j * kP2AggBlock, ic = i < r1 ? i : r0;
-              more[j] = __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.out_lo + ic));
-            }
-            take_batch(more, base, r1, pass);
+          for (uint32_t j = 0; j < kBatch; ++j) {
+            const uint32_t i = base + tid + j * kP2AggBlock;
+            more[j] = __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.out_lo + at_of(i < n ? i : 0u)));
           }
+          take_batch(more, base, n, pass);
         }
       }
       __syncthreads();
@@ -974,6 +1308,12 @@ uint32_t part2_lds_entries(bool compact) {
   return (uint32_t)((kP2LdsBytes / kP2AggPerCu - kP2Groups * 16 - 256) / (compact ? 8 : 16)) & ~63u;
 }
 
+int part2_keys_ahead(const AggParams& p) { return part_keys_ahead(p); }
+uint32_t part2_piece_chunks(uint32_t piece_tiles) { return (uint32_t)(2ull * piece_tiles * kTileRows / kP2SpillChunk + 4); }
+bool part2_lines_fit(uint32_t p2_bits, uint32_t piece_tiles) {
+  return p2_lines_lds(p2_bits, part2_piece_chunks(piece_tiles)) <= kP2LdsBytes;
+}
+
 void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q, const AggParams* scan) {
   if (q.n_rows == 0) return;
   if (q.direct && (!scan || !q.compact || (q.fine_limit && !q.spill_rec) || (q.emit_out && q.spill_rec) || q.n_tiles == 0 || q.slice_tiles == 0 || (q.slice_tiles & 1u)))
@@ -1021,7 +1361,20 @@ void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q, cons
     k_part2_scan<<<dim3(1), dim3(1024), 0, ctx->stream>>>(q, n_fine);
     PRISM_HIP(hipGetLastError());
   }
-  {
+  if (q.lines) {
+    if (!q.spill_rec || !q.direct || (ahead != 2 && ahead != 3) || !q.bounds || !q.pieces || !q.n_pieces || q.piece_tiles == 0 || q.piece_max == 0 ||
+        q.piece_max > 63 || q.max_pieces == 0 || q.n_tiles >= (1ull << 32))
+      fail(PRISM_GPU_EINTERNAL, "bad shape for the scatter pass by staging lines");
+    KernelTimer timer(ctx, "part2_scatter", q.n_rows * 24, true);
+    k_part2_bounds<<<dim3((1u << q.p1_bits) + 1), dim3(64), 0, ctx->stream>>>(q, ap);
+    k_part2_pieces<<<dim3(1), dim3(1024), 0, ctx->stream>>>(q);
+    const size_t lds = p2_lines_lds(q.p2_bits, q.piece_chunks);
+    if (q.piece_chunks < 2ull * q.piece_tiles * kTileRows / kP2SpillChunk + 4 || lds > kP2LdsBytes) fail(PRISM_GPU_EINTERNAL, "bad spill chunk table for the scatter pass by staging lines");
+    auto kernel = ahead == 3 ? k_part2_lines<3> : k_part2_lines<2>;
+    PRISM_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    kernel<<<dim3(q.max_pieces), dim3(kP2Block), lds, ctx->stream>>>(q, ap);
+    PRISM_HIP(hipGetLastError());
+  } else {
     KernelTimer timer(ctx, "part2_scatter", q.n_rows * (q.compact ? 24 : 32), true);
     // (the columns' form can run two workgroups of 512 threads a CU, option "part2_half_blocks"; measured
     // slower at C5, 13.5-14.4 against 13.1-13.2 ms, and shorter runs spill more: off by default)
@@ -1049,11 +1402,12 @@ void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q, cons
       sc.fine_cursor = q.spill_cur;
       k_part2_scan<<<dim3(1), dim3(1024), 0, ctx->stream>>>(sc, q.n_regions);
       k_spill_place<<<dim3(grid), dim3(256), 0, ctx->stream>>>(q, out_offset);
-      k_spill_runs<<<dim3((uint32_t)ceil_div(q.n_regions, 256)), dim3(256), 0, ctx->stream>>>(q, out_offset);
+      if (q.lines) k_spill_runs_lines<<<dim3((uint32_t)ceil_div(q.n_regions, 256)), dim3(256), 0, ctx->stream>>>(q, out_offset);
+      else k_spill_runs<<<dim3((uint32_t)ceil_div(q.n_regions, 256)), dim3(256), 0, ctx->stream>>>(q, out_offset);
       PRISM_HIP(hipGetLastError());
     }
     Part2Params m = q;
-    m.n_src = 2;
+    m.n_src = q.lines ? q.piece_max + 1 : 2;
     m.world = 1;
     m.rank = 0;
     m.seg_base = q.seg_base_out;
@@ -1107,7 +1461,7 @@ void launch_shard_runs(prism_gpu_ctx* ctx, const unsigned long long* recv_counts
 }
 
 void launch_distinct_merge(prism_gpu_ctx* ctx, const Part2Params& q, uint32_t n_own) {
-  if (!q.compact || q.n_src == 0 || !q.seg_base || !q.seg_cnt || q.world == 0 || q.rank >= q.world)
+  if (!q.compact || q.n_src == 0 || q.n_src > 64 || !q.seg_base || !q.seg_cnt || q.world == 0 || q.rank >= q.world)
     fail(PRISM_GPU_EINTERNAL, "bad shape for the merge of distinct records");
   if (q.lds_entries > part2_lds_entries(true)) fail(PRISM_GPU_EINTERNAL, "the pair table exceeds LDS");
   if (n_own == 0) return;

@@ -27,6 +27,7 @@ void copy_options(prism_gpu_ctx* c, prism_gpu_ctx* parent) {
   c->part_half_blocks.store(parent->part_half_blocks.load());
   c->part_wc.store(parent->part_wc.load());
   c->part_wc_leading.store(parent->part_wc_leading.load());
+  c->part2_lines.store(parent->part2_lines.load());
   c->part2_fixed.store(parent->part2_fixed.load());
   c->part2_direct.store(parent->part2_direct.load());
   c->part2_half_blocks.store(parent->part2_half_blocks.load());

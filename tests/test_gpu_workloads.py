@@ -389,7 +389,9 @@ def test_large_c5_same_counts_on_every_route(oracle):
         base, ran = run(wl.query)
         assert "part2_agg" in ran
         base = sort(base)
-        for name, value in (("part2_compact", 0), ("part_half_blocks", 0)):
+        # (part2_lines: the one-level scatter by staging lines, the default here -- rows in time order, a time
+        # bucket runs through hundreds of tiles -- against the tile-by-tile one; part2_direct: against two levels)
+        for name, value in (("part2_compact", 0), ("part_half_blocks", 0), ("part2_lines", 0), ("part2_direct", 0)):
             ctx.set_option(name, value)
             other, ran = run(wl.query)
             ctx.set_option(name, 1)
