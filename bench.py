@@ -85,7 +85,7 @@ def stream_feed(args) -> int:
 
 DOMINANT = {"C1": "filter_count", "C2": "group_by", "C3": "group_by", "C4": "like_contains", "C4G": "like_contains", "C5": "group_by"}
 SYMBOLS = {"group_by": ("k_group_by_stream", "k_part_agg", "k_part_scatter", "k_part_hist", "k_part_offsets",
-                        "k_part_plan", "k_part2_hist", "k_part2_scan", "k_part2_scatter", "k_part2_agg", "k_part2_agg_compact",
+                        "k_part_plan", "k_part2_hist", "k_part2_scan", "k_part2_scatter", "k_part2_lines", "k_part2_bounds", "k_part2_pieces", "k_spill_runs_lines", "k_part2_agg", "k_part2_agg_compact",
                         "k_group_by_wide", "k_group_by", "k_wc_sample", "k_wc_build", "k_wc_scatter", "k_wc_agg", "k_part2_layout",
                         "k_part2_hist_direct", "k_part2_layout_uniform", "k_spill_count", "k_spill_place", "k_spill_runs"),
            "filter_count": ("k_cmp_leaf",), "like_contains": ("k_contains_find", "k_contains_mark")}

@@ -225,7 +225,9 @@ void prism_gpu_ctx_free(prism_gpu_ctx* ctx);
  *   "part2_lines"    0: that one-level form sorts every tile of rows by fine bucket in LDS and writes the runs;
  *                    1 (default): a workgroup takes a stretch of rows of ONE time bucket (found by bisection),
  *                    keeps a staging line of 8 records per fine bucket in LDS and copies full lines out as 64
- *                    aligned bytes into its own part of the bucket's region (no barrier, no partial cache lines)
+ *                    aligned bytes into its own part of the bucket's region (no barrier, no partial cache lines),
+ *                    when a time bucket runs through 64 scan tiles and more and there are 1.5 such stretches per CU;
+ *                    2: whenever the plan's shape allows it (tests)
  *   "part2_half_blocks" 1: the scatter pass of that one-level form runs two workgroups of 512 threads per CU
  *                    (default 0: one of 1024, which measured faster)
  *   "part2_compact"  0: COUNT(DISTINCT) partitioned twice always keeps two-word records at the

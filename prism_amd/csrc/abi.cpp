@@ -355,7 +355,7 @@ int prism_gpu_set_option(prism_gpu_ctx* ctx, const char* name, int64_t value) {
     if (n == "part_min_rows") { require(value >= 0, "part_min_rows must not be negative"); ctx->part_min_rows.store((uint64_t)value); }
     else if (n == "part_force") ctx->part_force.store(value != 0 ? 1 : 0);
     else if (n == "part_wc") ctx->part_wc.store(value != 0 ? 1 : 0);
-    else if (n == "part2_lines") ctx->part2_lines.store(value != 0 ? 1 : 0);
+    else if (n == "part2_lines") { require(value >= 0 && value <= 2, "part2_lines must be 0, 1 or 2"); ctx->part2_lines.store((int)value); }
     else if (n == "part_wc_leading") ctx->part_wc_leading.store(value != 0 ? 1 : 0);
     else if (n == "part_wc_min_rows") { require(value >= 0, "part_wc_min_rows must not be negative"); ctx->part_wc_min_rows.store((uint64_t)value); }
     else if (n == "part2_fixed") ctx->part2_fixed.store(value != 0 ? 1 : 0);

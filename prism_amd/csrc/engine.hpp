@@ -153,6 +153,7 @@ struct prism_gpu_plan {
   // rows that repeat a pair need no entry of the LDS sets, so fine buckets may hold more rows
   std::atomic<uint32_t> distinct_pairs_per_1024{0};
   std::atomic<int> part2_fixed{0};  // -1: a fine bucket of this plan's data outgrew its fixed region: the second level keeps its histogram
+  std::atomic<int> part2_lines{0};  // -1: a time bucket of this plan's data held far more rows than the others: the one-level scatter goes tile by tile
   std::atomic<int> part2_direct{0};  // -1: this plan's rows did not arrive in time order: COUNT(DISTINCT) partitions them by the group key first
 };
 

@@ -1622,14 +1622,19 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggPar
   Scratch spill_rec, spill_fine, spill_small, d_pieces;
   // (the scatter pass by staging lines: a workgroup per piece of a coarse bucket's stretch of tiles; about three pieces a CU)
   const int ahead_keys = part2_keys_ahead(ap);
-  const bool lines_wanted = spill && ctx->part2_lines.load(std::memory_order_relaxed) != 0 && (ahead_keys == 2 || ahead_keys == 3) && ap.sd.n_tiles < (1ull << 32) &&
-                     // (the rows of the tiles where the coarse bucket changes take the spill list: a coarse bucket should run through many tiles)
-                     ap.sd.n_tiles >= 64 * std::max<uint64_t>(1, coarse_used);
-  const uint32_t piece_tiles = (uint32_t)std::max<uint64_t>(8, ceil_div(ap.sd.n_tiles, (uint64_t)ctx->n_cus * 3));
-  const uint32_t piece_max = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, ceil_div(ceil_div(ap.sd.n_tiles, std::max<uint64_t>(1, coarse_used)), (uint64_t)piece_tiles)));
+  // A coarse bucket is cut into at most 16 pieces (its fine buckets then are 17 runs for the last pass), of at
+  // least a third of a CU's share of the tiles each; with fewer pieces than 1.5 a CU the tile-by-tile pass stays.
+  const uint64_t tiles_per_coarse = ceil_div(ap.sd.n_tiles, std::max<uint64_t>(1, coarse_used));
+  const uint32_t piece_tiles = (uint32_t)std::max<uint64_t>({8, ceil_div(ap.sd.n_tiles, (uint64_t)ctx->n_cus * 3), ceil_div(tiles_per_coarse, 16)});
+  const uint32_t piece_max = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, ceil_div(tiles_per_coarse, (uint64_t)piece_tiles)));
   const uint32_t max_pieces = (uint32_t)(P1 + ap.sd.n_tiles / piece_tiles + 2);
-  const bool lines = lines_wanted && part2_lines_fit((uint32_t)p2, piece_tiles);
-  const size_t n_runs = lines ? piece_max + 1 : 2;
+  bool lines = spill && ctx->part2_lines.load(std::memory_order_relaxed) != 0 && plan->part2_lines.load(std::memory_order_relaxed) >= 0 &&
+               (ahead_keys == 2 || ahead_keys == 3) && ap.sd.n_tiles < (1ull << 32) &&
+               // (the rows of the tiles where the coarse bucket changes take the spill list: a coarse bucket should run through many tiles)
+               ((ap.sd.n_tiles >= 64 * std::max<uint64_t>(1, coarse_used) && 2 * (ap.sd.n_tiles / piece_tiles) >= 3 * (uint64_t)ctx->n_cus) ||
+                ctx->part2_lines.load(std::memory_order_relaxed) == 2) &&
+               part2_lines_fit((uint32_t)p2, piece_tiles);
+  const size_t n_runs = lines ? piece_max + 1 : 2;  // (sizes the arrays; a run without the lines uses two)
   const size_t spill_small_bytes = ((size_t)3 * (n_regions + 1) + 2 * n_runs * n_regions) * 4 + 64;
   if (spill) {
     spill_rec = Scratch(ctx, spill_capacity * 8 + 64);
@@ -1641,8 +1646,8 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggPar
     if (w == 0 || !compact)
       rec2[w] = Scratch(ctx, std::max<uint64_t>(fixed ? fixed_capacity : selected, spill ? region_records + spill_capacity : 0) * 8 + 256);
   Scratch d_fine(ctx, (size_t)n_fine * 16 + 64);
-  struct { uint32_t flags[2]; uint64_t pad[2]; unsigned long long pairs[8]; } h{};
-  static_assert(sizeof(h) == 88, "layout of the small block from offset 40 on");
+  struct { uint32_t flags[2]; uint64_t pad[2]; unsigned long long pairs[8]; uint32_t n_pieces, pieces_too_long; unsigned long long dropped; } h{};
+  static_assert(sizeof(h) == 104, "layout of the small block from offset 40 on");
   for (;;) {
     PRISM_HIP(hipMemsetAsync(d_fine.p, 0, (size_t)n_fine * 4, ctx->stream));
     PRISM_HIP(hipMemsetAsync(d_small.as<uint8_t>() + 32, 0, 224, ctx->stream));
@@ -1704,7 +1709,7 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggPar
         q2.spill_base = q2.spill_count + (n_regions + 1);
         q2.spill_cur = q2.spill_base + (n_regions + 1);
         q2.seg_base_out = q2.spill_cur + (n_regions + 1);
-        q2.seg_cnt_out = q2.seg_base_out + n_runs * (size_t)n_regions;
+        q2.seg_cnt_out = q2.seg_base_out + (lines ? piece_max + 1 : 2) * (size_t)n_regions;
         if (lines) {
           q2.lines = 1;
           q2.piece_tiles = piece_tiles;
@@ -1714,6 +1719,8 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggPar
           q2.pieces = d_pieces.as<P2Piece>();
           q2.bounds = (uint32_t*)(d_pieces.as<P2Piece>() + max_pieces);
           q2.n_pieces = (uint32_t*)(d_small.as<uint8_t>() + 128);
+          q2.dropped = (unsigned long long*)(d_small.as<uint8_t>() + 136);
+          q2.pieces_too_long = q2.n_pieces + 1;
         }
       }
     }
@@ -1722,11 +1729,17 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggPar
     PRISM_HIP(hipStreamSynchronize(ctx->stream));
     collect_timings(ctx);
     if (std::getenv("PRISM_WC_DEBUG"))
-      std::fprintf(stderr, "[part2] p1 %d p2 %d compact %d fixed %d direct %d spill %d lines %d (%u tiles a piece, %u pieces a bucket) rows %llu: flags %u %u strays %llu spilled %llu\n", p1, p2,
+      std::fprintf(stderr, "[part2] p1 %d p2 %d compact %d fixed %d direct %d spill %d lines %d (%u tiles a piece, %u pieces a bucket) rows %llu: flags %u %u strays %llu spilled %llu pieces %u dropped %llu\n", p1, p2,
                    (int)compact, (int)fixed, (int)direct, (int)spill, (int)lines, piece_tiles, piece_max, (unsigned long long)selected, h.flags[0], h.flags[1],
-                   (unsigned long long)h.pad[0], (unsigned long long)h.pad[1]);
+                   (unsigned long long)h.pad[0], (unsigned long long)h.pad[1], h.n_pieces, h.dropped);
     // (rows out of time order: the next run sorts by the group key first again)
     if (direct && !shard && h.pad[0] > selected / 8) plan->part2_direct.store(-1, std::memory_order_relaxed);
+    if (lines && h.pieces_too_long != 0) {
+      // a time bucket with far more rows than the others: this plan scatters tile by tile from now on
+      plan->part2_lines.store(-1, std::memory_order_relaxed);
+      lines = false;
+      continue;
+    }
     if (spill && h.flags[1] != 0) {
       // the spill list ran over (few distinct pairs that repeat a great deal): exact places from a histogram from now on
       plan->part2_fixed.store(-1, std::memory_order_relaxed);

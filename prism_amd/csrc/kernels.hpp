@@ -407,6 +407,8 @@ struct Part2Params {
   uint32_t* bounds;       // [2^p1_bits + 1] first tile of every coarse bucket's stretch
   P2Piece* pieces;        // [max_pieces]
   uint32_t* n_pieces;
+  uint32_t* pieces_too_long;    // set when a piece would pass 2 * piece_tiles tiles (no piece is made then: the caller scatters another way)
+  unsigned long long* dropped;  // rows dropped because they repeated a recently staged record (statistics)
 };
 uint32_t part2_lds_entries(bool compact);
 // Key columns of the scan whose loads the second level can request a tile ahead (0: some key is nullable, or too many).

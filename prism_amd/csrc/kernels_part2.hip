@@ -622,7 +622,7 @@ __global__ __launch_bounds__(1024) void k_part2_pieces(Part2Params q) {
       pc.t0 = t0 + (uint32_t)((uint64_t)(t1 - t0) * j / k);
       pc.t1 = t0 + (uint32_t)((uint64_t)(t1 - t0) * (j + 1) / k);
       // (a coarse bucket with far more rows than the others: its pieces would outgrow the workgroup's table of spill chunks)
-      if (pc.t1 - pc.t0 > 2 * q.piece_tiles) q.flags[1] = 1u;
+      if (pc.t1 - pc.t0 > 2 * q.piece_tiles) *q.pieces_too_long = 1u;
       pc.coarse = c;
       pc.src = j;
       pc.seg_first = j * cap;
@@ -633,7 +633,8 @@ __global__ __launch_bounds__(1024) void k_part2_pieces(Part2Params q) {
     if (tid == 1023) carry = before + incl;
     __syncthreads();
   }
-  if (tid == 0) *q.n_pieces = carry < q.max_pieces ? carry : q.max_pieces;
+  __syncthreads();
+  if (tid == 0) *q.n_pieces = *q.pieces_too_long ? 0u : (carry < q.max_pieces ? carry : q.max_pieces);
 }
 
 constexpr uint32_t kP2Stage = 8;  // records of a staging line (64 bytes)
@@ -643,7 +644,7 @@ constexpr uint32_t kP2Stage = 8;  // records of a staging line (64 bytes)
 // counts in LDS; what it leaves unused of its last chunk is marked (spill_fine = all ones).
 constexpr uint32_t kP2SpillChunk = 1024;
 constexpr uint32_t kP2NoChunk = 0xffffffffu, kP2BadChunk = 0xfffffffeu;
-constexpr uint32_t kP2Recent = 4;
+constexpr uint32_t kP2Recent = 8;
 constexpr size_t p2_lines_lds(uint32_t p2_bits, uint32_t chunks) {
   return (((size_t)kP2Stage * 8 + 8 + (size_t)kP2Recent * 8) << p2_bits) + (size_t)chunks * 4;
 }
@@ -712,7 +713,7 @@ __global__ __launch_bounds__(kP2Block) __attribute__((amdgpu_waves_per_eu(4))) v
     if (at != kP2NoChunk) { q.spill_rec[at] = rec; q.spill_fine[at] = ff; }
   };
   unsigned long long raw[NK][R];
-  uint32_t live = 0, live_next = 0, strays = 0;
+  uint32_t live = 0, live_next = 0, strays = 0, drops = 0;
   PartCursor<NK> cur;
   if (t0 < t1) {
     part_cursor_init<NK, 0>(p, cur, t0);
@@ -734,7 +735,7 @@ __global__ __launch_bounds__(kP2Block) __attribute__((amdgpu_waves_per_eu(4))) v
       if (!((live >> r) & 1u)) continue;
       if (c == coarse) {
         unsigned long long* seen = &recent[bkt[r] * kP2Recent + ((uint32_t)key[r] & (kP2Recent - 1))];
-        if (*seen == key[r]) continue;  // (a record is less than 2^63: never the empty entry)
+        if (*seen == key[r]) { ++drops; continue; }  // (a record is less than 2^63: never the empty entry)
         *seen = key[r];
         tk[r] = atomicAdd(&fill[bkt[r]], 1u);
         needw |= 1u << r;
@@ -835,6 +836,10 @@ __global__ __launch_bounds__(kP2Block) __attribute__((amdgpu_waves_per_eu(4))) v
     }
   }
   if (strays) atomicAdd(&n_stray, strays);
+  {
+    const unsigned long long wave_drops = wave_sum_u64(drops);
+    if ((tid & 63u) == 0 && wave_drops && q.dropped) atomicAdd(q.dropped, wave_drops);
+  }
   __syncthreads();
   if (tid == 0 && n_stray && q.strays) atomicAdd(q.strays, (unsigned long long)n_stray);
   // the rest of the piece's last spill chunk holds no records
@@ -1058,17 +1063,18 @@ __global__ __launch_bounds__(kP2AggBlock) void k_part2_agg_compact(Part2Params q
       continue;
     }
     // where record i of the bucket lies in q.out_lo (i < n)
-    auto at_of = [&](uint32_t i) -> uint32_t {
+    // (a thread asks for rising i: `r`, the run of its last record, is where the search goes on)
+    auto at_of = [&](uint32_t i, uint32_t& r) -> uint32_t {
       if (MODE != kP2Merge) return b0 + i;
-      uint32_t r = 0;
       while (r + 1 < n_src && i >= run_off[r + 1]) ++r;
       return run_base[r] + (i - run_off[r]);
     };
     uint64_t b[kBatch];  // the leading rows stay in registers for all the passes
+    uint32_t run_first = 0;
 #pragma unroll
     for (uint32_t j = 0; j < kBatch; ++j) {
       const uint32_t i = tid + j * kP2AggBlock;
-      b[j] = __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.out_lo + at_of(i < n ? i : 0u)));
+      b[j] = __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.out_lo + at_of(i < n ? i : n - 1, run_first)));
     }
     // A bucket of more rows than the set is sure to take (n > S / 2) is first tried in one go
     // all the same: what makes a bucket large is, as a rule, one very frequent pair, and rows
@@ -1146,12 +1152,13 @@ __global__ __launch_bounds__(kP2AggBlock) void k_part2_agg_compact(Part2Params q
         take_batch(b, 0, n, pass);
         // (what lies beyond the first rows is fetched once per pass, again a batch at a time so
         // that a thread waits for memory once per batch)
+        uint32_t run_more = run_first;
         for (uint32_t base = kBatch * kP2AggBlock; base < n; base += kBatch * kP2AggBlock) {
           uint64_t more[kBatch];
 #pragma unroll
           for (uint32_t j = 0; j < kBatch; ++j) {
             const uint32_t i = base + tid + j * kP2AggBlock;
-            more[j] = __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.out_lo + at_of(i < n ? i : 0u)));
+            more[j] = __builtin_nontemporal_load((P2WordPtr)(uint64_t)(q.out_lo + at_of(i < n ? i : n - 1, run_more)));
           }
           take_batch(more, base, n, pass);
         }
@@ -1362,12 +1369,16 @@ void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q, cons
     PRISM_HIP(hipGetLastError());
   }
   if (q.lines) {
-    if (!q.spill_rec || !q.direct || (ahead != 2 && ahead != 3) || !q.bounds || !q.pieces || !q.n_pieces || q.piece_tiles == 0 || q.piece_max == 0 ||
+    if (!q.spill_rec || !q.direct || (ahead != 2 && ahead != 3) || !q.bounds || !q.pieces || !q.n_pieces || !q.pieces_too_long || q.piece_tiles == 0 || q.piece_max == 0 ||
         q.piece_max > 63 || q.max_pieces == 0 || q.n_tiles >= (1ull << 32))
       fail(PRISM_GPU_EINTERNAL, "bad shape for the scatter pass by staging lines");
+    {
+      KernelTimer timer(ctx, "part2_pieces", 0, true);
+      k_part2_bounds<<<dim3((1u << q.p1_bits) + 1), dim3(64), 0, ctx->stream>>>(q, ap);
+      k_part2_pieces<<<dim3(1), dim3(1024), 0, ctx->stream>>>(q);
+      PRISM_HIP(hipGetLastError());
+    }
     KernelTimer timer(ctx, "part2_scatter", q.n_rows * 24, true);
-    k_part2_bounds<<<dim3((1u << q.p1_bits) + 1), dim3(64), 0, ctx->stream>>>(q, ap);
-    k_part2_pieces<<<dim3(1), dim3(1024), 0, ctx->stream>>>(q);
     const size_t lds = p2_lines_lds(q.p2_bits, q.piece_chunks);
     if (q.piece_chunks < 2ull * q.piece_tiles * kTileRows / kP2SpillChunk + 4 || lds > kP2LdsBytes) fail(PRISM_GPU_EINTERNAL, "bad spill chunk table for the scatter pass by staging lines");
     auto kernel = ahead == 3 ? k_part2_lines<3> : k_part2_lines<2>;

@@ -318,6 +318,59 @@ def test_count_distinct_over_rows_out_of_time_order(part_ctx, oracle):
         g.close()
 
 
+def test_count_distinct_scatter_by_staging_lines(part_ctx, oracle):
+    """Rows in time order whose hours run through hundreds of scan tiles each: the one-level
+    scatter takes a stretch of rows of one hour per workgroup (the hours' first tiles found by
+    bisection) and copies full staging lines into the piece's part of the fine buckets' regions.
+    Checked against the oracle and against the tile-by-tile scatter: in order; with some rows far
+    from their place (they take the spill list); with a crawler's id in a third of the rows
+    (dropped as repeats of a recently staged record); and with nearly all rows in one hour (the
+    pieces would be too long: exact places from a histogram instead)."""
+    import numpy as np
+    import pyarrow as pa
+    from prism_amd.engine import Plan, Table
+
+    rng = np.random.default_rng(31)
+    n, hours = 2_400_000, 5
+    q = QueryPlan([count_distinct("user")], keys=[date_bin(3_600_000, "ts"), "svc"])
+
+    def table(ts, heavy=0.0):
+        user = rng.integers(0, 400_000, n).astype(np.int64) * (2**62 // 400_000) - 2**61  # (62-bit ids: the pair takes two words)
+        if heavy:
+            user[rng.random(n) < heavy] = 12345 * (2**62 // 400_000) - 2**61
+        return pa.table({"ts": pa.array(1_700_000_000_000 + ts, pa.timestamp("ms")),
+                         "svc": pa.array(rng.integers(0, 9, n).astype(np.int32)), "user": pa.array(user)})
+
+    even = np.sort(rng.integers(0, hours * 3_600_000, n))
+    astray = even.copy()
+    far = rng.random(n) < 0.03
+    astray[far] = rng.integers(0, hours * 3_600_000, int(far.sum()))
+    uneven = np.sort(np.where(rng.random(n) < 0.97, rng.integers(0, 3_600_000, n), rng.integers(0, hours * 3_600_000, n)))
+    for name, t, lines_expected in [("in order", table(even), True), ("astray", table(astray), True),
+                                    ("crawler", table(even, heavy=0.35), True), ("one long hour", table(uneven), None)]:
+        want = oracle.execute(t, q)
+        g = Table(part_ctx, t.schema)
+        g.append_table(t, 4)
+        try:
+            for lines in (2, 0):  # (2: also for tables of a few hundred tiles)
+                part_ctx.set_option("part2_lines", lines)
+                plan = Plan(part_ctx, t.schema, q)
+                try:
+                    part_ctx.reset_stats()
+                    got = [plan.execute(g), plan.execute(g)]
+                    ran = _kernels(part_ctx)
+                finally:
+                    plan.close()
+                for r in got:
+                    assert_tables_match(r, want, 2)
+                assert "part2_scatter" in ran and "part_scatter" not in ran, (name, lines, ran)
+                if lines_expected is not None:
+                    assert ("part2_pieces" in ran) == (lines == 2), (name, lines, ran)
+        finally:
+            part_ctx.set_option("part2_lines", 1)
+            g.close()
+
+
 def test_count_distinct_of_one_dominant_group(part_ctx, oracle):
     """Nine rows in ten belong to one group.  With values that hardly repeat its fine buckets
     hold far more distinct pairs than the LDS set takes: the attempt to take such a bucket in
