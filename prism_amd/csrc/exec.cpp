@@ -21,6 +21,8 @@ struct ColUse {
   bool codes;  // dictionary codes of a string column rather than its raw form
 };
 
+std::shared_ptr<void> lease_pinned(prism_gpu_ctx* ctx, size_t bytes);
+
 struct ScanSet {
   prism_gpu_ctx* ctx = nullptr;
   std::vector<const Chunk*> chunks;
@@ -30,6 +32,14 @@ struct ScanSet {
   const prism_gpu_col_stats* stats_override = nullptr;  // agreed between ranks: replaces the chunks' statistics
   Scratch d_segs, d_cols;
   ScanDesc desc{};
+  // The descriptors leave for the device from a page-locked block, in one copy that nobody waits
+  // for (from the vectors it was two copies and a wait for them: 40 us in front of every query's
+  // first kernel).  The block must outlive the copy: whoever drops the scan set early -- an error
+  // unwinding -- waits for the stream first.
+  std::shared_ptr<void> staged;
+  ~ScanSet() {
+    if (staged && ctx) (void)hipStreamSynchronize(ctx->stream);
+  }
 
   bool uploaded = false;
   int use(int column, bool codes) {
@@ -53,10 +63,9 @@ struct ScanSet {
       if (seg_bytes + col_bytes > arena_bytes) fail(PRISM_GPU_EUNSUPPORTED, "too many partitions for the allocation-free entry point");
       segs_dst = arena;
     } else {
-      d_segs = Scratch(ctx, segs.size() * sizeof(ScanSeg));
+      d_segs = Scratch(ctx, seg_bytes + col_bytes + 256);
       segs_dst = d_segs.p;
     }
-    PRISM_HIP(hipMemcpyAsync(segs_dst, segs.data(), segs.size() * sizeof(ScanSeg), hipMemcpyHostToDevice, ctx->stream));
     std::vector<ColPtr> cp(uses.size() * segs.size());
     for (size_t u = 0; u < uses.size(); ++u)
       for (size_t s = 0; s < segs.size(); ++s) {
@@ -67,17 +76,18 @@ struct ScanSet {
         else { c.values = dc.values; c.bytes = dc.bytes; }
         if (!c.values) fail(PRISM_GPU_EINTERNAL, "column representation missing on the device");
       }
-    cols_dev = nullptr;
-    if (!cp.empty()) {
-      if (arena) {
-        cols_dev = (ColPtr*)((uint8_t*)arena + seg_bytes);
-      } else {
-        d_cols = Scratch(ctx, cp.size() * sizeof(ColPtr));
-        cols_dev = d_cols.as<ColPtr>();
-      }
-      PRISM_HIP(hipMemcpyAsync(cols_dev, cp.data(), cp.size() * sizeof(ColPtr), hipMemcpyHostToDevice, ctx->stream));
+    cols_dev = cp.empty() ? nullptr : (ColPtr*)((uint8_t*)segs_dst + seg_bytes);
+    if (arena) {
+      // (the entry point that may not allocate: straight from the vectors, and waited for)
+      PRISM_HIP(hipMemcpyAsync(segs_dst, segs.data(), segs.size() * sizeof(ScanSeg), hipMemcpyHostToDevice, ctx->stream));
+      if (!cp.empty()) PRISM_HIP(hipMemcpyAsync(cols_dev, cp.data(), col_bytes, hipMemcpyHostToDevice, ctx->stream));
+      PRISM_HIP(hipStreamSynchronize(ctx->stream));  // segs' and cp's host memory may go away
+    } else {
+      staged = lease_pinned(ctx, seg_bytes + col_bytes);
+      std::memcpy(staged.get(), segs.data(), segs.size() * sizeof(ScanSeg));
+      if (!cp.empty()) std::memcpy((uint8_t*)staged.get() + seg_bytes, cp.data(), col_bytes);
+      PRISM_HIP(hipMemcpyAsync(segs_dst, staged.get(), seg_bytes + col_bytes, hipMemcpyHostToDevice, ctx->stream));
     }
-    PRISM_HIP(hipStreamSynchronize(ctx->stream));  // segs' and cp's host memory may go away
     desc.segs = (const ScanSeg*)segs_dst;
     desc.n_segs = (uint32_t)segs.size();
     desc.n_tiles = n_tiles;
@@ -710,25 +720,23 @@ void table_alloc(prism_gpu_ctx* ctx, GroupTable& g, bool dense, uint64_t capacit
   g.dense = dense;
   g.key_words = key_words;
   g.keys_hi = Scratch();
-  if (key_words == 2) {
-    g.keys_hi = Scratch(ctx, (capacity + 1) * 8);
-    PRISM_HIP(hipMemsetAsync(g.keys_hi.p, 0xff, (capacity + 1) * 8, ctx->stream));
-  }
+  if (key_words == 2) g.keys_hi = Scratch(ctx, (capacity + 1) * 8);
   g.capacity = capacity;
   g.n_slots = (int)slot_ops.size();
   g.state = Scratch(ctx, (capacity + 1) * 8 * slot_ops.size());
   g.overflow = Scratch(ctx, 256);
-  PRISM_HIP(hipMemsetAsync(g.overflow.p, 0, 4, ctx->stream));
-  if (!dense) {
-    g.keys = Scratch(ctx, (capacity + 1) * 8);
-    PRISM_HIP(hipMemsetAsync(g.keys.p, 0xff, (capacity + 1) * 8, ctx->stream));
-  }
-  for (size_t s = 0; s < slot_ops.size(); ++s) {
-    int64_t* base = g.state.as<int64_t>() + s * (capacity + 1);
-    long long id = slot_identity_host(slot_ops[s]);
-    if (id == 0) PRISM_HIP(hipMemsetAsync(base, 0, (capacity + 1) * 8, ctx->stream));
-    else launch_fill_i64(ctx, base, capacity + 1, id);
-  }
+  if (!dense) g.keys = Scratch(ctx, (capacity + 1) * 8);
+  // (one launch for the whole table: a fill per array was five launches in front of every query's kernel)
+  TableInit t{};
+  t.keys = dense ? nullptr : g.keys.as<unsigned long long>();
+  t.keys_hi = key_words == 2 ? g.keys_hi.as<unsigned long long>() : nullptr;
+  t.state = g.state.as<long long>();
+  t.entries = capacity + 1;
+  t.n_slots = (int)slot_ops.size();
+  if (slot_ops.size() > (size_t)kMaxSlots) fail(PRISM_GPU_EINTERNAL, "too many accumulators in one group table");
+  for (size_t s = 0; s < slot_ops.size(); ++s) t.identity[s] = slot_identity_host(slot_ops[s]);
+  t.flag = g.overflow.as<uint32_t>();
+  launch_table_init(ctx, t);
 }
 
 // The table's flag word: 0, 1 (an insertion found the table full), 2 (a merged key fell
@@ -2400,6 +2408,7 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       partitioned_group_by(ctx, plan, ap, selected, ss.rows, key_bytes, value_bytes, vals_nullable, slot_ops, gt, leading, &lead);
       dense = false;
     }
+    std::shared_ptr<void> flag_landing;  // (see below: the table's flag word, read with the groups)
     while (!use_part && !outer_ready) {
       {
         HostTimer ht(ctx, "host:table_alloc");
@@ -2414,6 +2423,15 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       if (fused) PRISM_HIP(hipMemsetAsync(d_scalar.p, 0, kCountBytes, ctx->stream));
       launch_group_by(ctx, ap, (ap.row_mode == kRowsSelvec ? selected : ss.rows) * value_bytes);
       if (dense && !ap.stop_if_scattered) break;
+      if (dense && !capture) {
+        // Nothing but "the rows scatter" can come back from a directly indexed table: the groups are
+        // read out at once, and the flag word lands with them (one wait instead of two; it is looked
+        // at before the groups are used).
+        flag_landing = lease_pinned(ctx, 64);
+        *(volatile uint32_t*)flag_landing.get() = 0;
+        PRISM_HIP(hipMemcpyAsync(flag_landing.get(), gt.overflow.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+        break;
+      }
       const uint32_t flag = table_flag(ctx, gt);
       if (flag == 3u && ap.stop_if_scattered) {
         // The rows mostly missed the LDS tables: this plan partitions its rows from now on.
@@ -2481,6 +2499,21 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
         GroupTable q;
         distinct_fold_outer(ctx, layout, selected, gt, q);
         groups_out = distinct_emit_outer(ctx, plan, table, keys, layout, q, cols);
+      }
+    }
+    if (flag_landing) {
+      PRISM_HIP(hipStreamSynchronize(ctx->stream));
+      if (*(volatile uint32_t*)flag_landing.get() == 3u && ap.stop_if_scattered) {
+        // the kernel stopped because its rows scatter: what was read out is no result.  This plan
+        // partitions its rows from now on; start over.
+        plan->part_mode.store(1, std::memory_order_relaxed);
+        gt = GroupTable();
+        sel.bits.reset();
+        selvec.reset();
+        collect_timings(ctx);
+        execute_impl(plan, table, partition_ids, n_partitions, merge_input, out, stats_override, capture, emit_partial, ctx_override,
+                     cols_out, shard_req);
+        return;
       }
     }
   }

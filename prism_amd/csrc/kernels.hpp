@@ -584,6 +584,17 @@ void launch_owner_scatter(prism_gpu_ctx* ctx, const OwnerParams& p, unsigned lon
 
 // Fills n entries with `value`.
 void launch_fill_i64(prism_gpu_ctx* ctx, int64_t* dst, uint64_t n, int64_t value);
+// keys / keys_hi (either may be null) = all ones, state[s][i] = identity[s] for i < entries, *flag (may be null) = 0
+struct TableInit {
+  unsigned long long* keys;
+  unsigned long long* keys_hi;
+  long long* state;
+  uint64_t entries;
+  int n_slots;
+  long long identity[kMaxSlots];
+  uint32_t* flag;
+};
+void launch_table_init(prism_gpu_ctx* ctx, const TableInit& t);
 // Compacts the occupied entries of a table: out_keys[i], out_state[s * out_stride + i].
 // g_keys_hi / out_keys_hi are non-null for two-word keys.  Entries whose position (counted
 // from *out_count's value on entry) is out_limit or more are counted but not written.

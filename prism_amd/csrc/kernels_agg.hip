@@ -460,6 +460,16 @@ __global__ __launch_bounds__(kBlock) void k_merge_packed(MergeParams p) {
   }
 }
 
+// A fresh group table in one launch: keys all ones, every slot its identity, the flag word zero.
+__global__ __launch_bounds__(kBlock) void k_table_init(TableInit t) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && t.flag) *t.flag = 0u;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < t.entries; i += (uint64_t)gridDim.x * kBlock) {
+    if (t.keys) t.keys[i] = ~0ull;
+    if (t.keys_hi) t.keys_hi[i] = ~0ull;
+    for (int s = 0; s < t.n_slots; ++s) t.state[(uint64_t)s * t.entries + i] = t.identity[s];
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void k_fill_i64(long long* dst, uint64_t n, long long value) {
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) dst[i] = value;
 }
@@ -858,6 +868,12 @@ void launch_merge_packed(prism_gpu_ctx* ctx, const MergeParams& p) {
   if (p.n == 0) return;
   KernelTimer timer(ctx, "merge_packed", p.n * 8 * (1 + (uint64_t)p.n_slots));
   k_merge_packed<<<dim3(stream_grid(ctx, p.n)), dim3(kBlock), 0, ctx->stream>>>(p);
+  PRISM_HIP(hipGetLastError());
+}
+
+void launch_table_init(prism_gpu_ctx* ctx, const TableInit& t) {
+  if (t.n_slots < 0 || t.n_slots > kMaxSlots) fail(PRISM_GPU_EINTERNAL, "bad slot count for a group table");
+  k_table_init<<<dim3(stream_grid(ctx, t.entries ? t.entries : 1)), dim3(kBlock), 0, ctx->stream>>>(t);
   PRISM_HIP(hipGetLastError());
 }
 
