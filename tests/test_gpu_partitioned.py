@@ -611,6 +611,32 @@ def test_order_by_count_limit_lists_only_the_groups_that_can_lead(wc_ctx, oracle
         table.close()
 
 
+def test_profiling_levels_time_composite_launches_as_a_whole(wc_ctx):
+    """prism_gpu_set_profiling: level 1 brackets every pass of a partitioned GROUP BY with events,
+    level 2 only the launch as a whole ("group_by"); the passes are counted either way."""
+    from prism_amd.engine import Plan
+
+    wl = workloads.c3(id_bits=18)
+    rows = 1_000_000
+    table = workloads.build_gpu_table(wc_ctx, wl, 0, rows, rows, 2)
+    plan = Plan(wc_ctx, wl.schema, QueryPlan([count_star()], keys=["UserID"]))
+    try:
+        plan.execute(table)
+        for level, passes_timed in ((1, True), (2, False), (0, False)):
+            wc_ctx.reset_stats()
+            wc_ctx.set_profiling(level)
+            plan.execute(table)
+            wc_ctx.set_profiling(0)
+            k = wc_ctx.stats()["kernels"]
+            assert k["wc_scatter"]["launches"] == 1 and k["group_by"]["launches"] == 1
+            assert (k["group_by"]["total_ms"] > 0) == (level != 0)
+            assert (k["wc_scatter"]["total_ms"] > 0) == passes_timed and (k["wc_agg"]["total_ms"] > 0) == passes_timed
+    finally:
+        wc_ctx.set_profiling(0)
+        plan.close()
+        table.close()
+
+
 def test_histogram_free_path_hot_keys_and_many_groups(wc_ctx, oracle):
     """Log-uniform ids: the frequent ids are found in the sample and counted in LDS (they would
     overflow any segment: one id alone holds 1/20 of the rows), the rest goes through the
