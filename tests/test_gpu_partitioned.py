@@ -366,6 +366,20 @@ def test_count_distinct_scatter_by_staging_lines(part_ctx, oracle):
                 assert "part2_scatter" in ran and "part_scatter" not in ran, (name, lines, ran)
                 if lines_expected is not None:
                     assert ("part2_pieces" in ran) == (lines == 2), (name, lines, ran)
+            if name == "in order":
+                # a WHERE (the pieces read the selection bitmap) and a group key of the hour alone (two key columns)
+                part_ctx.set_option("part2_lines", 2)
+                for q2 in (QueryPlan([count_distinct("user")], keys=[date_bin(3_600_000, "ts"), "svc"], predicate=col("svc") != 3),
+                           QueryPlan([count_distinct("user")], keys=[date_bin(3_600_000, "ts")])):
+                    plan = Plan(part_ctx, t.schema, q2)
+                    try:
+                        part_ctx.reset_stats()
+                        got2 = plan.execute(g)
+                        ran = _kernels(part_ctx)
+                    finally:
+                        plan.close()
+                    assert_tables_match(got2, oracle.execute(t, q2), len(q2.keys))
+                    assert "part2_pieces" in ran, ran
         finally:
             part_ctx.set_option("part2_lines", 1)
             g.close()
