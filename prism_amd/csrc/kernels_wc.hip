@@ -498,6 +498,7 @@ __global__ __launch_bounds__(kWcBlock) void k_wc_agg(AggParams p, WcParams w) {
     __syncthreads();
     const unsigned long long* region = (const unsigned long long*)w.rec + (((uint64_t)b * w.n_wg) << w.cap_shift);
     bool lost = false;
+    uint32_t my_new = 0;  // keys this lane put into the table (added up per wave when the bucket is done)
     for (uint32_t seg0 = 0; seg0 < w.n_wg; seg0 += kWcBlock / LPS) {
       const uint32_t seg = seg0 + seg_lane;
       const uint32_t c = seg < w.n_wg ? segcnt[seg] : 0u;
@@ -547,13 +548,13 @@ __global__ __launch_bounds__(kWcBlock) void k_wc_agg(AggParams p, WcParams w) {
           if (claim[u])
             old[u] = atomicCAS(&keys[2 * h1[u] + (c1[u].x == kWcEmpty ? 0u : 1u)], kWcEmpty, (unsigned long long)key[u]);
         }
-        uint32_t n_new = 0, miss = 0;
+        uint32_t miss = 0;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const bool ins = claim[u] && old[u] == kWcEmpty;
           if (claim[u] && (old[u] == kWcEmpty || old[u] == key[u])) e[u] = (int)(2 * h1[u] + (c1[u].x == kWcEmpty ? 0u : 1u));
           if (in[u] && e[u] < 0) miss |= 1u << u;
-          n_new += (uint32_t)__popcll(__ballot(ins));
+          my_new += ins ? 1u : 0u;
           if (in[u] && e[u] >= 0) atomicAdd(&cnt[e[u]], 1u);
         }
         // The rows whose first home bucket held two other keys, or whose claim another lane won:
@@ -573,12 +574,15 @@ __global__ __launch_bounds__(kWcBlock) void k_wc_agg(AggParams p, WcParams w) {
             if (at < 0) lost = true;
             else atomicAdd(&cnt[at], 1u);
           }
-          n_new += (uint32_t)__popcll(__ballot(ins));
+          my_new += ins ? 1u : 0u;
         }
-        if (n_new && lane == 0) atomicAdd(&n_entries, n_new);
       }
     }
     if (lost) w.flags[2] = 1u;
+    {
+      const uint32_t wave_new = (uint32_t)wave_sum_u64(my_new);
+      if (lane == 0 && wave_new) atomicAdd(&n_entries, wave_new);
+    }
     __syncthreads();
     const uint32_t n = n_entries;
     if (cut) {
