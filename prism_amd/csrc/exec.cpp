@@ -1624,8 +1624,10 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggPar
   const uint32_t region_cap = direct ? (uint32_t)(((((selected / std::max<uint64_t>(1, coarse_used)) >> p2) * 3 / 2 + 64) + 15) & ~15ull) : 0;
   const uint64_t spill_capacity = selected / 2 + 4096, region_records = (uint64_t)n_regions * region_cap;
   Scratch emitted;  // (a sharded query without a first level: where the last pass writes the buckets' distinct records)
-  if (direct && shard) emitted = Scratch(ctx, std::max<uint64_t>(1, selected) * 8 + 256);
-  bool spill = direct && !shard && ctx->part2_fixed.load(std::memory_order_relaxed) != 0 && plan->part2_fixed.load(std::memory_order_relaxed) >= 0 &&
+  if (direct && shard) emitted = Scratch(ctx, std::max<uint64_t>({1, selected, region_records}) * 8 + 256);
+  // (a sharded query takes the regions and the spill list too: its last pass then writes a bucket's distinct records
+  // into the bucket's region, and a bucket with more of them than the region holds sends the plan back to the histogram)
+  bool spill = direct && ctx->part2_fixed.load(std::memory_order_relaxed) != 0 && plan->part2_fixed.load(std::memory_order_relaxed) >= 0 &&
                region_records + spill_capacity < (1ull << 32);
   Scratch spill_rec, spill_fine, spill_small, d_pieces;
   // (the scatter pass by staging lines: a workgroup per piece of a coarse bucket's stretch of tiles; about three pieces a CU)

@@ -1004,7 +1004,9 @@ __global__ __launch_bounds__(kP2AggBlock) void k_part2_agg(Part2Params q, uint32
 // is counted.  kP2Merge (the owner's part): bucket j of this rank's share of the fine buckets
 // is the union of one run of records per sending rank (q.seg_base / q.seg_cnt, in q.out_lo),
 // each run distinct in itself; counted like kP2Count.
-enum P2AggMode { kP2Count = 0, kP2Emit = 1, kP2Merge = 2 };
+// kP2EmitRuns: both -- a rank's own part whose buckets lie in several runs (the scatter by staging
+// lines): the bucket's distinct records go to q.emit_out at the start of the bucket's region.
+enum P2AggMode { kP2Count = 0, kP2Emit = 1, kP2Merge = 2, kP2EmitRuns = 3 };
 
 template <int MODE>
 __global__ __launch_bounds__(kP2AggBlock) void k_part2_agg_compact(Part2Params q, uint32_t n_fine) {
@@ -1020,7 +1022,7 @@ __global__ __launch_bounds__(kP2AggBlock) void k_part2_agg_compact(Part2Params q
   for (uint32_t i = tid; i < kP2Groups; i += kP2AggBlock) gcnt[i] = 0;
   if (tid == 0) emit_n = 0;
   constexpr uint32_t kBatch = 8;  // rows a thread requests together
-  const uint32_t n_src = MODE == kP2Merge ? q.n_src : 1u;
+  const uint32_t n_src = (MODE & kP2Merge) != 0 ? q.n_src : 1u;
   // kP2Merge: the bucket's runs (at most 64) are taken as ONE sequence of records -- record i lies
   // in the run r with run_off[r] <= i < run_off[r + 1], at run_base[r] + i - run_off[r] -- so that
   // a batch of loads is full whatever the runs' lengths (run by run, six runs of a thousand records
@@ -1031,7 +1033,7 @@ __global__ __launch_bounds__(kP2AggBlock) void k_part2_agg_compact(Part2Params q
   auto fetch_runs = [&](uint32_t f2) {
     nx_base = 0;
     nx_cnt = 0;
-    if (MODE == kP2Merge && tid < n_src && f2 < n_fine) {
+    if ((MODE & kP2Merge) != 0 && tid < n_src && f2 < n_fine) {
       nx_base = q.seg_base[(uint64_t)tid * n_fine + f2];
       nx_cnt = q.seg_cnt[(uint64_t)tid * n_fine + f2];
     }
@@ -1040,7 +1042,7 @@ __global__ __launch_bounds__(kP2AggBlock) void k_part2_agg_compact(Part2Params q
   for (uint32_t f = blockIdx.x; f < n_fine; f += gridDim.x) {
     __syncthreads();
     uint32_t b0 = 0, n = 0;  // (other modes: the bucket is records [b0, b0 + n))
-    if (MODE == kP2Merge) {
+    if ((MODE & kP2Merge) != 0) {
       if (tid < 64) {
         uint32_t incl = nx_cnt;
 #pragma unroll
@@ -1054,18 +1056,19 @@ __global__ __launch_bounds__(kP2AggBlock) void k_part2_agg_compact(Part2Params q
       fetch_runs(f + gridDim.x);
       __syncthreads();
       n = run_off[n_src];
+      if ((MODE & kP2Emit) != 0) b0 = q.fine_base[f];  // (where the bucket's distinct records go)
     } else {
       b0 = q.fine_base[f];
       n = p2_bucket_end(q, f) - b0;
     }
     if (n == 0) {
-      if (MODE == kP2Emit && tid == 0) q.fine_count[f] = 0;
+      if ((MODE & kP2Emit) != 0 && tid == 0) q.fine_count[f] = 0;
       continue;
     }
     // where record i of the bucket lies in q.out_lo (i < n)
     // (a thread asks for rising i: `r`, the run of its last record, is where the search goes on)
     auto at_of = [&](uint32_t i, uint32_t& r) -> uint32_t {
-      if (MODE != kP2Merge) return b0 + i;
+      if ((MODE & kP2Merge) == 0) return b0 + i;
       while (r + 1 < n_src && i >= run_off[r + 1]) ++r;
       return run_base[r] + (i - run_off[r]);
     };
@@ -1116,7 +1119,7 @@ __global__ __launch_bounds__(kP2AggBlock) void k_part2_agg_compact(Part2Params q
             const uint32_t e = 2 * bkt + (c.x == kP2Empty ? 0u : 1u);
             const unsigned long long old = atomicCAS(&keys[e], kP2Empty, (unsigned long long)rec);
             if (old == kP2Empty) {  // seen for the first time: counts for its group
-              if (MODE != kP2Emit) atomicAdd(&gcnt[(uint32_t)(rec >> lo_rest)], 1u);
+              if ((MODE & kP2Emit) == 0) atomicAdd(&gcnt[(uint32_t)(rec >> lo_rest)], 1u);
               return true;
             }
             if (old == rec) return false;
@@ -1134,14 +1137,17 @@ __global__ __launch_bounds__(kP2AggBlock) void k_part2_agg_compact(Part2Params q
         for (uint32_t j = 0; j < kBatch; ++j) {
           bool fresh = false;
           if (first + tid + j * kP2AggBlock < end) fresh = take(r[j], pass);
-          if (MODE == kP2Emit) {
+          if ((MODE & kP2Emit) != 0) {
             // the wave's new records take consecutive places behind the bucket's earlier ones
             const uint64_t m = __ballot(fresh);
             if (m) {
               uint32_t at = 0;
               if (lane == (uint32_t)(__ffsll((long long)m) - 1)) at = atomicAdd(&emit_n, (uint32_t)__popcll(m));
               at = __shfl(at, __ffsll((long long)m) - 1);
-              if (fresh) q.emit_out[(uint64_t)b0 + at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r[j];
+              const uint32_t place = at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+              // (kP2EmitRuns: the records go to the bucket's region, which may be shorter than the bucket with its spilled rows)
+              if (fresh && (MODE & kP2Merge) != 0 && place >= q.region_cap) q.flags[1] = 1u;
+              else if (fresh) q.emit_out[(uint64_t)b0 + place] = r[j];
             }
           }
         }
@@ -1174,7 +1180,7 @@ __global__ __launch_bounds__(kP2AggBlock) void k_part2_agg_compact(Part2Params q
       if (passes < 2) passes = 2;
       __syncthreads();
     }
-    if (MODE == kP2Emit) {
+    if ((MODE & kP2Emit) != 0) {
       if (tid == 0) {
         q.fine_count[f] = emit_n;
         my_pairs += emit_n;
@@ -1183,7 +1189,7 @@ __global__ __launch_bounds__(kP2AggBlock) void k_part2_agg_compact(Part2Params q
       continue;
     }
     // (kP2Merge: bucket f of this rank's share is fine bucket (c * world + rank, sub) of the query)
-    const uint64_t coarse = MODE == kP2Merge ? (uint64_t)(f >> q.p2_bits) * q.world + q.rank : (uint64_t)(f >> q.p2_bits);
+    const uint64_t coarse = (MODE & kP2Merge) != 0 ? (uint64_t)(f >> q.p2_bits) * q.world + q.rank : (uint64_t)(f >> q.p2_bits);
     for (uint32_t i = tid; i < n_groups; i += kP2AggBlock) {
       const uint32_t c = gcnt[i];
       if (c == 0) continue;
@@ -1325,7 +1331,7 @@ bool part2_lines_fit(uint32_t p2_bits, uint32_t piece_tiles) {
 
 void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q, const AggParams* scan) {
   if (q.n_rows == 0) return;
-  if (q.direct && (!scan || !q.compact || (q.fine_limit && !q.spill_rec) || (q.emit_out && q.spill_rec) || q.n_tiles == 0 || q.slice_tiles == 0 || (q.slice_tiles & 1u)))
+  if (q.direct && (!scan || !q.compact || (q.fine_limit && !q.spill_rec) || q.n_tiles == 0 || q.slice_tiles == 0 || (q.slice_tiles & 1u)))
     fail(PRISM_GPU_EINTERNAL, "bad shape for a second partition level that reads the scan's columns");
   if (q.spill_rec) {
     const uint64_t regions = (uint64_t)q.n_regions * q.region_cap;
@@ -1427,9 +1433,10 @@ void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q, cons
     m.seg_cnt = q.seg_cnt_out;
     KernelTimer timer(ctx, "part2_agg", q.n_rows * 8, true);
     const size_t lds = (size_t)q.lds_entries * 8;
-    PRISM_HIP(hipFuncSetAttribute((const void*)k_part2_agg_compact<kP2Merge>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    auto kernel = q.emit_out ? k_part2_agg_compact<kP2EmitRuns> : k_part2_agg_compact<kP2Merge>;
+    PRISM_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint32_t grid = (uint32_t)std::min<uint64_t>(q.n_regions, (uint64_t)ctx->n_cus * kP2AggPerCu);
-    k_part2_agg_compact<kP2Merge><<<dim3(grid), dim3(kP2AggBlock), lds, ctx->stream>>>(m, q.n_regions);
+    kernel<<<dim3(grid), dim3(kP2AggBlock), lds, ctx->stream>>>(m, q.n_regions);
     PRISM_HIP(hipGetLastError());
     return;
   }

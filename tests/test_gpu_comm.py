@@ -390,6 +390,8 @@ def _distinct_at_scale_worker(rank: int, world: int, port: int, q):
             table.close()
         ran = {k for k, v in ctx.stats()["kernels"].items() if v["launches"]}
         assert "part2_merge" in ran and "shard_gather" in ran, ran
+        # (the rank's own part: rows in time order, an hour runs through hundreds of scan tiles -- one level, staging lines)
+        assert "part2_pieces" in ran and "part2_hist" not in ran and "part_scatter" not in ran, ran
         assert comm.stats()["bytes_sent"] > rows  # the distinct records of the other rank's buckets: gigabytes
         if rank == 0:
             whole = workloads.build_gpu_table(ctx, wl, 0, total, total, 16)
