@@ -1650,7 +1650,7 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggPar
     spill_rec = Scratch(ctx, spill_capacity * 8 + 64);
     spill_fine = Scratch(ctx, spill_capacity * 4 + 64);
     spill_small = Scratch(ctx, spill_small_bytes);
-    if (lines) d_pieces = Scratch(ctx, (size_t)max_pieces * sizeof(P2Piece) + (size_t)(P1 + 1) * 4 + 64);
+    if (lines) d_pieces = Scratch(ctx, (size_t)max_pieces * sizeof(P2Piece) + (size_t)(P1 + 1) * 4 + 64 + 256);
   }
   for (int w = 0; w < 2; ++w)
     if (w == 0 || !compact)
@@ -1728,6 +1728,7 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggPar
           q2.piece_chunks = part2_piece_chunks(piece_tiles);
           q2.pieces = d_pieces.as<P2Piece>();
           q2.bounds = (uint32_t*)(d_pieces.as<P2Piece>() + max_pieces);
+          q2.rare = (P2Rare*)(d_pieces.as<uint8_t>() + (((size_t)max_pieces * sizeof(P2Piece) + (size_t)(P1 + 1) * 4 + 63) & ~(size_t)63));
           q2.n_pieces = (uint32_t*)(d_small.as<uint8_t>() + 128);
           q2.dropped = (unsigned long long*)(d_small.as<uint8_t>() + 136);
           q2.pieces_too_long = q2.n_pieces + 1;

@@ -328,6 +328,21 @@ struct P2Piece {
   uint32_t seg_first;  // its part of a fine bucket's region: first record and records
   uint32_t seg_cap;
 };
+// What the scatter by staging lines needs on its rare paths only (spilled lines, rows of other
+// coarse buckets, the end of a piece): kept in device memory and read where it is used, so that
+// the main loop does not hold it in scalar registers (k_part2_pieces fills it in).
+struct P2Rare {
+  uint64_t* spill_rec;
+  uint32_t* spill_fine;
+  unsigned long long* spill_cursor;
+  uint64_t spill_capacity;
+  uint32_t* flags;
+  unsigned long long* strays;
+  unsigned long long* dropped;
+  uint32_t* seg_base_out;
+  uint32_t* seg_cnt_out;
+  uint32_t piece_chunks, n_regions;
+};
 struct Part2Params {
   const uint64_t* in_lo;        // records sorted by coarse bucket
   const uint64_t* in_hi;
@@ -407,6 +422,7 @@ struct Part2Params {
   uint32_t* bounds;       // [2^p1_bits + 1] first tile of every coarse bucket's stretch
   P2Piece* pieces;        // [max_pieces]
   uint32_t* n_pieces;
+  P2Rare* rare;
   uint32_t* pieces_too_long;    // set when a piece would pass 2 * piece_tiles tiles (no piece is made then: the caller scatters another way)
   unsigned long long* dropped;  // rows dropped because they repeated a recently staged record (statistics)
 };

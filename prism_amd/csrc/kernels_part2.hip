@@ -634,7 +634,22 @@ __global__ __launch_bounds__(1024) void k_part2_pieces(Part2Params q) {
     __syncthreads();
   }
   __syncthreads();
-  if (tid == 0) *q.n_pieces = *q.pieces_too_long ? 0u : (carry < q.max_pieces ? carry : q.max_pieces);
+  if (tid == 0) {
+    *q.n_pieces = *q.pieces_too_long ? 0u : (carry < q.max_pieces ? carry : q.max_pieces);
+    P2Rare r;
+    r.spill_rec = q.spill_rec;
+    r.spill_fine = q.spill_fine;
+    r.spill_cursor = q.spill_cursor;
+    r.spill_capacity = q.spill_capacity;
+    r.flags = q.flags;
+    r.strays = q.strays;
+    r.dropped = q.dropped;
+    r.seg_base_out = q.seg_base_out;
+    r.seg_cnt_out = q.seg_cnt_out;
+    r.piece_chunks = q.piece_chunks;
+    r.n_regions = q.n_regions;
+    *q.rare = r;
+  }
 }
 
 constexpr uint32_t kP2Stage = 8;  // records of a staging line (64 bytes)
@@ -657,12 +672,13 @@ typedef uint32_t __attribute__((ext_vector_type(4), aligned(4))) p2_u32x4;
 // whoever puts a generation's eighth record in place copies the line out and opens the next
 // generation.  No tile, no sort, no barrier inside the loop (the protocol of the histogram-free
 // GROUP BY's scatter pass, kernels_wc.hip).
-template <int NK>
+template <int NK, bool BIN64>
 __global__ __launch_bounds__(kP2Block) __attribute__((amdgpu_waves_per_eu(4))) void k_part2_lines(Part2Params q, AggParams p) {
   constexpr int R = 4;
   extern __shared__ __align__(16) unsigned long long p2l_lds[];
   __shared__ uint32_t n_stray;
   if (blockIdx.x >= *q.n_pieces) return;
+  const P2Rare* const rare = q.rare;  // (read where it is used: see P2Rare)
   const uint32_t n_sub = 1u << q.p2_bits, tid = threadIdx.x;
   unsigned long long* stage = p2l_lds;                                  // [n_sub][kP2Stage]
   uint32_t* fill = (uint32_t*)(stage + (size_t)n_sub * kP2Stage);       // [n_sub]
@@ -671,14 +687,14 @@ __global__ __launch_bounds__(kP2Block) __attribute__((amdgpu_waves_per_eu(4))) v
   // dropped where it stands -- a pair counts once however often it comes, and the pairs that come
   // tens of thousands of times (a crawler's id in one hour) are what overflows the regions.
   unsigned long long* recent = (unsigned long long*)(prog + n_sub);     // [n_sub][kP2Recent]
-  uint32_t* chunk = (uint32_t*)(recent + (size_t)n_sub * kP2Recent);    // [q.piece_chunks] where the piece's spill chunks start
+  uint32_t* chunk = (uint32_t*)(recent + (size_t)n_sub * kP2Recent);    // [rare->piece_chunks] where the piece's spill chunks start
   __shared__ uint32_t sp_pos;                                           // records the piece has spilled
   const uint32_t t0 = __builtin_amdgcn_readfirstlane(q.pieces[blockIdx.x].t0), t1 = __builtin_amdgcn_readfirstlane(q.pieces[blockIdx.x].t1);
   const uint32_t coarse = __builtin_amdgcn_readfirstlane(q.pieces[blockIdx.x].coarse), src = __builtin_amdgcn_readfirstlane(q.pieces[blockIdx.x].src);
   const uint32_t seg_first = __builtin_amdgcn_readfirstlane(q.pieces[blockIdx.x].seg_first);
   const uint32_t seg_cap = __builtin_amdgcn_readfirstlane(q.pieces[blockIdx.x].seg_cap);
   for (uint32_t i = tid; i < n_sub; i += kP2Block) { fill[i] = 0; prog[i] = 0; }
-  for (uint32_t i = tid; i < q.piece_chunks; i += kP2Block) chunk[i] = kP2NoChunk;
+  for (uint32_t i = tid; i < rare->piece_chunks; i += kP2Block) chunk[i] = kP2NoChunk;
   for (uint32_t i = tid; i < n_sub * kP2Recent; i += kP2Block) recent[i] = kP2Empty;
   if (tid == 0) { n_stray = 0; sp_pos = 0; }
   __syncthreads();
@@ -690,15 +706,15 @@ __global__ __launch_bounds__(kP2Block) __attribute__((amdgpu_waves_per_eu(4))) v
   // holds the first record of a chunk fetches the chunk (sp_chunk) BEFORE anybody of its wave
   // asks for a place in it; lanes of other waves wait here for the chunk's start to appear.
   auto sp_chunk = [&](uint32_t ci) {
-    if (ci >= q.piece_chunks) { q.flags[1] = 1u; return; }
-    const unsigned long long at = atomicAdd(q.spill_cursor, (unsigned long long)kP2SpillChunk);
-    const bool fits = at + kP2SpillChunk <= q.spill_capacity;
-    if (!fits) q.flags[1] = 1u;
+    if (ci >= rare->piece_chunks) { rare->flags[1] = 1u; return; }
+    const unsigned long long at = atomicAdd(rare->spill_cursor, (unsigned long long)kP2SpillChunk);
+    const bool fits = at + kP2SpillChunk <= rare->spill_capacity;
+    if (!fits) rare->flags[1] = 1u;
     __hip_atomic_store(&chunk[ci], fits ? (uint32_t)at : kP2BadChunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
   auto sp_place = [&](uint32_t pos) -> uint32_t {
     const uint32_t ci = pos / kP2SpillChunk;
-    if (ci >= q.piece_chunks) return kP2NoChunk;
+    if (ci >= rare->piece_chunks) return kP2NoChunk;
     uint32_t base;
     do {
       base = __hip_atomic_load(&chunk[ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -706,11 +722,11 @@ __global__ __launch_bounds__(kP2Block) __attribute__((amdgpu_waves_per_eu(4))) v
     return base == kP2BadChunk ? kP2NoChunk : base + pos % kP2SpillChunk;
   };
   auto spill_one = [&](uint64_t rec, uint32_t ff) {
-    if (ff >= q.n_regions) { q.flags[0] = 1u; return; }  // (a bucket the columns' statistics rule out: the result is void)
+    if (ff >= rare->n_regions) { rare->flags[0] = 1u; return; }  // (a bucket the columns' statistics rule out: the result is void)
     const uint32_t pos = atomicAdd(&sp_pos, 1u);
     if (pos % kP2SpillChunk == 0) sp_chunk(pos / kP2SpillChunk);
     const uint32_t at = sp_place(pos);
-    if (at != kP2NoChunk) { q.spill_rec[at] = rec; q.spill_fine[at] = ff; }
+    if (at != kP2NoChunk) { rare->spill_rec[at] = rec; rare->spill_fine[at] = ff; }
   };
   unsigned long long raw[NK][R];
   uint32_t live = 0, live_next = 0, strays = 0, drops = 0;
@@ -721,7 +737,7 @@ __global__ __launch_bounds__(kP2Block) __attribute__((amdgpu_waves_per_eu(4))) v
   }
   for (uint64_t t = t0; t < t1; ++t) {
     uint64_t rec2[2][R], key[R];
-    part_finish<2, NK, 0, R>(p, raw, rec2);
+    part_finish<2, NK, 0, R, BIN64>(p, raw, rec2);
     live = live_next;
     if (t + 1 < t1) part_issue<NK, 0, R>(p, cur, t + 1, t1, tid, raw, live_next);
     uint32_t bkt[R], tk[R], needw = 0;
@@ -796,9 +812,9 @@ __global__ __launch_bounds__(kP2Block) __attribute__((amdgpu_waves_per_eu(4))) v
             if (c1 == c0) {
               const uint32_t at = sp_place(pos);
               if (at != kP2NoChunk) {
-                p2_u64x2* dr = (p2_u64x2*)(q.spill_rec + at);
+                p2_u64x2* dr = (p2_u64x2*)(rare->spill_rec + at);
                 dr[0] = p2_u64x2{a.x, a.y}; dr[1] = p2_u64x2{b.x, b.y}; dr[2] = p2_u64x2{c.x, c.y}; dr[3] = p2_u64x2{d.x, d.y};
-                p2_u32x4* df = (p2_u32x4*)(q.spill_fine + at);
+                p2_u32x4* df = (p2_u32x4*)(rare->spill_fine + at);
                 df[0] = p2_u32x4{ff, ff, ff, ff}; df[1] = p2_u32x4{ff, ff, ff, ff};
               }
             } else {
@@ -806,7 +822,7 @@ __global__ __launch_bounds__(kP2Block) __attribute__((amdgpu_waves_per_eu(4))) v
 #pragma unroll
               for (uint32_t j = 0; j < kP2Stage; ++j) {
                 const uint32_t at = sp_place(pos + j);
-                if (at != kP2NoChunk) { q.spill_rec[at] = w[j]; q.spill_fine[at] = ff; }
+                if (at != kP2NoChunk) { rare->spill_rec[at] = w[j]; rare->spill_fine[at] = ff; }
               }
             }
           }
@@ -830,24 +846,24 @@ __global__ __launch_bounds__(kP2Block) __attribute__((amdgpu_waves_per_eu(4))) v
         for (uint32_t j = 0; j < rem; ++j) spill_one(stage[(size_t)b * kP2Stage + j], ff);
       }
     }
-    if (ff < q.n_regions) {
-      q.seg_base_out[(uint64_t)src * q.n_regions + ff] = (uint32_t)(piece_base + (uint64_t)b * q.region_cap);
-      q.seg_cnt_out[(uint64_t)src * q.n_regions + ff] = in_region;
+    if (ff < rare->n_regions) {
+      rare->seg_base_out[(uint64_t)src * rare->n_regions + ff] = (uint32_t)(piece_base + (uint64_t)b * q.region_cap);
+      rare->seg_cnt_out[(uint64_t)src * rare->n_regions + ff] = in_region;
     }
   }
   if (strays) atomicAdd(&n_stray, strays);
   {
     const unsigned long long wave_drops = wave_sum_u64(drops);
-    if ((tid & 63u) == 0 && wave_drops && q.dropped) atomicAdd(q.dropped, wave_drops);
+    if ((tid & 63u) == 0 && wave_drops && rare->dropped) atomicAdd(rare->dropped, wave_drops);
   }
   __syncthreads();
-  if (tid == 0 && n_stray && q.strays) atomicAdd(q.strays, (unsigned long long)n_stray);
+  if (tid == 0 && n_stray && rare->strays) atomicAdd(rare->strays, (unsigned long long)n_stray);
   // the rest of the piece's last spill chunk holds no records
   const uint32_t spilled = sp_pos;
-  if (spilled % kP2SpillChunk != 0 && spilled / kP2SpillChunk < q.piece_chunks) {
+  if (spilled % kP2SpillChunk != 0 && spilled / kP2SpillChunk < rare->piece_chunks) {
     const uint32_t base = chunk[spilled / kP2SpillChunk];
     if (base != kP2NoChunk && base != kP2BadChunk)
-      for (uint32_t i = spilled % kP2SpillChunk + tid; i < kP2SpillChunk; i += kP2Block) q.spill_fine[base + i] = 0xffffffffu;
+      for (uint32_t i = spilled % kP2SpillChunk + tid; i < kP2SpillChunk; i += kP2Block) rare->spill_fine[base + i] = 0xffffffffu;
   }
 }
 
@@ -1377,7 +1393,7 @@ void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q, cons
     PRISM_HIP(hipGetLastError());
   }
   if (q.lines) {
-    if (!q.spill_rec || !q.direct || (ahead != 2 && ahead != 3) || !q.bounds || !q.pieces || !q.n_pieces || !q.pieces_too_long || q.piece_tiles == 0 || q.piece_max == 0 ||
+    if (!q.spill_rec || !q.direct || (ahead != 2 && ahead != 3) || !q.bounds || !q.pieces || !q.n_pieces || !q.pieces_too_long || !q.rare || q.piece_tiles == 0 || q.piece_max == 0 ||
         q.piece_max > 63 || q.max_pieces == 0 || q.n_tiles >= (1ull << 32))
       fail(PRISM_GPU_EINTERNAL, "bad shape for the scatter pass by staging lines");
     {
@@ -1389,7 +1405,9 @@ void launch_distinct_second_level(prism_gpu_ctx* ctx, const Part2Params& q, cons
     KernelTimer timer(ctx, "part2_scatter", q.n_rows * 24, true);
     const size_t lds = p2_lines_lds(q.p2_bits, q.piece_chunks);
     if (q.piece_chunks < 2ull * q.piece_tiles * kTileRows / kP2SpillChunk + 4 || lds > kP2LdsBytes) fail(PRISM_GPU_EINTERNAL, "bad spill chunk table for the scatter pass by staging lines");
-    auto kernel = ahead == 3 ? k_part2_lines<3> : k_part2_lines<2>;
+    bool bin64 = false;  // a date_bin over a span of 2^32 and more among the keys
+    for (int k = 0; k < ap.n_keys; ++k) bin64 = bin64 || (ap.keys[k].date_bin && !ap.keys[k].fast32);
+    auto kernel = ahead == 3 ? (bin64 ? k_part2_lines<3, true> : k_part2_lines<3, false>) : (bin64 ? k_part2_lines<2, true> : k_part2_lines<2, false>);
     PRISM_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     kernel<<<dim3(q.max_pieces), dim3(kP2Block), lds, ctx->stream>>>(q, ap);
     PRISM_HIP(hipGetLastError());

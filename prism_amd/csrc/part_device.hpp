@@ -278,7 +278,9 @@ __device__ __forceinline__ void part_issue(const AggParams& p, PartCursor<NK + N
 }
 
 // The words requested by part_issue as a record: packed key word(s), then the widened values.
-template <int KW, int NK, int NV, int R>
+// BIN64 = false: the caller has checked that no key is a date_bin over a span of 2^32 and more (its
+// constants -- a 64-bit magic number, origin and stride per key -- then stay out of the registers).
+template <int KW, int NK, int NV, int R, bool BIN64 = true>
 __device__ __forceinline__ void part_finish(const AggParams& p, const unsigned long long (&raw)[NK + NV][R],
                                             uint64_t (&rec)[KW + NV][R]) {
   uint64_t lo[R], hi[R];
@@ -304,7 +306,7 @@ __device__ __forceinline__ void part_finish(const AggParams& p, const unsigned l
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         long long v = part_widen(raw[k][r], ks.width, ks.is_unsigned);
-        if (ks.date_bin) v = bucket_number(v, ks);
+        if (BIN64 && ks.date_bin) v = bucket_number(v, ks);
         const uint64_t field = ((uint64_t)v - (uint64_t)ks.bias) << ks.bit_pos;
         if (KW == 2 && ks.word) hi[r] |= field; else lo[r] |= field;
       }
