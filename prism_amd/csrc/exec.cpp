@@ -741,11 +741,14 @@ void table_alloc(prism_gpu_ctx* ctx, GroupTable& g, bool dense, uint64_t capacit
 
 // The table's flag word: 0, 1 (an insertion found the table full), 2 (a merged key fell
 // outside a dense table) or 3 (the streaming kernel stopped because its rows scatter).
+// (Words read back from the device land in a page-locked block of the pool: a copy into pageable
+// memory -- a variable on the stack -- goes through the runtime's own staging first, some tens
+// of microseconds that a query of a few million rows notices.)
 uint32_t table_flag(prism_gpu_ctx* ctx, const GroupTable& g) {
-  uint32_t flag = 0;
-  PRISM_HIP(hipMemcpyAsync(&flag, g.overflow.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  std::shared_ptr<void> landing = lease_pinned(ctx, 64);
+  PRISM_HIP(hipMemcpyAsync(landing.get(), g.overflow.p, 4, hipMemcpyDeviceToHost, ctx->stream));
   PRISM_HIP(hipStreamSynchronize(ctx->stream));
-  return flag;
+  return *(const volatile uint32_t*)landing.get();
 }
 
 bool table_overflowed(prism_gpu_ctx* ctx, const GroupTable& g) { return table_flag(ctx, g) != 0; }
@@ -980,8 +983,10 @@ uint64_t emit_groups(prism_gpu_ctx* ctx, const prism_gpu_plan* plan, const prism
                           ec, vals, valid, stride, count, use_order, d_topk.as<TopKState>());
     };
     Scratch d_count(ctx, 256), d_vals, d_valid;
-    unsigned long long count[2] = {0, 0};  // groups emitted, "a dictionary code was out of range"
-    unsigned long long recount[2] = {0, 0};  // the same from the second pass over a large table
+    std::shared_ptr<void> counts_landing = lease_pinned(ctx, 64);  // (page-locked: see table_flag)
+    unsigned long long* const count = (unsigned long long*)counts_landing.get();  // groups emitted, "a dictionary code was out of range"
+    unsigned long long* const recount = count + 2;  // the same from the second pass over a large table
+    count[0] = count[1] = recount[0] = recount[1] = 0;
     uint64_t stride = 0;
     bool fresh = true;
     for (const OutColumn& oc : cols) fresh = fresh && oc.rows() == 0;
@@ -1191,7 +1196,8 @@ bool wc_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggParams& ap, 
     }
     struct { unsigned long long cursor; uint32_t n_cand, pad; uint32_t flags[4]; unsigned long long hot_rows, groups_total; uint32_t cut, pad2; } h{};
     HostTimer ht_wait(ctx, "host:part_wait");
-    PRISM_HIP(hipMemcpyAsync(&h, d_small, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    std::shared_ptr<void> h_landing = lease_pinned(ctx, sizeof(h));  // (page-locked: see table_flag)
+    PRISM_HIP(hipMemcpyAsync(h_landing.get(), d_small, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     std::shared_ptr<void> lead_pin;
     const uint64_t lead_fetch = std::min<uint64_t>(kLeadFetch, list_cap);
     if (w.leading && lead) {
@@ -1200,6 +1206,7 @@ bool wc_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggParams& ap, 
       PRISM_HIP(hipMemcpyAsync((uint64_t*)lead_pin.get() + kLeadFetch, list.state.p, lead_fetch * 8, hipMemcpyDeviceToHost, ctx->stream));
     }
     PRISM_HIP(hipStreamSynchronize(ctx->stream));
+    std::memcpy(&h, h_landing.get(), sizeof(h));
     if (std::getenv("PRISM_WC_DEBUG"))
       std::fprintf(stderr, "[wc] n_wg %u tiles/wg %u cap 2^%u entries %u sample %u thr %u: groups %llu cand %u flags %u %u %u\n", w.n_wg,
                    w.tiles_per_wg, w.cap_shift, w.lds_entries, w.sample_tiles, w.hot_threshold, h.cursor, h.n_cand, h.flags[0],
@@ -1736,8 +1743,12 @@ bool partitioned_distinct(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggPar
       }
     }
     launch_distinct_second_level(ctx, q2, direct ? &ap : nullptr);
-    PRISM_HIP(hipMemcpyAsync(&h, q2.flags, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-    PRISM_HIP(hipStreamSynchronize(ctx->stream));
+    {
+      std::shared_ptr<void> h_landing = lease_pinned(ctx, sizeof(h));  // (page-locked: see table_flag)
+      PRISM_HIP(hipMemcpyAsync(h_landing.get(), q2.flags, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+      PRISM_HIP(hipStreamSynchronize(ctx->stream));
+      std::memcpy(&h, h_landing.get(), sizeof(h));
+    }
     collect_timings(ctx);
     if (std::getenv("PRISM_WC_DEBUG"))
       std::fprintf(stderr, "[part2] p1 %d p2 %d compact %d fixed %d direct %d spill %d lines %d (%u tiles a piece, %u pieces a bucket) rows %llu: flags %u %u strays %llu spilled %llu pieces %u dropped %llu\n", p1, p2,
@@ -2117,7 +2128,6 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
 
   // a count many workgroups add to: kCountShards partial sums (kernels.hpp), added up here
   Scratch d_scalar(ctx, kCountBytes);
-  std::vector<unsigned long long> h_count(kCountBytes / 8);
   if (has_pred && count_only) {
     const PredNode& n = *range_a;
     const FieldType& f = table->fields[n.column];
@@ -2128,9 +2138,11 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
                       d_scalar.as<unsigned long long>(), range_b ? range_b->cmp_mask : (kLt | kEq | kGt),
                       range_b ? range_b->lit_i64 : 0);
     }
-    PRISM_HIP(hipMemcpyAsync(h_count.data(), d_scalar.p, kCountBytes, hipMemcpyDeviceToHost, ctx->stream));
+    // (into a page-locked block: a copy into pageable memory goes through the runtime's own staging first)
+    std::shared_ptr<void> landing = lease_pinned(ctx, kCountBytes);
+    PRISM_HIP(hipMemcpyAsync(landing.get(), d_scalar.p, kCountBytes, hipMemcpyDeviceToHost, ctx->stream));
     PRISM_HIP(hipStreamSynchronize(ctx->stream));
-    const unsigned long long c = count_total(h_count.data());
+    const unsigned long long c = count_total((const unsigned long long*)landing.get());
     collect_timings(ctx);
     std::vector<OutColumn> cols = make_columns(partial ? plan->partial_fields : plan->final_fields);
     cols[0].push_int((int64_t)c);
@@ -2168,9 +2180,12 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
     sel.bits = pe.eval(plan->pred_root);
     PRISM_HIP(hipMemsetAsync(d_scalar.p, 0, kCountBytes, ctx->stream));
     launch_bitmap_count(ctx, sel.bits.as<uint64_t>(), n_words, d_scalar.as<unsigned long long>());
-    PRISM_HIP(hipMemcpyAsync(h_count.data(), d_scalar.p, kCountBytes, hipMemcpyDeviceToHost, ctx->stream));
-    PRISM_HIP(hipStreamSynchronize(ctx->stream));
-    sel.count = selected = count_total(h_count.data());
+    {
+      std::shared_ptr<void> landing = lease_pinned(ctx, kCountBytes);  // (page-locked: see table_flag)
+      PRISM_HIP(hipMemcpyAsync(landing.get(), d_scalar.p, kCountBytes, hipMemcpyDeviceToHost, ctx->stream));
+      PRISM_HIP(hipStreamSynchronize(ctx->stream));
+      sel.count = selected = count_total((const unsigned long long*)landing.get());
+    }
     // COUNT(*) alone is the number of TRUE rows: nothing left to aggregate
     bool only_count_star = plan->keys.empty() && !plan->distinct_plan && !capture && !plan->aggs.empty();
     for (const AggPlan& a : plan->aggs) only_count_star = only_count_star && a.func == PRISM_AGG_COUNT_STAR;
