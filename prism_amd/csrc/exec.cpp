@@ -762,9 +762,10 @@ GroupRows table_read(prism_gpu_ctx* ctx, const GroupTable& g, const TopKOrder* o
   PRISM_HIP(hipMemsetAsync(d_count.p, 0, 8, ctx->stream));
   launch_emit(ctx, g.dense, g.capacity, g.keys.as<uint64_t>(), g.keys_hi.as<uint64_t>(), g.state.as<int64_t>(),
               g.n_slots, nullptr, nullptr, nullptr, 0, d_count.as<unsigned long long>(), order, d_threshold);
-  unsigned long long n = 0;
-  PRISM_HIP(hipMemcpyAsync(&n, d_count.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+  std::shared_ptr<void> n_landing = lease_pinned(ctx, 64);  // (page-locked: see table_flag)
+  PRISM_HIP(hipMemcpyAsync(n_landing.get(), d_count.p, 8, hipMemcpyDeviceToHost, ctx->stream));
   PRISM_HIP(hipStreamSynchronize(ctx->stream));
+  const unsigned long long n = *(const volatile unsigned long long*)n_landing.get();
   rows.n = n;
   if (n == 0) return rows;
   Scratch d_keys(ctx, n * 8), d_state(ctx, n * 8 * g.n_slots), d_keys_hi;
@@ -2268,8 +2269,10 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       ap.overflow = gt.overflow.as<uint32_t>();
       if (fused) PRISM_HIP(hipMemsetAsync(d_scalar.p, 0, kCountBytes, ctx->stream));
       launch_group_by(ctx, ap, agg_bytes, "agg_global");
-      std::vector<int64_t> both((size_t)ap.n_slots * 2);  // entry 0 and the unused extra entry of every slot
-      PRISM_HIP(hipMemcpyAsync(both.data(), gt.state.p, both.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+      // entry 0 and the unused extra entry of every slot (into page-locked memory: see table_flag)
+      std::shared_ptr<void> both_landing = lease_pinned(ctx, (size_t)ap.n_slots * 16);
+      const int64_t* both = (const int64_t*)both_landing.get();
+      PRISM_HIP(hipMemcpyAsync(both_landing.get(), gt.state.p, (size_t)ap.n_slots * 16, hipMemcpyDeviceToHost, ctx->stream));
       if (fused) PRISM_HIP(hipMemcpyAsync(fused_slot(), d_scalar.p, kCountBytes, hipMemcpyDeviceToHost, ctx->stream));
       PRISM_HIP(hipStreamSynchronize(ctx->stream));
       for (int s = 0; s < ap.n_slots; ++s) g.state[s] = both[(size_t)s * 2];
