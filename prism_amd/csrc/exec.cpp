@@ -1185,9 +1185,9 @@ bool wc_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggParams& ap, 
     list.keys = Scratch(ctx, (list_cap + 1) * 8);
     list.state = Scratch(ctx, (list_cap + 1) * 8);
     list.overflow = Scratch(ctx, 256);
-    PRISM_HIP(hipMemsetAsync(list.overflow.p, 0, 4, ctx->stream));
-    PRISM_HIP(hipMemsetAsync(w.s_keys, 0xff, n_cm * 8, ctx->stream));
-    PRISM_HIP(hipMemsetAsync(w.s_cnt, 0, n_cm * 4 + (size_t)wc_hot_slots() * 8 + 64, ctx->stream));
+    // (one launch instead of three fills)
+    launch_wc_clear(ctx, (unsigned long long*)w.s_keys, n_cm, (unsigned long long*)w.s_cnt, (n_cm * 4 + (size_t)wc_hot_slots() * 8 + 64) / 8,
+                    list.overflow.as<uint32_t>());
     w.list_keys = list.keys.as<uint64_t>();
     w.list_state = list.state.as<int64_t>();
     w.list_capacity = list_cap;

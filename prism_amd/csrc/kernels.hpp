@@ -315,6 +315,8 @@ uint32_t wc_hot_slots();
 uint32_t wc_max_candidates();
 uint64_t wc_sample_counters();
 void launch_wc_group_by(prism_gpu_ctx* ctx, const AggParams& p, const WcParams& w, uint64_t key_bytes);
+// ones[0..n_ones) = all ones, zeros[0..n_zeros) = 0 (8-byte words), *flag = 0: what launch_wc_group_by expects on entry
+void launch_wc_clear(prism_gpu_ctx* ctx, unsigned long long* ones, uint64_t n_ones, unsigned long long* zeros, uint64_t n_zeros, uint32_t* flag);
 
 // COUNT(DISTINCT x) GROUP BY k over two-word (x, k) pairs whose set is far too large for one
 // level of buckets: the records, already sorted into coarse buckets by a hash of k, are

@@ -647,6 +647,23 @@ uint32_t wc_hot_slots() { return kWcHotSlots; }
 uint32_t wc_max_candidates() { return kWcMaxCand; }
 uint64_t wc_sample_counters() { return 1ull << kWcCmBits; }
 
+// What the passes expect on entry, in one launch: the sample's keys all ones, its counts and the
+// small counters behind them zero, the list's flag word zero.
+__global__ __launch_bounds__(256) void k_wc_clear(unsigned long long* ones, uint64_t n_ones, unsigned long long* zeros, uint64_t n_zeros,
+                                                  uint32_t* flag) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && flag) *flag = 0u;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_ones + n_zeros; i += (uint64_t)gridDim.x * 256) {
+    if (i < n_ones) ones[i] = ~0ull;
+    else zeros[i - n_ones] = 0ull;
+  }
+}
+
+void launch_wc_clear(prism_gpu_ctx* ctx, unsigned long long* ones, uint64_t n_ones, unsigned long long* zeros, uint64_t n_zeros, uint32_t* flag) {
+  const uint32_t grid = (uint32_t)std::min<uint64_t>(ceil_div(n_ones + n_zeros, (uint64_t)256 * 8), (uint64_t)ctx->n_cus * 8);
+  k_wc_clear<<<dim3(std::max(1u, grid)), dim3(256), 0, ctx->stream>>>(ones, n_ones, zeros, n_zeros, flag);
+  PRISM_HIP(hipGetLastError());
+}
+
 void launch_wc_group_by(prism_gpu_ctx* ctx, const AggParams& p, const WcParams& w, uint64_t key_bytes) {
   if (!wc_plan_fits(p)) fail(PRISM_GPU_EINTERNAL, "plan shape does not fit the histogram-free GROUP BY");
   if (w.n_wg == 0 || (uint64_t)w.n_wg * w.tiles_per_wg < p.sd.n_tiles || w.cap_shift < 3 || w.cap_shift > 28 ||
