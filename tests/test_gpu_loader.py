@@ -254,3 +254,45 @@ def test_packed_indices_beyond_the_dictionary_are_refused(gpu_ctx):
         assert g.num_rows == n and g.num_partitions == 1
     finally:
         g.close()
+
+
+def test_hostile_run_headers_of_packed_indices_are_refused(gpu_ctx):
+    """The loader keeps a string chunk's dictionary indices as the file's RLE / bit-packed runs
+    (no NULLs in the chunk): a run header whose group count wraps the byte count, and a run
+    that claims bytes beyond its page, are EINVAL there as they are in the host reader."""
+    import numpy as np
+
+    from prism_amd.engine import PrismGpuError, Table
+    from tests.test_parquet_reader import _first_data_page, _page_header_fields, _write
+
+    rng = np.random.default_rng(5)
+    t = pa.table({"s": pa.array([f"v{int(i):03d}" for i in rng.integers(0, 200, 5000)])},
+                 schema=pa.schema([pa.field("s", pa.string(), nullable=False)]))
+    good = _write(t, data_page_version="1.0", compression="none", use_dictionary=True)
+    _, body = _page_header_fields(good, _first_data_page(good))
+
+    def with_header(width, header):
+        data = bytearray(good)
+        data[body] = width
+        p = body + 1
+        while True:
+            b = header & 0x7F
+            header >>= 7
+            data[p] = b | (0x80 if header else 0)
+            p += 1
+            if not header:
+                return bytes(data)
+
+    g = Table(gpu_ctx, t.schema)
+    try:
+        g.append_parquet(0, good)
+        assert g.num_rows == 5000
+        for bad in (with_header(32, ((1 << 59) << 1) | 1),   # 2^59 groups of 32 bits: the byte count wraps to zero
+                    with_header(8, ((1 << 20) << 1) | 1),    # a bit-packed run far longer than the page
+                    with_header(8, 0 << 1)):                 # an empty RLE run
+            with pytest.raises(PrismGpuError) as e:
+                g.append_parquet(1, bad)
+            assert e.value.code == -1, e.value.msg
+        assert g.num_rows == 5000 and g.num_partitions == 1
+    finally:
+        g.close()
