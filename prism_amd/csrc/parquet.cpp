@@ -19,6 +19,8 @@
 #include <string>
 #include <vector>
 
+#include <unordered_map>
+
 #include "engine.hpp"
 
 namespace prism {
@@ -267,7 +269,15 @@ void snappy_decompress(const uint8_t* src, size_t n, std::vector<uint8_t>& out, 
   Thrift v{src, src + n};
   const uint64_t total = v.varint();
   if (total != expect) bad("Snappy block announces another size than the page header");
-  out.resize((size_t)total);
+  // Sixteen bytes of slack behind the block: short literals and copies are moved as two 8-byte words
+  // whatever their length (what they write beyond it is overwritten by the next element, or cut off
+  // at the end).  Sorted timestamps compress into a copy of five or six bytes and a literal of two
+  // or three per value: with a library call per element, millions of them per column chunk, this
+  // loop was most of the loader's time.
+  constexpr size_t kSlack = 16;
+  out.resize((size_t)total + kSlack);
+  uint8_t* const dst = out.data();
+  const size_t cap = (size_t)total;
   const uint8_t* p = v.p;
   const uint8_t* end = src + n;
   size_t o = 0;
@@ -283,8 +293,13 @@ void snappy_decompress(const uint8_t* src, size_t n, std::vector<uint8_t>& out, 
         p += extra;
       }
       l += 1;
-      if ((size_t)(end - p) < l || o + l > out.size()) bad("Snappy literal overruns");
-      std::memcpy(&out[o], p, l);
+      if ((size_t)(end - p) < l || o + l > cap) bad("Snappy literal overruns");
+      if (l <= 16 && (size_t)(end - p) >= 16) {
+        std::memcpy(dst + o, p, 8);
+        std::memcpy(dst + o + 8, p + 8, 8);
+      } else {
+        std::memcpy(dst + o, p, l);
+      }
       p += l;
       o += l;
     } else {
@@ -304,13 +319,21 @@ void snappy_decompress(const uint8_t* src, size_t n, std::vector<uint8_t>& out, 
         off = (size_t)p[0] | ((size_t)p[1] << 8) | ((size_t)p[2] << 16) | ((size_t)p[3] << 24);
         p += 4;
       }
-      if (off == 0 || off > o || o + l > out.size()) bad("Snappy copy out of range");
-      if (off >= l) std::memcpy(&out[o], &out[o - off], l);
-      else for (size_t i = 0; i < l; ++i) out[o + i] = out[o - off + i];  // overlapping: byte by byte
+      if (off == 0 || off > o || o + l > cap) bad("Snappy copy out of range");
+      uint8_t* d = dst + o;
+      const uint8_t* s = d - off;
+      if (off >= 8) {
+        // word by word, front to back: a word read behind the ones just written sees them, as a copy that overlaps itself must
+        // (l <= 64: at most 7 bytes beyond it are written, inside the slack)
+        for (size_t i = 0; i < l; i += 8) std::memcpy(d + i, s + i, 8);
+      } else {
+        for (size_t i = 0; i < l; ++i) d[i] = s[i];  // a pattern shorter than a word: byte by byte
+      }
       o += l;
     }
   }
-  if (o != out.size()) bad("Snappy block shorter than announced");
+  if (o != cap) bad("Snappy block shorter than announced");
+  out.resize(cap);
 }
 
 // ---- RLE / bit-packed hybrid ------------------------------------------------------------------
@@ -402,10 +425,98 @@ void rle_runs(const uint8_t* p, const uint8_t* end, int bit_width, size_t count,
   }
 }
 
+// ---- page-locked blocks for the decoded values of large column chunks ---------------------------
+// The loader (table_append_parquet) decodes a fixed-width column chunk straight into page-locked
+// memory: table_append then hands such a buffer to the copy engine as it is, where a pageable one
+// goes through the context's staging ring first -- one thread at a time copying at memcpy speed,
+// which for sixteen files appended at once was as long as their decode.  The blocks are kept
+// for the next chunk (at most kMaxRetained bytes of them); the host-only reader never asks.
+struct PinnedBlocks {
+  static constexpr size_t kMaxRetained = 2ull << 30;
+  static constexpr size_t kMinBytes = 1u << 20;
+  std::mutex mu;
+  std::unordered_map<size_t, std::vector<void*>> free_blocks;  // by size class
+  std::unordered_map<void*, size_t> out;                       // handed out: block -> size class
+  size_t retained = 0;
+  static size_t size_class(size_t bytes) {
+    size_t c = kMinBytes;
+    while (c < bytes) c <<= 1;
+    return c;
+  }
+  void* take(size_t bytes) {
+    const size_t cls = size_class(bytes);
+    {
+      std::lock_guard<std::mutex> g(mu);
+      auto it = free_blocks.find(cls);
+      if (it != free_blocks.end() && !it->second.empty()) {
+        void* p = it->second.back();
+        it->second.pop_back();
+        retained -= cls;
+        out.emplace(p, cls);
+        return p;
+      }
+    }
+    void* p = nullptr;
+    if (hipHostMalloc(&p, cls, hipHostMallocDefault) != hipSuccess || !p) {
+      (void)hipGetLastError();  // (no page-locked memory to be had: the caller takes ordinary memory)
+      return nullptr;
+    }
+    std::lock_guard<std::mutex> g(mu);
+    out.emplace(p, cls);
+    return p;
+  }
+  // false: not one of ours
+  bool give(void* p) {
+    size_t cls;
+    {
+      std::lock_guard<std::mutex> g(mu);
+      auto it = out.find(p);
+      if (it == out.end()) return false;
+      cls = it->second;
+      out.erase(it);
+      if (retained + cls <= kMaxRetained) {
+        free_blocks[cls].push_back(p);
+        retained += cls;
+        return true;
+      }
+    }
+    (void)hipHostFree(p);
+    return true;
+  }
+};
+PinnedBlocks& pinned_blocks() {
+  static PinnedBlocks* pool = new PinnedBlocks();  // (never destroyed: no HIP call from a static destructor)
+  return *pool;
+}
+thread_local bool tls_pin_values = false;  // set by the loader's decode threads
+
+template <typename T>
+struct ValuesAlloc {
+  using value_type = T;
+  ValuesAlloc() = default;
+  template <typename U>
+  ValuesAlloc(const ValuesAlloc<U>&) {}
+  T* allocate(size_t n) {
+    const size_t bytes = n * sizeof(T);
+    if (tls_pin_values && bytes >= PinnedBlocks::kMinBytes)
+      if (void* p = pinned_blocks().take(bytes)) return (T*)p;
+    void* p = std::malloc(bytes ? bytes : 1);
+    if (!p) throw std::bad_alloc();
+    return (T*)p;
+  }
+  void deallocate(T* p, size_t) {
+    if (!pinned_blocks().give(p)) std::free(p);
+  }
+  template <typename U>
+  bool operator==(const ValuesAlloc<U>&) const { return true; }
+  template <typename U>
+  bool operator!=(const ValuesAlloc<U>&) const { return false; }
+};
+
 // ---- one column of one row group ----------------------------------------------------------------
 struct PqColumn {
   FieldType type;
-  std::vector<uint8_t> values;    // fixed width: type.width bytes per row
+  std::vector<uint8_t, ValuesAlloc<uint8_t>> values;  // fixed width: type.width bytes per row (the loader's: page-locked when large)
   std::vector<int32_t> offsets;   // strings: rows + 1
   std::vector<uint8_t> bytes;
   std::vector<uint8_t> validity;  // bit per row, all rows present
@@ -627,8 +738,9 @@ void decode_chunk(const uint8_t* file, size_t len, const Leaf& leaf, const Chunk
         rle_runs(vals + 1, vals_end, vals[0], present, (uint64_t)seen, dict.size(), col.runs, col.packed);
       } else {
         rle_decode(vals + 1, vals_end, vals[0], present, idx);
-        for (uint32_t k : idx)
-          if (k >= dict.size()) bad("dictionary index out of range in `" + leaf.name + "`");
+        uint32_t largest = 0;
+        for (uint32_t k : idx) largest = k > largest ? k : largest;
+        if (!idx.empty() && largest >= dict.size()) bad("dictionary index out of range in `" + leaf.name + "`");
       }
     }
     if (present == n) set_bits(col.validity, seen, (int64_t)n);
@@ -685,6 +797,17 @@ void decode_chunk(const uint8_t* file, size_t len, const Leaf& leaf, const Chunk
       if (!by_dict && (uint64_t)(vals_end - p) / (uint64_t)pw < (uint64_t)present) bad("page of `" + leaf.name + "` ends inside a value");
       if (!by_dict && dense && divisor == 1 && pw == w) {
         std::memcpy(out, p, n * (size_t)w);  // PLAIN values of the column's own width, none missing
+      } else if (by_dict && dense && divisor == 1 && (w == 8 || w == 4)) {
+        // dictionary indices, none missing: a plain gather (the general loop below, with its branches
+        // per row, took 15 ns a row: as long as everything else of the column chunk together)
+        const int64_t* d = dict.ints.data();
+        const uint32_t* ix = idx.data();
+        if (w == 8) {
+          int64_t* o64 = (int64_t*)out;  // (the column's buffer is a byte vector: 8-byte stores through memcpy)
+          for (size_t i = 0; i < n; ++i) { const int64_t v = d[ix[i]]; std::memcpy(o64 + i, &v, 8); }
+        } else {
+          for (size_t i = 0; i < n; ++i) { const int32_t v = (int32_t)d[ix[i]]; std::memcpy(out + i * 4, &v, 4); }
+        }
       } else {
         for (size_t i = 0; i < n; ++i) {
           if (!dense && !def[i]) continue;
@@ -895,6 +1018,8 @@ void table_append_parquet(prism_gpu_table* table, uint32_t partition_id, const v
     std::mutex err_mu;
     std::unique_ptr<Error> err;
     auto decode_columns = [&]() {
+      tls_pin_values = true;
+      struct Unpin { ~Unpin() { tls_pin_values = false; } } unpin;
       for (;;) {
         const size_t f = next.fetch_add(1);
         if (f >= table->fields.size()) return;

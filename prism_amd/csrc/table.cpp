@@ -295,7 +295,18 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
   if (n > 0x1fffffff) fail(PRISM_GPU_EUNSUPPORTED, "a chunk may hold at most 2^29-1 rows");
 
   auto t0 = std::chrono::steady_clock::now();
-  std::lock_guard<std::mutex> g(t->mu);
+  // Bytes that travel straight from the batches' own (page-locked) buffers must have left them before
+  // the batches go: an event behind this append's work, waited for once the locks are released --
+  // callers that append from several threads then queue their copies while this one's are under way.
+  struct DirectDone {
+    hipEvent_t ev = nullptr;
+    ~DirectDone() {
+      if (!ev) return;
+      (void)hipEventSynchronize(ev);
+      (void)hipEventDestroy(ev);
+    }
+  } direct_done;  // (declared in front of the locks: its wait runs after they are released, and before the batches' release)
+  std::unique_lock<std::mutex> g(t->mu);
   Chunk ch;
   ch.partition_id = partition_id;
   ch.rows = (uint64_t)n;
@@ -313,7 +324,7 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
   } guard{t, &ch};
   init_stats(t, ch, t->fields.size());
 
-  std::lock_guard<std::mutex> stage_lock(ctx->stage_mu);
+  std::unique_lock<std::mutex> stage_lock(ctx->stage_mu);
   ensure_stage_ring(ctx);
   StageWriter w(ctx);
   for (size_t ci = 0; ci < t->fields.size(); ++ci) {
@@ -672,7 +683,10 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
   // The bytes are in pinned memory or on their way: the batches can go.  The copies are
   // awaited where the chunk's statistics are read (table_sync_stats), before any scan.
   // (Bytes that travel straight from the batches' own buffers must have left them first.)
-  if (w.direct) PRISM_HIP(hipStreamSynchronize(ctx->copy_stream));
+  if (w.direct) {
+    PRISM_HIP(hipEventCreateWithFlags(&direct_done.ev, hipEventDisableTiming));
+    PRISM_HIP(hipEventRecord(direct_done.ev, ctx->copy_stream));
+  }
   {
     std::lock_guard<std::mutex> gs(ctx->mu);
     ctx->stats.staging_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -680,6 +694,9 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
   }
   guard.armed = false;
   t->chunks.push_back(std::move(ch));
+  stage_lock.unlock();
+  g.unlock();
+  // (direct_done waits here, on the way out)
 }
 
 void table_append(prism_gpu_table* t, uint32_t partition_id, ArrowArray* batch, bool take) {
