@@ -457,7 +457,7 @@ struct PinnedBlocks {
       }
     }
     void* p = nullptr;
-    if (hipHostMalloc(&p, cls, hipHostMallocDefault) != hipSuccess || !p) {
+    if (hipHostMalloc(&p, cls, hipHostMallocPortable) != hipSuccess || !p) {
       (void)hipGetLastError();  // (no page-locked memory to be had: the caller takes ordinary memory)
       return nullptr;
     }
@@ -1018,6 +1018,8 @@ void table_append_parquet(prism_gpu_table* table, uint32_t partition_id, const v
     std::mutex err_mu;
     std::unique_ptr<Error> err;
     auto decode_columns = [&]() {
+      // (the thread's page-locked blocks belong with the table's GPU: helper threads start on device 0)
+      if (hipSetDevice(table->ctx->device) != hipSuccess) (void)hipGetLastError();
       tls_pin_values = true;
       struct Unpin { ~Unpin() { tls_pin_values = false; } } unpin;
       for (;;) {
