@@ -62,6 +62,8 @@ int prism_gpu_init(int device_ordinal, prism_gpu_ctx** out) {
     prism::noalloc_init(device_ordinal);
     PRISM_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     PRISM_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    PRISM_HIP(hipStreamCreateWithFlags(&ctx->direct_stream, hipStreamNonBlocking));
+    PRISM_HIP(hipEventCreateWithFlags(&ctx->stream_join, hipEventDisableTiming));
     *out = ctx.release();
   });
 }

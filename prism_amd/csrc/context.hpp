@@ -31,7 +31,12 @@ struct PinnedPool {
 struct prism_gpu_ctx {
   int device = 0;
   hipStream_t stream = nullptr;       // compute
-  hipStream_t copy_stream = nullptr;  // host <-> HBM staging
+  hipStream_t copy_stream = nullptr;  // host <-> HBM staging: the pinned ring's copies and the loader's kernels
+  // Large copies that read the caller's own page-locked buffers, and the statistics kernels over
+  // what they bring: apart, so that nothing waiting for a small copy waits for them.  Work on it
+  // may wait for copy_stream (through stream_join), never the other way round within an append.
+  hipStream_t direct_stream = nullptr;
+  hipEvent_t stream_join = nullptr;  // (under stage_mu)
   int n_cus = 256;
   size_t lds_per_block_max = 65536;
 
@@ -52,11 +57,15 @@ struct prism_gpu_ctx {
   void* stage[2] = {nullptr, nullptr};
   hipEvent_t stage_done[2] = {nullptr, nullptr};
   bool stage_used[2] = {false, false};
-  int stage_next = 0;
+  int stage_cur = -1;     // the half being filled
+  size_t stage_fill = 0;  // ... and how far
   // device scratch of the loader's kernels (under stage_mu; grown on demand, reused by the next
   // append: every use is ordered on copy_stream)
   void* load_tmp = nullptr;
   size_t load_tmp_bytes = 0;
+  // where the loader reads a few bytes back (page-locked: a copy into ordinary memory takes a
+  // detour through the runtime's own staging; under stage_mu, allocated with the ring)
+  void* load_landing = nullptr;
 
   // ---- child contexts: same device, streams / ring / pool / statistics of their own ----
   prism_gpu_ctx* parent = nullptr;
@@ -111,6 +120,7 @@ inline void ensure_stage_ring(prism_gpu_ctx* ctx) {
   for (int i = 0; i < 2; ++i) {
     if (!ctx->stage[i]) PRISM_HIP(hipHostMalloc(&ctx->stage[i], ctx->stage_bytes, hipHostMallocDefault));
     if (!ctx->stage_done[i]) PRISM_HIP(hipEventCreateWithFlags(&ctx->stage_done[i], hipEventDisableTiming));
+    if (!ctx->load_landing) PRISM_HIP(hipHostMalloc(&ctx->load_landing, 64, hipHostMallocDefault));
   }
 }
 
@@ -243,6 +253,13 @@ struct HostTimer {
     if (i >= 0) { ctx->stats.kernels[i].launches += 1; ctx->stats.kernels[i].total_ms += ms; }
   }
 };
+
+// Everything the loader has queued: the small copies and its kernels, then the large direct copies.
+inline hipError_t sync_copy_streams(prism_gpu_ctx* ctx) {
+  hipError_t a = ctx->copy_stream ? hipStreamSynchronize(ctx->copy_stream) : hipSuccess;
+  hipError_t b = ctx->direct_stream ? hipStreamSynchronize(ctx->direct_stream) : hipSuccess;
+  return a != hipSuccess ? a : b;
+}
 
 // Call after the stream has been synchronised: folds event pairs into the stats.
 inline void collect_timings(prism_gpu_ctx* ctx) {

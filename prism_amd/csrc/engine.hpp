@@ -62,6 +62,17 @@ struct prism_gpu_table {
   std::deque<prism::Chunk> chunks;
   std::vector<prism::ColumnDict> dicts;  // one per column (used by string columns)
   std::mutex mu;  // appends hold it throughout; scans while they collect their chunks
+  // Column buffers of middling size are cut from slabs: obtaining 8-16 MiB from the runtime
+  // costs ~0.12 ms a time (and ~0.15 ms to return), a few hundred MiB a third of that, and a
+  // loader appends a few such buffers per row group.  A slab goes back once every buffer cut
+  // from it has been freed (the chunks of a dropped partition, mostly neighbours in a slab).
+  struct Slab {
+    uint8_t* base = nullptr;
+    size_t size = 0, used = 0;
+    uint32_t live = 0;  // buffers cut from it and not yet freed
+  };
+  std::vector<Slab> slabs;  // (the last one is the one being filled)
+  std::mutex slab_mu;
   ~prism_gpu_table();
 };
 

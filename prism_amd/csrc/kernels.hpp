@@ -629,6 +629,10 @@ struct ColStats {
   unsigned long long null_count;
 };
 // Folds min/max/null count of `rows` values into *stats (device; initialised by the caller).
+// Page-locked host memory -> HBM by a kernel that reads the host's memory where it is: for the
+// loader's small copies, which as copy-engine commands would queue behind the tens of megabytes
+// of column values that the same engine moves.  src and dst must agree modulo 16.
+void launch_stage_copy(prism_gpu_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t stream);
 void launch_col_stats(prism_gpu_ctx* ctx, const void* values, const uint64_t* validity, int width, bool is_unsigned,
                       uint64_t rows, ColStats* stats, hipStream_t stream);
 
@@ -647,6 +651,11 @@ struct DictExpand {
   int32_t* offsets;
   uint8_t* bytes;
   uint32_t* block_sums;  // dict_expand_blocks(rows) words of scratch
+  // launch_dict_lens, optional: two words in page-locked host memory that receive *flag_in (0
+  // without one) and the bytes' total, so that a caller who must know them before going on
+  // awaits the stream and no copy besides.
+  const uint32_t* flag_in = nullptr;
+  uint32_t* report = nullptr;
 };
 // codes[r] (an index into the dictionary of r's batch) becomes remap[seg_base[s] + codes[r]], s the
 // segment of row r (seg_row: first rows, ascending, seg_row[0] == 0); NULL rows become 0.

@@ -20,14 +20,43 @@ __global__ __launch_bounds__(kBlock) void k_col_stats(const void* values, const 
     mn = v < mn ? v : mn;
     mx = v > mx ? v : mx;
   }
+  // One set of atomics per workgroup: they all go to one address, where the memory side takes
+  // them one at a time -- a set per wave made them the whole cost of the kernel.
+  __shared__ long long s_mn[kBlock / 64], s_mx[kBlock / 64];
+  __shared__ unsigned long long s_nulls[kBlock / 64];
   mn = wave_min_i64(mn);
   mx = wave_max_i64(mx);
   nulls = wave_sum_u64(nulls);
   if ((threadIdx.x & 63) == 0) {
-    atomicMin(&stats->min, mn);
-    atomicMax(&stats->max, mx);
+    s_mn[threadIdx.x >> 6] = mn;
+    s_mx[threadIdx.x >> 6] = mx;
+    s_nulls[threadIdx.x >> 6] = nulls;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kBlock / 64; ++w) {
+      mn = s_mn[w] < mn ? s_mn[w] : mn;
+      mx = s_mx[w] > mx ? s_mx[w] : mx;
+      nulls += s_nulls[w];
+    }
+    if (mn <= mx) {
+      atomicMin(&stats->min, mn);
+      atomicMax(&stats->max, mx);
+    }
     if (nulls) atomicAdd(&stats->null_count, nulls);
   }
+}
+
+// dst and src agree modulo 16: bytes up to the first 16-byte boundary, whole vectors, the tail.
+__global__ __launch_bounds__(kBlock) void k_stage_copy(uint8_t* dst, const uint8_t* src, uint64_t bytes) {
+  const uint64_t head = min((uint64_t)((16 - ((uintptr_t)dst & 15)) & 15), bytes), vecs = (bytes - head) >> 4;
+  const uint64_t tid = (uint64_t)blockIdx.x * kBlock + threadIdx.x, stride = (uint64_t)gridDim.x * kBlock;
+  const uint4* s = (const uint4*)(src + head);
+  uint4* d = (uint4*)(dst + head);
+  for (uint64_t i = tid; i < vecs; i += stride) d[i] = s[i];
+  if (tid < head) dst[tid] = src[tid];
+  const uint64_t tail0 = head + (vecs << 4);
+  if (tail0 + tid < bytes && tid < 16) dst[tail0 + tid] = src[tail0 + tid];
 }
 
 __global__ __launch_bounds__(kBlock) void k_synth(SynthColDev c, uint64_t first_row, uint64_t n_rows,
@@ -107,7 +136,14 @@ __global__ __launch_bounds__(kDictThreads) void k_dict_scan(DictExpand q, uint32
     q.block_sums[b] = at;
     at += v;
   }
-  if (threadIdx.x == 0) q.offsets[q.rows] = (int32_t)total;
+  if (threadIdx.x == 0) {
+    q.offsets[q.rows] = (int32_t)total;
+    if (q.report) {
+      q.report[0] = q.flag_in ? *q.flag_in : 0u;
+      q.report[1] = total;
+      __threadfence_system();
+    }
+  }
 }
 
 __global__ __launch_bounds__(kDictThreads) void k_dict_expand(DictExpand q) {
@@ -236,10 +272,18 @@ void launch_synth_url(prism_gpu_ctx* ctx, const int32_t* offsets, uint8_t* bytes
   PRISM_HIP(hipGetLastError());
 }
 
+void launch_stage_copy(prism_gpu_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t stream) {
+  if (bytes == 0) return;
+  if ((((uintptr_t)dst ^ (uintptr_t)src) & 15) != 0) fail(PRISM_GPU_EINTERNAL, "stage copy between addresses that disagree modulo 16");
+  uint32_t grid = (uint32_t)std::min<uint64_t>(ceil_div((uint64_t)bytes, (uint64_t)kBlock * 16 * 4), (uint64_t)ctx->n_cus * 4);
+  k_stage_copy<<<dim3(std::max(1u, grid)), dim3(kBlock), 0, stream>>>((uint8_t*)dst, (const uint8_t*)src, (uint64_t)bytes);
+  PRISM_HIP(hipGetLastError());
+}
+
 void launch_col_stats(prism_gpu_ctx* ctx, const void* values, const uint64_t* validity, int width, bool is_unsigned,
                       uint64_t rows, ColStats* stats, hipStream_t stream) {
   if (rows == 0) return;
-  uint32_t grid = (uint32_t)std::min<uint64_t>(ceil_div(rows, (uint64_t)kBlock * 8), (uint64_t)ctx->n_cus * 8);
+  uint32_t grid = (uint32_t)std::min<uint64_t>(ceil_div(rows, (uint64_t)kBlock * 8), (uint64_t)ctx->n_cus * 2);
   k_col_stats<<<dim3(std::max(1u, grid)), dim3(kBlock), 0, stream>>>(values, validity, width, is_unsigned ? 1 : 0, rows,
                                                                    stats);
   PRISM_HIP(hipGetLastError());

@@ -57,6 +57,8 @@ prism_gpu_ctx* ctx_acquire_child(prism_gpu_ctx* parent) {
   copy_options(c.get(), parent);
   PRISM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   PRISM_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  PRISM_HIP(hipStreamCreateWithFlags(&c->direct_stream, hipStreamNonBlocking));
+  PRISM_HIP(hipEventCreateWithFlags(&c->stream_join, hipEventDisableTiming));
   return c.release();
 }
 
@@ -93,7 +95,7 @@ void ctx_destroy(prism_gpu_ctx* ctx) {
   for (prism_gpu_ctx* c : ctx->idle_children) ctx_destroy(c);
   ctx->idle_children.clear();
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+  (void)sync_copy_streams(ctx);
   for (auto& kv : ctx->free_blocks) (void)hipFree(kv.second);
   for (auto& kv : ctx->live_blocks) (void)hipFree(kv.first);
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
@@ -103,9 +105,12 @@ void ctx_destroy(prism_gpu_ctx* ctx) {
     if (ctx->stage_done[i]) (void)hipEventDestroy(ctx->stage_done[i]);
   }
   if (ctx->load_tmp) (void)hipFree(ctx->load_tmp);
+  if (ctx->load_landing) (void)hipHostFree(ctx->load_landing);
   if (ctx->result_pinned) (void)hipHostFree(ctx->result_pinned);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+  if (ctx->direct_stream) (void)hipStreamDestroy(ctx->direct_stream);
+  if (ctx->stream_join) (void)hipEventDestroy(ctx->stream_join);
   delete ctx;
 }
 

@@ -33,19 +33,61 @@ namespace {
 
 // Device memory of a table's columns: a plain allocation, or (tables that come and go,
 // like the chunks of a streaming partition) a block of the context's scratch pool.
+// Requests below kSlabMin are cheap as they are (the runtime cuts them from blocks of its own),
+// those of kSlabMax and above cost one runtime call each whatever their size.
+constexpr size_t kSlabMin = 256u << 10, kSlabMax = 64u << 20, kSlabFirst = 32u << 20, kSlabLargest = 512u << 20;
+
 void* dev_alloc(prism_gpu_table* t, size_t bytes) {
   // slack: kernels read whole 16-byte vectors (plus one dword) at the tail
   const size_t padded = round_up(bytes, 256) + 256;
   if (t->pooled) return alloc_scratch(t->ctx, padded);
   void* p = nullptr;
-  PRISM_HIP(hipMalloc(&p, padded));
+  if (padded < kSlabMin || padded >= kSlabMax) {
+    PRISM_HIP(hipMalloc(&p, padded));
+    return p;
+  }
+  std::lock_guard<std::mutex> g(t->slab_mu);
+  if (t->slabs.empty() || t->slabs.back().size - t->slabs.back().used < padded) {
+    // the slab being filled has no room (what is left of it stays unused): the next one is twice as large
+    if (!t->slabs.empty() && t->slabs.back().live == 0) {
+      (void)hipFree(t->slabs.back().base);
+      t->slabs.pop_back();
+    }
+    size_t size = kSlabFirst;
+    for (const auto& sl : t->slabs) size = std::max(size, std::min(kSlabLargest, sl.size * 2));
+    size = std::max(size, padded);
+    PRISM_HIP(hipMalloc(&p, size));
+    prism_gpu_table::Slab sl;
+    sl.base = (uint8_t*)p;
+    sl.size = size;
+    t->slabs.push_back(sl);
+  }
+  prism_gpu_table::Slab& sl = t->slabs.back();
+  p = sl.base + sl.used;
+  sl.used += padded;
+  sl.live += 1;
   return p;
 }
 
 void dev_free(prism_gpu_table* t, void* p) {
   if (!p) return;
-  if (t->pooled) free_scratch(t->ctx, p);
-  else (void)hipFree(p);
+  if (t->pooled) { free_scratch(t->ctx, p); return; }
+  {
+    std::lock_guard<std::mutex> g(t->slab_mu);
+    for (size_t i = 0; i < t->slabs.size(); ++i) {
+      prism_gpu_table::Slab& sl = t->slabs[i];
+      if ((uint8_t*)p < sl.base || (uint8_t*)p >= sl.base + sl.size) continue;
+      if (--sl.live != 0) return;
+      if (i + 1 == t->slabs.size()) {
+        sl.used = 0;  // the slab being filled starts over
+      } else {
+        (void)hipFree(sl.base);
+        t->slabs.erase(t->slabs.begin() + (ptrdiff_t)i);
+      }
+      return;
+    }
+  }
+  (void)hipFree(p);
 }
 
 // Bytes into the pinned ring.  The host never reads them back (the copy engine does), so they
@@ -74,21 +116,43 @@ inline void copy_into_ring(uint8_t* d, const uint8_t* s, size_t n) {
 }
 
 // Host -> HBM through the pinned ring: bytes are gathered into a pinned half (they may come
-// from many small Arrow buffers) and leave with one copy per half while the other half
-// fills.  A half is reused only after the copy that read it has completed (its event); the
+// from many small Arrow buffers) and leave with one copy per destination, or per half, while
+// the gathering goes on.  A half is reused only after the copies that read it have completed (its event); the
 // ring belongs to one context, and a context stages for one thread at a time (ctx->stage_mu).
 struct StageWriter {
   prism_gpu_ctx* ctx;
   uint8_t* dst = nullptr;  // device address the next flushed byte goes to
-  int half = -1;
-  size_t fill = 0;
+  int half = -1;             // the ring half being filled (-1: none taken yet, or since the last flush)
+  size_t start = 0, fill = 0;  // bytes [start, fill) of it are gathered and not yet on their way
   uint64_t staged = 0;  // bytes handed to the copy stream; the owner adds them to the statistics under ctx->mu
   bool direct = false;  // some bytes travel straight from the caller's (pinned) buffers: await the stream before those may go
+  // Those bytes travel on a stream of their own (ctx->direct_stream): tens of megabytes at a
+  // time, and whatever waits for a small copy on copy_stream (the reuse of a ring half, a
+  // total read back in the middle of an append) would otherwise wait for them as well.
+  bool direct_pending = false;  // ... and some of them since new_column(): see join() and reader_stream()
   explicit StageWriter(prism_gpu_ctx* c) : ctx(c) {}
+  void new_column() { flush(); direct_pending = false; }
+  // In front of kernels on copy_stream that read what was written since new_column().
+  void join() {
+    flush();
+    if (!direct_pending) return;
+    PRISM_HIP(hipEventRecord(ctx->stream_join, ctx->direct_stream));
+    PRISM_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->stream_join, 0));
+    direct_pending = false;
+  }
+  // The stream for a kernel that reads what was written since new_column() and whose results
+  // nothing on copy_stream waits for: the direct stream, once it has seen the small copies.
+  hipStream_t reader_stream() {
+    flush();
+    if (!direct_pending) return ctx->copy_stream;
+    PRISM_HIP(hipEventRecord(ctx->stream_join, ctx->copy_stream));
+    PRISM_HIP(hipStreamWaitEvent(ctx->direct_stream, ctx->stream_join, 0));
+    return ctx->direct_stream;
+  }
   // Large buffers that already are page-locked memory of this process (the PARTIAL batches this
   // library hands out are; so is whatever a caller allocated with hipHostMalloc) need no second
   // host copy: the copy engine reads them where they are.
-  static constexpr size_t kDirectMinBytes = 1u << 20;
+  static constexpr size_t kDirectMinBytes = 1u << 20, kKernelCopyMaxBytes = 8u << 20;
   static bool page_locked(const void* p) {
     hipPointerAttribute_t at;
     if (hipPointerGetAttributes(&at, p) != hipSuccess) {
@@ -98,41 +162,67 @@ struct StageWriter {
     return at.type == hipMemoryTypeHost;
   }
   void begin(void* device_dst) { flush(); dst = (uint8_t*)device_dst; }
-  void acquire() {
-    half = ctx->stage_next;
-    ctx->stage_next ^= 1;
+  // The half being filled is filled on, flush after flush, until it is full: only then is its
+  // event recorded and the other half taken (whose event, by then, is long past -- waiting for
+  // an event that has not completed costs tens of microseconds however short the wait).
+  void open() {
+    if (ctx->stage_cur < 0) ctx->stage_cur = 0;
+    half = ctx->stage_cur;
+    start = fill = ctx->stage_fill;
+    if (fill == ctx->stage_bytes) next_half();
+  }
+  void next_half() {
+    PRISM_HIP(hipEventRecord(ctx->stage_done[half], ctx->copy_stream));
+    ctx->stage_used[half] = true;
+    half ^= 1;
     if (ctx->stage_used[half]) PRISM_HIP(hipEventSynchronize(ctx->stage_done[half]));
-    fill = 0;
+    ctx->stage_cur = half;
+    ctx->stage_fill = start = fill = 0;
   }
   void write(const void* src, size_t bytes) {
     const uint8_t* s = (const uint8_t*)src;
     if (bytes >= kDirectMinBytes && page_locked(src)) {
       flush();
-      PRISM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+      PRISM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->direct_stream));
+      direct_pending = true;
       staged += bytes;
       dst += bytes;
       direct = true;
       return;
     }
     while (bytes) {
-      if (half < 0) acquire();
+      if (half < 0) open();
       const size_t room = ctx->stage_bytes - fill, n = bytes < room ? bytes : room;
       copy_into_ring((uint8_t*)ctx->stage[half] + fill, s, n);
       fill += n;
       s += n;
       bytes -= n;
-      if (fill == ctx->stage_bytes) flush();
+      if (fill == ctx->stage_bytes) {
+        send();
+        next_half();
+      }
     }
   }
+  // queues the copy of what has been gathered since the last one
+  void send() {
+    if (fill == start) return;
+    const uint8_t* from = (const uint8_t*)ctx->stage[half] + start;
+    // Small amounts are fetched by a kernel: as commands of the copy engine they would wait
+    // their turn behind the direct copies, and so would whoever awaits copy_stream.
+    if (fill - start <= kKernelCopyMaxBytes && (((uintptr_t)dst ^ (uintptr_t)from) & 15) == 0)
+      launch_stage_copy(ctx, dst, from, fill - start, ctx->copy_stream);
+    else
+      PRISM_HIP(hipMemcpyAsync(dst, from, fill - start, hipMemcpyHostToDevice, ctx->copy_stream));
+    staged += fill - start;
+    dst += fill - start;
+    start = fill;
+  }
   void flush() {
-    if (half < 0 || fill == 0) { return; }
-    PRISM_HIP(hipMemcpyAsync(dst, ctx->stage[half], fill, hipMemcpyHostToDevice, ctx->copy_stream));
-    PRISM_HIP(hipEventRecord(ctx->stage_done[half], ctx->copy_stream));
-    ctx->stage_used[half] = true;
-    staged += fill;
-    dst += fill;
+    if (half < 0) return;
+    send();
+    // (the next gather starts on a line of its own)
+    ctx->stage_fill = std::min(ctx->stage_bytes, round_up(fill, 256));
     half = -1;
-    fill = 0;
   }
 };
 
@@ -142,7 +232,7 @@ void stage_copy(prism_gpu_ctx* ctx, void* dst, const void* src, size_t bytes) {
   StageWriter w(ctx);
   w.begin(dst);
   w.write(src, bytes);
-  w.flush();
+  w.join();  // (callers order their kernels on copy_stream)
   std::lock_guard<std::mutex> gs(ctx->mu);
   ctx->stats.bytes_staged += w.staged;
 }
@@ -207,8 +297,9 @@ void free_chunk_memory(prism_gpu_table* t, Chunk& ch) {
 prism_gpu_table::~prism_gpu_table() {
   if (ctx) (void)hipSetDevice(ctx->device);
   // copies and statistics kernels of recent appends may still be reading or writing the buffers
-  if (ctx && ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+  if (ctx) (void)prism::sync_copy_streams(ctx);
   for (auto& ch : chunks) prism::free_chunk_memory(this, ch);
+  for (auto& sl : slabs) (void)hipFree(sl.base);
 }
 
 namespace prism {
@@ -318,18 +409,20 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
     bool armed = true;
     ~ChunkGuard() {
       if (!armed) return;
-      (void)hipStreamSynchronize(t->ctx->copy_stream);  // copies into the chunk may be under way
+      (void)sync_copy_streams(t->ctx);  // copies into the chunk may be under way
       free_chunk_memory(t, *ch);
     }
   } guard{t, &ch};
   init_stats(t, ch, t->fields.size());
 
   std::unique_lock<std::mutex> stage_lock(ctx->stage_mu);
+  HostTimer locked_timer(ctx, "host:append_locked");  // (the part of an append that callers on other threads wait for)
   ensure_stage_ring(ctx);
   StageWriter w(ctx);
   for (size_t ci = 0; ci < t->fields.size(); ++ci) {
     const FieldType& f = t->fields[ci];
     DeviceColumn& dc = ch.cols[ci];
+    w.new_column();
     // ---- validity: one bitmap for the chunk, present only if some row is NULL ----
     bool any_null = false;
     for (size_t b = 0; b < n_batches && !any_null; ++b) {
@@ -366,8 +459,7 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
         if (a->n_buffers < 2 || !a->buffers[1]) fail(PRISM_GPU_EINVAL, "column " + f.name + " has no value buffer");
         w.write((const uint8_t*)a->buffers[1] + (size_t)a->offset * f.width, (size_t)a->length * f.width);
       }
-      w.flush();
-      launch_col_stats(ctx, dc.values, dc.validity, f.width, f.is_unsigned, (uint64_t)n, &ch.d_stats[ci], ctx->copy_stream);
+      launch_col_stats(ctx, dc.values, dc.validity, f.width, f.is_unsigned, (uint64_t)n, &ch.d_stats[ci], w.reader_stream());
       continue;
     }
     // ---- string column: raw representation + table-wide dictionary codes ----
@@ -458,7 +550,7 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
           for (int64_t k = 0; k < d->length; ++k) remap[(size_t)k] = dict.id_of(dbytes + doff[k], (size_t)(doff[k + 1] - doff[k]));
         }
         if (device_expand) {
-          if (cat_off.empty()) { cat_off.push_back(0); index.resize((size_t)n); }
+          if (cat_off.empty()) cat_off.push_back(0);
           const uint64_t base = cat_off.size() - 1;
           if (base + (uint64_t)d->length >= 0xffffffffull) fail(PRISM_GPU_EUNSUPPORTED, "the dictionaries of one chunk of " + f.name + " hold 2^32 entries or more");
           uint64_t longest = 0;
@@ -480,6 +572,7 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
             continue;
           }
           need_idx();
+          if (index.empty()) index.resize((size_t)n);  // (rows of packed batches: written on the device, after this has been copied)
           const uint32_t* len_at = cat_off.data() + base;
           for (int64_t i = 0; i < nb; ++i) {
             const bool valid = !vbits || bit_at(vbits, a->offset + i);
@@ -570,7 +663,7 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
       w.write(remap_all.data(), remap_all.size() * 4);
       w.begin(dc.codes);
       for (const Piece& pc : pieces) w.write(pc.p, pc.n);
-      w.flush();
+      w.join();
       launch_dict_codes(ctx, dc.codes, dc.validity, (uint64_t)n, (const uint32_t*)tmp, (const uint32_t*)(tmp + base_at), (uint32_t)n_segs,
                         (const uint32_t*)(tmp + remap_at), ctx->copy_stream);
       launch_col_stats(ctx, dc.codes, dc.validity, 4, true, (uint64_t)n, &ch.d_stats[ci], ctx->copy_stream);
@@ -586,9 +679,13 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
         packed_need += pad(pb.pk->n_runs * sizeof(PackedRun)) + pad(pb.pk->n_bytes);
         packed_rows += pb.rows;
       }
-      const size_t off_at = 0, remap_at = off_at + pad(cat_off.size() * 4), sums_at = remap_at + pad(n_ent * 4),
-                   dbytes_at = sums_at + pad(n_blocks * 4), index_at = dbytes_at + pad((size_t)cat_off.back()),
-                   packed_at = index_at + pad(dict.alive ? 0 : (size_t)n * 4), need = packed_at + packed_need;
+      // What the host provides lies end to end at the front of the scratch and leaves with one
+      // copy: the dictionaries' offsets, their codes, their bytes, a flag and a spare word (zero),
+      // every packed batch's runs and bytes.  What only kernels write follows.
+      const size_t remap_bytes = dict.alive ? n_ent * 4 : 0;
+      const size_t off_at = 0, remap_at = off_at + pad(cat_off.size() * 4), dbytes_at = remap_at + pad(remap_bytes),
+                   packed_at = dbytes_at + pad((size_t)cat_off.back()), sums_at = packed_at + packed_need,
+                   index_at = sums_at + pad(n_blocks * 4), need = index_at + pad(dict.alive ? 0 : (size_t)n * 4);
       uint8_t* tmp = (uint8_t*)load_scratch(ctx, need);
       dc.values = dev_alloc(t, ((size_t)n + 1) * 4);
       if (packed_batches.empty()) {
@@ -596,33 +693,39 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
         dc.n_bytes = total;
       }
       if (dict.alive) dc.codes = (uint32_t*)dev_alloc(t, (size_t)n * 4);
-      w.begin(tmp + off_at);
-      w.write(cat_off.data(), cat_off.size() * 4);
-      if (dict.alive) {
-        w.begin(tmp + remap_at);
-        w.write(remap_all.data(), n_ent * 4);
+      static const uint8_t zeros[16] = {0};
+      size_t pos = 0;
+      auto put = [&](const void* p, size_t bytes) {  // ... and zeros up to the next multiple of 16
+        if (bytes) w.write(p, bytes);
+        pos += bytes;
+        if (pad(pos) != pos) {
+          w.write(zeros, pad(pos) - pos);
+          pos = pad(pos);
+        }
+      };
+      w.begin(tmp);
+      put(cat_off.data(), cat_off.size() * 4);
+      if (dict.alive) put(remap_all.data(), n_ent * 4);
+      for (const Piece& pc : pieces) {
+        w.write(pc.p, pc.n);
+        pos += pc.n;
       }
-      w.begin(tmp + dbytes_at);
-      for (const Piece& pc : pieces) w.write(pc.p, pc.n);
+      put(nullptr, 0);
+      put(zeros, 16);
+      std::vector<size_t> runs_at;
+      for (const PackedBatch& pb : packed_batches) {
+        runs_at.push_back(pos);
+        put(pb.pk->runs, pb.pk->n_runs * sizeof(PackedRun));
+        put(pb.pk->bytes, pb.pk->n_bytes);
+      }
+      if (pos != sums_at) fail(PRISM_GPU_EINTERNAL, "the loader's scratch is laid out otherwise than it was sized");
       uint32_t* d_index = dict.alive ? dc.codes : (uint32_t*)(tmp + index_at);
       if (packed_rows < (uint64_t)n) {
         w.begin(d_index);
         w.write(index.data(), (size_t)n * 4);
       }
-      size_t at = packed_at + 16;
-      std::vector<size_t> runs_at;
-      for (const PackedBatch& pb : packed_batches) {
-        runs_at.push_back(at);
-        w.begin(tmp + at);
-        w.write(pb.pk->runs, pb.pk->n_runs * sizeof(PackedRun));
-        at += pad(pb.pk->n_runs * sizeof(PackedRun));
-        w.begin(tmp + at);
-        w.write(pb.pk->bytes, pb.pk->n_bytes);
-        at += pad(pb.pk->n_bytes);
-      }
-      w.flush();
+      w.join();
       uint32_t* d_flag = (uint32_t*)(tmp + packed_at);
-      if (!packed_batches.empty()) PRISM_HIP(hipMemsetAsync(d_flag, 0, 16, ctx->copy_stream));
       for (size_t k = 0; k < packed_batches.size(); ++k) {
         const PackedBatch& pb = packed_batches[k];
         const uint8_t* d_runs = tmp + runs_at[k];
@@ -642,11 +745,12 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
       if (packed_batches.empty()) {
         launch_dict_expand(ctx, q, ctx->copy_stream);
       } else {
-        // the bytes' total is only known on the device: it sizes the column's buffer
+        // the bytes' total is only known on the device: it sizes the column's buffer (the scan
+        // kernel leaves it, and the flag, in page-locked memory)
+        volatile uint32_t* back = (volatile uint32_t*)ctx->load_landing;
+        q.flag_in = d_flag;
+        q.report = (uint32_t*)ctx->load_landing;
         launch_dict_lens(ctx, q, ctx->copy_stream);
-        PRISM_HIP(hipMemcpyAsync(d_flag + 1, (const int32_t*)dc.values + n, 4, hipMemcpyDeviceToDevice, ctx->copy_stream));
-        uint32_t back[2] = {0, 0};
-        PRISM_HIP(hipMemcpyAsync(back, d_flag, 8, hipMemcpyDeviceToHost, ctx->copy_stream));
         PRISM_HIP(hipStreamSynchronize(ctx->copy_stream));
         if (back[0]) fail(PRISM_GPU_EINVAL, "dictionary index out of range in " + f.name);
         total = back[1];
@@ -671,11 +775,11 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
       dc.codes = (uint32_t*)dev_alloc(t, (size_t)n * 4);
       w.begin(dc.codes);
       w.write(codes.data(), (size_t)n * 4);
-      w.flush();
+      w.join();
       launch_col_stats(ctx, dc.codes, dc.validity, 4, true, (uint64_t)n, &ch.d_stats[ci], ctx->copy_stream);
     } else {
       // no codes: the offsets stand in as values so that the NULL count is still recorded
-      w.flush();
+      w.join();
       launch_col_stats(ctx, dc.values, dc.validity, 4, true, (uint64_t)n, &ch.d_stats[ci], ctx->copy_stream);
     }
   }
@@ -685,7 +789,7 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
   // (Bytes that travel straight from the batches' own buffers must have left them first.)
   if (w.direct) {
     PRISM_HIP(hipEventCreateWithFlags(&direct_done.ev, hipEventDisableTiming));
-    PRISM_HIP(hipEventRecord(direct_done.ev, ctx->copy_stream));
+    PRISM_HIP(hipEventRecord(direct_done.ev, ctx->direct_stream));
   }
   {
     std::lock_guard<std::mutex> gs(ctx->mu);
@@ -831,8 +935,8 @@ void table_device_dictionary(prism_gpu_table* t, int ci) {
   for (const Chunk& ch : t->chunks) complete = complete && (ch.rows == 0 || ch.cols[(size_t)ci].codes != nullptr);
   if (complete) return;
   HostTimer timer(ctx, "host:device_dictionary");
-  // the chunks' copies run on the staging stream; the kernels below on the compute stream
-  PRISM_HIP(hipStreamSynchronize(ctx->copy_stream));
+  // the chunks' copies run on the staging streams; the kernels below on the compute stream
+  PRISM_HIP(sync_copy_streams(ctx));
   std::vector<StrSeg> segs;
   std::vector<Chunk*> seg_chunks;
   uint64_t n_rows = 0, col_bytes = 0;
@@ -913,8 +1017,8 @@ void table_sync_stats(prism_gpu_table* t) {
   bool waited = false;
   for (auto& ch : t->chunks) {
     if (ch.stats_ready) continue;
-    // the chunk's copies and statistics kernels run on the staging stream
-    if (!waited) { PRISM_HIP(hipStreamSynchronize(t->ctx->copy_stream)); waited = true; }
+    // the chunk's copies and statistics kernels run on the staging streams
+    if (!waited) { PRISM_HIP(sync_copy_streams(t->ctx)); waited = true; }
     PRISM_HIP(hipMemcpy(ch.stats.data(), ch.d_stats, ch.stats.size() * sizeof(ColStats), hipMemcpyDeviceToHost));
     ch.stats_ready = true;
   }

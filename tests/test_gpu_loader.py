@@ -296,3 +296,59 @@ def test_hostile_run_headers_of_packed_indices_are_refused(gpu_ctx):
         assert g.num_rows == 5000 and g.num_partitions == 1
     finally:
         g.close()
+
+
+@pytest.mark.gpu
+def test_column_buffers_of_middling_size_survive_a_refused_append(gpu_ctx):
+    """Column buffers between a few hundred KiB and tens of MiB are cut from slabs the table
+    owns; an append that is refused half way (its string column's indices point past the
+    dictionary, after the fixed-width columns have their buffers) gives its buffers back, and the
+    appends before and after it still answer as the oracle does."""
+    import io
+
+    import numpy as np
+
+    from oracle import pyoracle
+    from prism_amd.engine import Plan, PrismGpuError, Table
+
+    rng = np.random.default_rng(11)
+    names = [f"svc-{i:02d}" for i in range(23)]
+    n = 300_000
+
+    def part(k):
+        codes = rng.integers(0, len(names), n).astype(np.int32)
+        return pa.table({"timestamp": pa.array(1_700_000_000_000 + (np.arange(n, dtype=np.int64) + k * n) * 7, pa.timestamp("ms")),
+                         "service": pa.DictionaryArray.from_arrays(pa.array(codes), pa.array(names)).cast(pa.string()),
+                         "value": pa.array(rng.integers(-1000, 1000, n, dtype=np.int64))})
+
+    def file_of(t):
+        sink = io.BytesIO()
+        pq.write_table(t, sink, compression="none", use_dictionary=True, data_page_version="1.0", write_statistics=False)
+        return bytearray(sink.getvalue())
+
+    query = QueryPlan([count_star(), sum_("value"), max_("timestamp")], keys=["service"])
+    good = [part(k) for k in range(5)]
+    schema = pa.schema([("timestamp", pa.timestamp("ms")), ("service", pa.string()), ("value", pa.int64())])
+    g = Table(gpu_ctx, schema)
+    plan = Plan(gpu_ctx, schema, query)
+    try:
+        for k in range(3):
+            g.append_parquet(k, bytes(file_of(good[k])))
+        bad = file_of(part(9))
+        # 23 names, five bits an index: bytes of ones inside the service column's packed indices are indices of 31
+        chunk = pq.ParquetFile(io.BytesIO(bytes(bad))).metadata.row_group(0).column(1)
+        assert chunk.path_in_schema == "service"
+        for pos in range(chunk.data_page_offset + 2000, chunk.data_page_offset + 2005):
+            bad[pos] = 0xFF
+        with pytest.raises(PrismGpuError) as e:
+            g.append_parquet(7, bytes(bad))
+        assert "index out of range" in e.value.msg
+        assert g.num_rows == 3 * n
+        for k in range(3, 5):
+            g.append_parquet(k, bytes(file_of(good[k])))
+        got = plan.execute(g)
+        want = pyoracle.execute(pa.concat_tables(good), query)
+        assert_tables_match(got, want, 1)
+    finally:
+        plan.close()
+        g.close()
