@@ -395,7 +395,7 @@ def main() -> int:
                     help="merge between GPUs: device-resident group tables (state) or PARTIAL Arrow batches (arrow); "
                          "auto = state when the plan allows it.  With one GPU, state/arrow run the same code in a "
                          "one-rank group (to measure the exchange's overhead)")
-    ap.add_argument("--parquet-threads", type=int, default=4, help="--feed parquet: threads decoding the column chunks of one file")
+    ap.add_argument("--parquet-threads", type=int, default=1, help="--feed parquet: threads decoding the column chunks of one file")
     ap.add_argument("--feed", default="resident", choices=["resident", "stream", "parquet"],
                     help="resident: partitions already in HBM when the timed region starts (the headline value). "
                          "stream: host Arrow batches of 8192 rows pushed through prism_gpu_push_batch on one thread "
