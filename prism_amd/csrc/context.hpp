@@ -37,6 +37,7 @@ struct prism_gpu_ctx {
   // may wait for copy_stream (through stream_join), never the other way round within an append.
   hipStream_t direct_stream = nullptr;
   hipEvent_t stream_join = nullptr;  // (under stage_mu)
+  bool direct_seen = false;          // this context has sent such copies (under stage_mu)
   int n_cus = 256;
   size_t lds_per_block_max = 65536;
 

@@ -152,7 +152,7 @@ struct StageWriter {
   // Large buffers that already are page-locked memory of this process (the PARTIAL batches this
   // library hands out are; so is whatever a caller allocated with hipHostMalloc) need no second
   // host copy: the copy engine reads them where they are.
-  static constexpr size_t kDirectMinBytes = 1u << 20, kKernelCopyMaxBytes = 8u << 20;
+  static constexpr size_t kDirectMinBytes = 1u << 20, kKernelCopyMaxBytes = 8u << 20, kKernelCopyAlwaysBytes = 1u << 20;
   static bool page_locked(const void* p) {
     hipPointerAttribute_t at;
     if (hipPointerGetAttributes(&at, p) != hipSuccess) {
@@ -184,6 +184,7 @@ struct StageWriter {
     if (bytes >= kDirectMinBytes && page_locked(src)) {
       flush();
       PRISM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->direct_stream));
+      ctx->direct_seen = true;
       direct_pending = true;
       staged += bytes;
       dst += bytes;
@@ -209,7 +210,10 @@ struct StageWriter {
     const uint8_t* from = (const uint8_t*)ctx->stage[half] + start;
     // Small amounts are fetched by a kernel: as commands of the copy engine they would wait
     // their turn behind the direct copies, and so would whoever awaits copy_stream.
-    if (fill - start <= kKernelCopyMaxBytes && (((uintptr_t)dst ^ (uintptr_t)from) & 15) == 0)
+    // (Megabytes at a time are the copy engine's to move when nothing else occupies it: the
+    // chunks of a streaming feed, all of which come through the ring.)
+    const size_t by_kernel = ctx->direct_seen ? kKernelCopyMaxBytes : kKernelCopyAlwaysBytes;
+    if (fill - start <= by_kernel && (((uintptr_t)dst ^ (uintptr_t)from) & 15) == 0)
       launch_stage_copy(ctx, dst, from, fill - start, ctx->copy_stream);
     else
       PRISM_HIP(hipMemcpyAsync(dst, from, fill - start, hipMemcpyHostToDevice, ctx->copy_stream));
