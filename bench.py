@@ -37,6 +37,11 @@ PCIE_BOUND_GBS = 64.0  # PCIe 5.0 x16, one direction
 
 
 def stream_feed(args) -> int:
+    print(json.dumps(stream_feed_line(args)), flush=True)
+    return 0
+
+
+def stream_feed_line(args) -> dict:
     """End-to-end figure: the native feeder (tests/c/stream_bench.cpp, one thread per partition
     as DataFusion polls them) pushes host Arrow batches through the C ABI; nothing is resident
     beforehand.  The rate is bounded by PCIe, not HBM, and priced against that."""
@@ -79,8 +84,7 @@ def stream_feed(args) -> int:
                     "staging_thread_ms_per_step": m["staging_thread_ms_last_step"]},
         "cpu_baseline": None,
     }
-    print(json.dumps(line), flush=True)
-    return 0
+    return line
 
 
 DOMINANT = {"C1": "filter_count", "C2": "group_by", "C3": "group_by", "C4": "like_contains", "C4G": "like_contains", "C5": "group_by"}
@@ -277,6 +281,11 @@ def check_launch(args) -> int:
 
 
 def parquet_feed(args) -> int:
+    print(json.dumps(parquet_feed_line(args)), flush=True)
+    return 0
+
+
+def parquet_feed_line(args) -> dict:
     """Loader figure: files shaped like prism-ingest's (data page v2, dictionary with PLAIN
     fallback, Snappy, one file per partition; src/prism-ingest/src/ingest.rs:98-119) sit in host
     memory, as after an object-store GET; prism_gpu_table_append_parquet decodes them (library
@@ -373,8 +382,33 @@ def parquet_feed(args) -> int:
                    "parity": "C2 result over the loaded rows equals the CPU oracle's over the same rows"},
         "cpu_baseline": None,
     }
-    print(json.dumps(line), flush=True)
-    return 0
+    return line
+
+
+def extra_feeds(args) -> dict:
+    """The two ways rows reach HBM from outside, a few steps each, for the default run's record:
+    host Arrow batches streamed through the C ABI (C2, 10^9 rows, PCIe-bound) and Parquet files
+    decoded by the library (C2-shaped, 32e6 rows).  A feed that fails is recorded as such."""
+    import copy
+
+    out = {}
+    for name, fn, over in (("stream_C2", stream_feed_line, {"feed": "stream", "steps": 3, "rows": 0}),
+                           ("parquet_C2", parquet_feed_line, {"feed": "parquet", "steps": 5, "warmup": 2, "rows": 0, "partitions": 0})):
+        a = copy.copy(args)
+        for k, v in over.items():
+            setattr(a, k, v)
+        t0 = time.time()
+        try:
+            line = fn(a)
+            out[name] = {k: line[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "config") if k in line}
+            for k in ("staging", "loader"):
+                if k in line:
+                    out[name][k] = line[k]
+        except (Exception, SystemExit) as e:  # noqa: BLE001  (the headline must still be printed)
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+        out[name]["wall_s"] = round(time.time() - t0, 1)
+        log(f"[feeds] {name}: {json.dumps(out[name])[:600]}")
+    return out
 
 
 def main() -> int:
@@ -408,7 +442,7 @@ def main() -> int:
                     help="only bring the ranks up (gloo rendezvous + one all-reduce, no GPU) and print what met; "
                          "lets a box without GPUs check that --gpus N starts N ranks")
     ap.add_argument("--no-extra-workloads", action="store_true",
-                    help="skip the `workloads` object (C1, C3, C4, C5 run for a few steps after the headline's timed region)")
+                    help="skip the `workloads` and `feeds` objects (C1, C3, C4, C5 and the two feeds run for a few steps after the headline's timed region)")
     args = ap.parse_args()
     if args.feed == "stream":
         return stream_feed(args)
@@ -616,6 +650,7 @@ def main() -> int:
             table.close()
             single = table = None
             line["workloads"] = extra_workloads(ctx, steps=5, warmup=3)
+            line["feeds"] = extra_feeds(args)
         print(json.dumps(line), file=json_out, flush=True)
 
     if comm is not None:
