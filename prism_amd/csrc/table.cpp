@@ -423,8 +423,12 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
   HostTimer locked_timer(ctx, "host:append_locked");  // (the part of an append that callers on other threads wait for)
   ensure_stage_ring(ctx);
   StageWriter w(ctx);
-  for (size_t ci = 0; ci < t->fields.size(); ++ci) {
+  // String columns first: theirs are the small copies (and, for packed indices, a wait for a
+  // total from the device) that should not stand behind this chunk's own blocks of values.
+  for (size_t turn = 0; turn < 2 * t->fields.size(); ++turn) {
+    const size_t ci = turn % t->fields.size();
     const FieldType& f = t->fields[ci];
+    if (f.is_string != (turn < t->fields.size())) continue;
     DeviceColumn& dc = ch.cols[ci];
     w.new_column();
     // ---- validity: one bitmap for the chunk, present only if some row is NULL ----
