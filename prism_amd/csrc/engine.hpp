@@ -79,9 +79,15 @@ struct prism_gpu_table {
 namespace prism {
 
 // Appends one RecordBatch.  `take` = release the array when done (moved), else borrow.
-void table_append(prism_gpu_table* t, uint32_t partition_id, ArrowArray* batch, bool take);
+// Bytes of page-locked buffers leave them by copies that may still be under way when the rows are
+// in the table's books: with `pending` null the call waits for them before it returns (and before
+// it releases a batch it took); otherwise, when such copies were queued, *pending receives an event
+// behind them -- the caller keeps the batch (take must be false), awaits and destroys the event, and
+// only then releases the batch.  A loader decodes its next row group meanwhile.
+void table_append(prism_gpu_table* t, uint32_t partition_id, ArrowArray* batch, bool take, hipEvent_t* pending = nullptr);
 // The same for several batches that become one chunk.
-void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray* const* batches, size_t n_batches, bool take);
+void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray* const* batches, size_t n_batches, bool take,
+                          hipEvent_t* pending = nullptr);
 void free_chunk_memory(prism_gpu_table* t, Chunk& ch);
 void table_synth(prism_gpu_table* t, uint32_t partition_id, uint64_t seed, uint64_t first_row, uint64_t n_rows,
                  uint64_t total_rows, const prism_gpu_synth_col* cols, uint32_t n_cols);

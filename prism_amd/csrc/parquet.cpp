@@ -12,6 +12,7 @@
 // (nested columns, other physical types, encodings or codecs) is PRISM_GPU_EUNSUPPORTED and
 // names the column.
 #include <atomic>
+#include <deque>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -265,7 +266,17 @@ FieldType leaf_field(const Leaf& l) {
 }
 
 // ---- Snappy (raw block format) --------------------------------------------------------------
+// Into dst, where `expect` bytes and kSnappySlack more may be written.
+constexpr size_t kSnappySlack = 16;
+void snappy_decompress_to(const uint8_t* src, size_t n, uint8_t* dst, size_t expect);
+
 void snappy_decompress(const uint8_t* src, size_t n, std::vector<uint8_t>& out, size_t expect) {
+  out.resize(expect + kSnappySlack);
+  snappy_decompress_to(src, n, out.data(), expect);
+  out.resize(expect);
+}
+
+void snappy_decompress_to(const uint8_t* src, size_t n, uint8_t* const dst, size_t expect) {
   Thrift v{src, src + n};
   const uint64_t total = v.varint();
   if (total != expect) bad("Snappy block announces another size than the page header");
@@ -274,9 +285,6 @@ void snappy_decompress(const uint8_t* src, size_t n, std::vector<uint8_t>& out, 
   // at the end).  Sorted timestamps compress into a copy of five or six bytes and a literal of two
   // or three per value: with a library call per element, millions of them per column chunk, this
   // loop was most of the loader's time.
-  constexpr size_t kSlack = 16;
-  out.resize((size_t)total + kSlack);
-  uint8_t* const dst = out.data();
   const size_t cap = (size_t)total;
   const uint8_t* p = v.p;
   const uint8_t* end = src + n;
@@ -333,7 +341,6 @@ void snappy_decompress(const uint8_t* src, size_t n, std::vector<uint8_t>& out, 
     }
   }
   if (o != cap) bad("Snappy block shorter than announced");
-  out.resize(cap);
 }
 
 // ---- RLE / bit-packed hybrid ------------------------------------------------------------------
@@ -507,6 +514,12 @@ struct ValuesAlloc {
   void deallocate(T* p, size_t) {
     if (!pinned_blocks().give(p)) std::free(p);
   }
+  // resize() leaves new elements uninitialised (the decoder writes every row it reports);
+  // assign(n, 0) and the like still store what they are given
+  template <typename U>
+  void construct(U* p) noexcept { ::new ((void*)p) U; }
+  template <typename U, typename... A>
+  void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
   template <typename U>
   bool operator==(const ValuesAlloc<U>&) const { return true; }
   template <typename U>
@@ -634,7 +647,7 @@ void decode_chunk(const uint8_t* file, size_t len, const Leaf& leaf, const Chunk
     if (as_index) col.index.reserve((size_t)rows);
     else { col.offsets.reserve((size_t)rows + 1); col.offsets.push_back(0); }
   } else {
-    col.values.assign((size_t)rows * (size_t)w, 0);  // (NULL rows keep the zero)
+    col.values.resize((size_t)rows * (size_t)w);  // (uninitialised: every page writes its rows, zeros where they are NULL)
   }
   col.validity.assign((size_t)(rows + 7) / 8, 0);
   auto append_string = [&](const uint8_t* p, uint32_t l) {
@@ -657,6 +670,7 @@ void decode_chunk(const uint8_t* file, size_t len, const Leaf& leaf, const Chunk
     const uint8_t* vals_end = nullptr;
     const uint8_t* def_p = nullptr;
     const uint8_t* def_end = nullptr;
+    bool def_ready = false;  // the page's definition levels are in `def` already
     if (h.type == 3) {
       if (h.rep_len != 0) unsupported("repetition levels in `" + leaf.name + "`");
       const int64_t lv = (int64_t)h.def_len + h.rep_len;
@@ -665,7 +679,24 @@ void decode_chunk(const uint8_t* file, size_t len, const Leaf& leaf, const Chunk
       def_end = body + h.def_len;
       const uint8_t* data = body + lv;
       const size_t data_comp = (size_t)(h.compressed - lv), data_raw = (size_t)(h.uncompressed - lv);
-      if (cm.codec == 1 && h.is_compressed && data_raw > 0) {
+      // A page of PLAIN values of the column's own width with no row missing is decompressed
+      // where its values belong (the levels of a v2 page lie in front of the compressed block, so
+      // that is known by now); the decoder's slack falls on the rows of the pages to come.
+      const size_t nv = (size_t)h.num_values;
+      bool in_place = cm.codec == 1 && h.is_compressed && !strings && h.encoding == 0 && divisor == 1 &&
+                      w == (leaf.physical == kInt32 ? 4 : 8) && data_raw > 0 && data_raw == nv * (size_t)w &&
+                      seen + (int64_t)nv <= rows && ((size_t)seen + nv) * (size_t)w + kSnappySlack <= col.values.size();
+      if (in_place && leaf.optional) {
+        rle_decode(def_p, def_end, 1, nv, def);
+        def_ready = true;
+        for (size_t i = 0; i < nv && in_place; ++i) in_place = def[i] != 0;
+      }
+      if (in_place) {
+        uint8_t* out = col.values.data() + (size_t)seen * (size_t)w;
+        snappy_decompress_to(data, data_comp, out, data_raw);
+        vals = out;
+        vals_end = out + data_raw;
+      } else if (cm.codec == 1 && h.is_compressed && data_raw > 0) {
         snappy_decompress(data, data_comp, page, data_raw);
         vals = page.data();
         vals_end = vals + page.size();
@@ -723,7 +754,7 @@ void decode_chunk(const uint8_t* file, size_t len, const Leaf& leaf, const Chunk
     if (seen + (int64_t)n > rows) bad("more values than rows in `" + leaf.name + "`");
     size_t present = n;
     if (leaf.optional) {
-      rle_decode(def_p, def_end, 1, n, def);
+      if (!def_ready) rle_decode(def_p, def_end, 1, n, def);
       present = 0;
       for (size_t i = 0; i < n; ++i) present += def[i];
     }
@@ -796,7 +827,7 @@ void decode_chunk(const uint8_t* file, size_t len, const Leaf& leaf, const Chunk
       uint8_t* out = col.values.data() + (size_t)seen * (size_t)w;
       if (!by_dict && (uint64_t)(vals_end - p) / (uint64_t)pw < (uint64_t)present) bad("page of `" + leaf.name + "` ends inside a value");
       if (!by_dict && dense && divisor == 1 && pw == w) {
-        std::memcpy(out, p, n * (size_t)w);  // PLAIN values of the column's own width, none missing
+        if (p != out) std::memcpy(out, p, n * (size_t)w);  // PLAIN values of the column's own width, none missing (decompressed in place where that could be)
       } else if (by_dict && dense && divisor == 1 && (w == 8 || w == 4)) {
         // dictionary indices, none missing: a plain gather (the general loop below, with its branches
         // per row, took 15 ns a row: as long as everything else of the column chunk together)
@@ -810,7 +841,10 @@ void decode_chunk(const uint8_t* file, size_t len, const Leaf& leaf, const Chunk
         }
       } else {
         for (size_t i = 0; i < n; ++i) {
-          if (!dense && !def[i]) continue;
+          if (!dense && !def[i]) {
+            std::memset(out + i * (size_t)w, 0, (size_t)w);
+            continue;
+          }
           int64_t v;
           if (by_dict) v = dict.ints[idx[k]];
           else if (pw == 4) { int32_t x; std::memcpy(&x, p + k * 4, 4); v = x; }
@@ -1008,6 +1042,26 @@ void table_append_parquet(prism_gpu_table* table, uint32_t partition_id, const v
     if (!same)
       unsupported("column `" + want.name + "` is " + have.format + " in the file and " + want.format + " in the table");
   }
+  constexpr size_t kRowGroupsInFlight = 2;
+  struct InFlight {
+    struct Item {
+      ArrowArray batch{};
+      hipEvent_t copied = nullptr;
+    };
+    std::deque<Item> q;
+    void settle_oldest() {
+      Item& it = q.front();
+      if (it.copied) {
+        (void)hipEventSynchronize(it.copied);
+        (void)hipEventDestroy(it.copied);
+      }
+      if (it.batch.release) it.batch.release(&it.batch);
+      q.pop_front();
+    }
+    ~InFlight() {
+      while (!q.empty()) settle_oldest();
+    }
+  } in_flight;
   for (const RowGroupMeta& rg : fm.groups) {
     if (rg.num_rows == 0) continue;
     std::vector<PqColumn> cols(table->fields.size());
@@ -1058,9 +1112,14 @@ void table_append_parquet(prism_gpu_table* table, uint32_t partition_id, const v
     decode_columns();
     for (std::thread& t : helpers) t.join();
     if (err) throw *err;
-    ArrowArray batch;
-    export_columns(std::move(cols), rg.num_rows, &batch);
-    table_append(table, partition_id, &batch, true);  // moves the batch
+    // The row group's page-locked blocks are read by the copy engine after the append has
+    // returned: the batch is kept until the event behind those copies has passed, and the next
+    // row group is decoded meanwhile (waiting here left the thread idle behind every other
+    // caller's copies, the engine's queue being one).
+    in_flight.q.emplace_back();
+    export_columns(std::move(cols), rg.num_rows, &in_flight.q.back().batch);
+    table_append(table, partition_id, &in_flight.q.back().batch, false, &in_flight.q.back().copied);
+    while (in_flight.q.size() > kRowGroupsInFlight) in_flight.settle_oldest();
   }
 }
 

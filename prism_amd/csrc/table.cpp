@@ -349,9 +349,14 @@ void append_bits(std::vector<uint64_t>& out, uint64_t at, const uint8_t* bits, i
 
 // One chunk from one or more RecordBatches (the batches of a streaming partition arrive
 // 8192 rows at a time; a chunk of them is staged and scanned as one).
-void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray* const* batches, size_t n_batches, bool take) {
+void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray* const* batches, size_t n_batches, bool take,
+                          hipEvent_t* pending) {
   prism_gpu_ctx* ctx = t->ctx;
   bind(ctx);
+  if (pending) {
+    *pending = nullptr;
+    if (take) fail(PRISM_GPU_EINTERNAL, "an append that hands its copies' event over cannot take the batches");
+  }
   struct Releaser {
     ArrowArray* const* b;
     size_t n;
@@ -395,8 +400,13 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
   // callers that append from several threads then queue their copies while this one's are under way.
   struct DirectDone {
     hipEvent_t ev = nullptr;
+    hipEvent_t* hand_over = nullptr;  // (set once the append has succeeded)
     ~DirectDone() {
       if (!ev) return;
+      if (hand_over) {
+        *hand_over = ev;
+        return;
+      }
       (void)hipEventSynchronize(ev);
       (void)hipEventDestroy(ev);
     }
@@ -806,18 +816,20 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
   }
   guard.armed = false;
   t->chunks.push_back(std::move(ch));
+  direct_done.hand_over = pending;
   stage_lock.unlock();
   g.unlock();
   // (direct_done waits here, on the way out)
 }
 
-void table_append(prism_gpu_table* t, uint32_t partition_id, ArrowArray* batch, bool take) {
+void table_append(prism_gpu_table* t, uint32_t partition_id, ArrowArray* batch, bool take, hipEvent_t* pending) {
   ArrowArray* one[1] = {batch};
   constexpr int64_t kMaxChunkRows = 1ll << 28;
   if (!batch || batch->length <= kMaxChunkRows || batch->offset < 0) {
-    table_append_batches(t, partition_id, one, 1, take);
+    table_append_batches(t, partition_id, one, 1, take, pending);
     return;
   }
+  if (pending) *pending = nullptr;  // (several chunks: each waits for its own copies)
   // A batch of more rows than a chunk holds (kernels address a chunk's column with 32-bit byte
   // offsets) becomes several chunks of the partition: row ranges of the same buffers, borrowed.
   struct Releaser {
