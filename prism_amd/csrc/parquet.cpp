@@ -344,10 +344,13 @@ void snappy_decompress_to(const uint8_t* src, size_t n, uint8_t* const dst, size
 }
 
 // ---- RLE / bit-packed hybrid ------------------------------------------------------------------
-// Decodes `count` values of `bit_width` bits from [p, end).
-void rle_decode(const uint8_t* p, const uint8_t* end, int bit_width, size_t count, std::vector<uint32_t>& out) {
-  out.resize(count);
-  if (bit_width == 0) { std::fill(out.begin(), out.end(), 0u); return; }
+// Decodes `count` values of `bit_width` bits from [p, end): emit(i, value) for i = 0 .. count - 1, in order.
+template <typename Emit>
+void rle_decode_each(const uint8_t* p, const uint8_t* end, int bit_width, size_t count, Emit&& emit) {
+  if (bit_width == 0) {
+    for (size_t i = 0; i < count; ++i) emit(i, 0u);
+    return;
+  }
   if (bit_width > 32) bad("bit width above 32");
   size_t n = 0;
   Thrift v{p, end};
@@ -369,13 +372,13 @@ void rle_decode(const uint8_t* p, const uint8_t* end, int bit_width, size_t coun
       for (; i < take && (bitpos >> 3) + 8 <= bytes; ++i, bitpos += bit_width) {
         uint64_t word;
         std::memcpy(&word, b + (bitpos >> 3), 8);
-        out[n++] = (uint32_t)((word >> (bitpos & 7)) & mask);
+        emit(n++, (uint32_t)((word >> (bitpos & 7)) & mask));
       }
       for (; i < take; ++i, bitpos += bit_width) {
         uint64_t word = 0;
         const uint64_t byte0 = bitpos >> 3;
         std::memcpy(&word, b + byte0, (size_t)std::min<uint64_t>(8, bytes - byte0));
-        out[n++] = (uint32_t)((word >> (bitpos & 7)) & mask);
+        emit(n++, (uint32_t)((word >> (bitpos & 7)) & mask));
       }
       v.p += bytes;
     } else {
@@ -384,10 +387,16 @@ void rle_decode(const uint8_t* p, const uint8_t* end, int bit_width, size_t coun
       uint32_t value = 0;
       std::memcpy(&value, v.p, value_bytes);
       v.p += value_bytes;
-      for (uint64_t i = 0; i < run && n < count; ++i) out[n++] = value;
+      for (uint64_t i = 0; i < run && n < count; ++i) emit(n++, value);
       if (run == 0) bad("empty RLE run");
     }
   }
+}
+
+void rle_decode(const uint8_t* p, const uint8_t* end, int bit_width, size_t count, std::vector<uint32_t>& out) {
+  out.resize(count);
+  uint32_t* const o = out.data();
+  rle_decode_each(p, end, bit_width, count, [o](size_t i, uint32_t value) { o[i] = value; });
 }
 
 // The runs of `count` values at [p, end) without expanding them: appended to `runs` (rows from
@@ -759,15 +768,18 @@ void decode_chunk(const uint8_t* file, size_t len, const Leaf& leaf, const Chunk
       for (size_t i = 0; i < n; ++i) present += def[i];
     }
     const bool by_dict = h.encoding == 2 || h.encoding == 8;
+    bool gather_page = false;
     if (!by_dict && h.encoding != 0) unsupported("encoding " + std::to_string(h.encoding) + " in column `" + leaf.name + "`");
     seen_rows = seen;
     const bool pack_page = as_packed && by_dict && present == n;
     if (!pack_page) unpack();
     if (by_dict) {
       if (vals_end - vals < 1) bad("dictionary-encoded page without a bit width");
+      // (integers with no row missing: the indices are decoded and looked up in one pass, further down)
+      gather_page = !strings && present == n && divisor == 1 && (w == 8 || w == 4);
       if (pack_page) {
         rle_runs(vals + 1, vals_end, vals[0], present, (uint64_t)seen, dict.size(), col.runs, col.packed);
-      } else {
+      } else if (!gather_page) {
         rle_decode(vals + 1, vals_end, vals[0], present, idx);
         uint32_t largest = 0;
         for (uint32_t k : idx) largest = k > largest ? k : largest;
@@ -828,17 +840,29 @@ void decode_chunk(const uint8_t* file, size_t len, const Leaf& leaf, const Chunk
       if (!by_dict && (uint64_t)(vals_end - p) / (uint64_t)pw < (uint64_t)present) bad("page of `" + leaf.name + "` ends inside a value");
       if (!by_dict && dense && divisor == 1 && pw == w) {
         if (p != out) std::memcpy(out, p, n * (size_t)w);  // PLAIN values of the column's own width, none missing (decompressed in place where that could be)
-      } else if (by_dict && dense && divisor == 1 && (w == 8 || w == 4)) {
-        // dictionary indices, none missing: a plain gather (the general loop below, with its branches
-        // per row, took 15 ns a row: as long as everything else of the column chunk together)
+      } else if (gather_page) {
+        // dictionary indices, none missing: decoded and looked up in one pass (through a vector of
+        // indices, and with the general loop's branches per row before that, this took as long as
+        // everything else of the column chunk together).  An index beyond the dictionary reads
+        // entry 0 and is reported once the page is through.
+        if (dict.ints.empty()) bad("dictionary index out of range in `" + leaf.name + "`");
         const int64_t* d = dict.ints.data();
-        const uint32_t* ix = idx.data();
+        const uint32_t dn = (uint32_t)std::min<size_t>(dict.ints.size(), 0xffffffffu);
+        uint32_t largest = 0;
         if (w == 8) {
-          int64_t* o64 = (int64_t*)out;  // (the column's buffer is a byte vector: 8-byte stores through memcpy)
-          for (size_t i = 0; i < n; ++i) { const int64_t v = d[ix[i]]; std::memcpy(o64 + i, &v, 8); }
+          rle_decode_each(vals + 1, vals_end, vals[0], n, [&](size_t i, uint32_t k) {
+            largest = k > largest ? k : largest;
+            const int64_t v = d[k < dn ? k : 0];
+            std::memcpy(out + i * 8, &v, 8);  // (the column's buffer is a byte vector: 8-byte stores through memcpy)
+          });
         } else {
-          for (size_t i = 0; i < n; ++i) { const int32_t v = (int32_t)d[ix[i]]; std::memcpy(out + i * 4, &v, 4); }
+          rle_decode_each(vals + 1, vals_end, vals[0], n, [&](size_t i, uint32_t k) {
+            largest = k > largest ? k : largest;
+            const int32_t v = (int32_t)d[k < dn ? k : 0];
+            std::memcpy(out + i * 4, &v, 4);
+          });
         }
+        if (largest >= dn) bad("dictionary index out of range in `" + leaf.name + "`");
       } else {
         for (size_t i = 0; i < n; ++i) {
           if (!dense && !def[i]) {

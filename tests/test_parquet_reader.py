@@ -256,3 +256,20 @@ def test_plain_pages_with_and_without_nulls_in_one_chunk():
             raw = np.frombuffer(col.buffers()[1], dtype=np.int32 if width == 4 else np.int64, count=n, offset=col.offset * width)
             if col.null_count:
                 assert not raw[~np.asarray(col.is_valid())].any(), name
+
+
+@pytest.mark.parametrize("width", [pa.int64(), pa.int32()])
+def test_an_integer_dictionary_index_beyond_the_dictionary_is_einval(width):
+    """Dense dictionary-encoded integer pages are decoded and looked up in one pass; an index
+    past the dictionary must not be read and is EINVAL (200 values: 8-bit indices, so a byte of
+    0xFF among the bit-packed indices is index 255)."""
+    rng = np.random.default_rng(9)
+    t = pa.table({"a": pa.array(rng.integers(0, 200, 5000), type=width)}, schema=pa.schema([pa.field("a", width, nullable=False)]))
+    data = bytearray(_write(t, data_page_version="1.0", compression="none", use_dictionary=True))
+    assert engine.parquet_read(bytes(data)).column("a").combine_chunks().equals(t.column("a").combine_chunks())
+    _, body = _page_header_fields(bytes(data), _first_data_page(bytes(data)))
+    assert data[body] == 8  # the indices' bit width
+    data[body + 1000] = 0xFF
+    with pytest.raises(engine.PrismGpuError) as e:
+        engine.parquet_read(bytes(data))
+    assert e.value.code == abi.EINVAL and "index out of range" in e.value.msg
