@@ -273,3 +273,31 @@ def test_an_integer_dictionary_index_beyond_the_dictionary_is_einval(width):
     with pytest.raises(engine.PrismGpuError) as e:
         engine.parquet_read(bytes(data))
     assert e.value.code == abi.EINVAL and "index out of range" in e.value.msg
+
+
+def test_flipped_bytes_in_the_pages_are_an_error_or_a_decode_never_a_crash():
+    """The reader is reachable from the C ABI with bytes it did not write: bytes of the page area
+    (headers, levels, Snappy blocks, dictionary indices) are overwritten at random, a few per
+    trial; every trial must end in a table of the file's row count or in EINVAL / EUNSUPPORTED."""
+    t = _table(3000, seed=17, nulls=True)
+    cases = [_write(t, data_page_version="2.0", compression="snappy", use_dictionary=True, data_page_size=4096),
+             _write(t, data_page_version="1.0", compression="snappy", use_dictionary=False, data_page_size=4096),
+             _write(t, data_page_version="2.0", compression="none", use_dictionary=True, dictionary_pagesize_limit=2048)]
+    rng = np.random.default_rng(23)
+    outcomes = {"decoded": 0, "refused": 0}
+    for good in cases:
+        md_len = int.from_bytes(good[-8:-4], "little")
+        body_end = len(good) - md_len - 8
+        for _ in range(120):
+            data = bytearray(good)
+            for _ in range(int(rng.integers(1, 4))):
+                at = int(rng.integers(4, body_end))
+                data[at] = int(rng.integers(0, 256))
+            try:
+                got = engine.parquet_read(bytes(data))
+                assert got.num_rows == t.num_rows
+                outcomes["decoded"] += 1
+            except engine.PrismGpuError as err:
+                assert err.code in (abi.EINVAL, abi.EUNSUPPORTED), err.msg
+                outcomes["refused"] += 1
+    assert outcomes["decoded"] and outcomes["refused"], outcomes
