@@ -222,9 +222,24 @@ int prism_gpu_merge(prism_gpu_plan* plan, struct ArrowArray* const* states, size
       return;
     }
     auto table = new_table(plan->ctx, plan->partial_fields);
+    // Page-locked states (the ones this library hands out are) are read by the copy engine where
+    // they lie: the appends only queue those copies, one behind the other, and the events behind
+    // them are awaited once, before the states go back to the caller (the execution below has
+    // waited for the copies anyway).
+    struct Pending {
+      std::vector<hipEvent_t> events;
+      ~Pending() {
+        for (hipEvent_t e : events) {
+          (void)hipEventSynchronize(e);
+          (void)hipEventDestroy(e);
+        }
+      }
+    } pending;
     for (size_t i = 0; i < n_states; ++i) {
       require(states[i] != nullptr, "null state array");
-      prism::table_append(table.get(), (uint32_t)i, states[i], false);
+      hipEvent_t e = nullptr;
+      prism::table_append(table.get(), (uint32_t)i, states[i], false, &e);
+      if (e) pending.events.push_back(e);
     }
     prism::execute_plan(plan, table.get(), nullptr, 0, true, out);
   });

@@ -165,6 +165,13 @@ struct prism_gpu_plan {
   std::atomic<int> part_mode{0};
   std::atomic<uint64_t> part_groups{0};
   std::atomic<uint64_t> part_table_capacity{0};  // capacity that the HBM table behind the LDS tables needed last time
+  // The same two for runs over PARTIAL state rows (a merge): a plan that aggregates partitions and
+  // then merges their states sees a partition's groups in the one and all groups in the other, and
+  // sized by the wrong one its list of groups is too short for the merge every time.
+  std::atomic<uint64_t> merge_part_groups{0};
+  std::atomic<uint64_t> merge_part_table_capacity{0};
+  std::atomic<uint64_t>& learnt_groups(bool merge_input) { return merge_input ? merge_part_groups : part_groups; }
+  std::atomic<uint64_t>& learnt_table_capacity(bool merge_input) { return merge_input ? merge_part_table_capacity : part_table_capacity; }
   std::atomic<int> wc_mode{0};  // -1: the histogram-free GROUP BY overflowed a segment or an LDS table on this plan's data
   // COUNT(DISTINCT) partitioned twice: distinct pairs per 1024 rows of the last run (0: not run yet);
   // rows that repeat a pair need no entry of the LDS sets, so fine buckets may hold more rows

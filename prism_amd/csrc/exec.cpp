@@ -1128,7 +1128,7 @@ bool part_forced(const prism_gpu_ctx* ctx) { return ctx->part_force != 0; }
 // overflowed (nothing usable was produced; the plan remembers, and the caller partitions with
 // the histogram).
 bool wc_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggParams& ap, uint64_t selected, uint64_t key_bytes,
-                 const std::vector<int>& slot_ops, GroupTable& gt, uint64_t* groups_out, uint32_t leading, GroupRows* lead) {
+                 const std::vector<int>& slot_ops, GroupTable& gt, uint64_t* groups_out, uint32_t leading, GroupRows* lead, bool merge_input) {
   // (with `leading`: the few listed groups are fetched along with the counters -- `lead`, and no table in `gt`)
   constexpr uint64_t kLeadFetch = 2048;
   WcParams w;
@@ -1172,7 +1172,7 @@ bool wc_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggParams& ap, 
   w.groups_total = (unsigned long long*)(d_small + 40);
   w.cut = (uint32_t*)(d_small + 48);
   if (w.lds_entries < wc_hot_slots() || leading > wc_hot_slots()) w.leading = 0;
-  uint64_t groups_est = plan->part_groups.load(std::memory_order_relaxed);
+  uint64_t groups_est = plan->learnt_groups(merge_input).load(std::memory_order_relaxed);
   if (!groups_est) groups_est = plan->groups_hint;
   uint64_t list_cap = groups_est ? groups_est + groups_est / 16 + 1024 : std::min<uint64_t>(selected, 1ull << 25);
   list_cap = std::max<uint64_t>(1, std::min(list_cap, selected + wc_hot_slots()));
@@ -1230,7 +1230,7 @@ bool wc_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggParams& ap, 
       lead->state.assign((const int64_t*)(k + kLeadFetch), (const int64_t*)(k + kLeadFetch) + groups);
       lead->n = groups;
       *groups_out = groups;
-      plan->part_groups.store(std::max<uint64_t>(1, h.groups_total + wc_hot_slots()), std::memory_order_relaxed);
+      plan->learnt_groups(merge_input).store(std::max<uint64_t>(1, h.groups_total + wc_hot_slots()), std::memory_order_relaxed);
       return true;
     }
     // (only the groups that can lead the order were listed: the list ends behind them)
@@ -1240,7 +1240,7 @@ bool wc_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggParams& ap, 
     PRISM_HIP(hipMemsetAsync(list.state.as<int64_t>() + groups, 0, tail * 8, ctx->stream));
     gt = std::move(list);
     *groups_out = groups;
-    plan->part_groups.store(std::max<uint64_t>(1, h.cut ? h.groups_total + wc_hot_slots() : groups), std::memory_order_relaxed);
+    plan->learnt_groups(merge_input).store(std::max<uint64_t>(1, h.cut ? h.groups_total + wc_hot_slots() : groups), std::memory_order_relaxed);
     return true;
   }
 }
@@ -1249,19 +1249,19 @@ bool wc_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, const AggParams& ap, 
 // predicate) through partitioning.  `gt` becomes a list of the groups; returns their number.
 uint64_t partitioned_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, AggParams ap, uint64_t selected, uint64_t scan_rows,
                               uint64_t key_bytes, uint64_t value_bytes, bool vals_nullable, const std::vector<int>& slot_ops,
-                              GroupTable& gt, uint32_t leading = 0, GroupRows* lead = nullptr) {
+                              GroupTable& gt, uint32_t leading = 0, GroupRows* lead = nullptr, bool merge_input = false) {
   const int words = part_record_words(ap, vals_nullable);
   if (words <= 0) fail(PRISM_GPU_EINTERNAL, "plan shape cannot be partitioned");
   // one-word keys and COUNT(*) alone: the path without a histogram, unless it overflowed before
   if (ctx->part_wc.load(std::memory_order_relaxed) != 0 && plan->wc_mode.load(std::memory_order_relaxed) >= 0 && wc_plan_fits(ap) &&
       selected >= ctx->part_wc_min_rows.load(std::memory_order_relaxed) && selected < (1ull << 32) - wc_hot_slots()) {
     uint64_t n = 0;
-    if (wc_group_by(ctx, plan, ap, selected, key_bytes, slot_ops, gt, &n, leading, lead)) return n;
+    if (wc_group_by(ctx, plan, ap, selected, key_bytes, slot_ops, gt, &n, leading, lead, merge_input)) return n;
   }
   const uint32_t p_max = part_max_buckets(words);
   const uint32_t lds_entries = part_lds_entries(ap);
   const uint32_t lds_limit = lds_entries / 4 * 3;
-  uint64_t groups_est = plan->part_groups.load(std::memory_order_relaxed);
+  uint64_t groups_est = plan->learnt_groups(merge_input).load(std::memory_order_relaxed);
   if (!groups_est) groups_est = plan->groups_hint;
   // a bucket should hold at most two thirds of what the LDS table takes; unknown: as many buckets as there are
   uint64_t want = groups_est ? pow2_ceil(ceil_div(groups_est * 3, (uint64_t)lds_limit * 2)) : p_max;
@@ -1305,7 +1305,7 @@ uint64_t partitioned_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, AggParam
   uint64_t list_cap = groups_est ? groups_est + groups_est / 16 + 1024 : std::min<uint64_t>(selected, 1ull << 25);
   list_cap = std::max<uint64_t>(1, std::min(list_cap, selected));
   // the HBM table behind the LDS tables: groups of buckets that were aggregated in slices, and stragglers
-  uint64_t fb_cap = std::max<uint64_t>(1ull << 16, plan->part_table_capacity.load(std::memory_order_relaxed));
+  uint64_t fb_cap = std::max<uint64_t>(1ull << 16, plan->learnt_table_capacity(merge_input).load(std::memory_order_relaxed));
   const uint64_t fb_max = pow2_ceil(std::max<uint64_t>(1024, 2 * selected));
   fb_cap = std::min(fb_cap, fb_max);
   const int n_slots = (int)slot_ops.size();
@@ -1377,7 +1377,7 @@ uint64_t partitioned_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, AggParam
       if (ap.key_words == 2) PRISM_HIP(hipMemsetAsync(list.keys_hi.as<uint64_t>() + groups, 0xff, tail * 8, ctx->stream));
       PRISM_HIP(hipMemsetAsync(list.state.as<int64_t>() + groups, 0, tail * 8, ctx->stream));
     }
-    if (h.flags[1]) plan->part_table_capacity.store(fb_cap, std::memory_order_relaxed);
+    if (h.flags[1]) plan->learnt_table_capacity(merge_input).store(fb_cap, std::memory_order_relaxed);
     // More groups than the largest number of buckets can hold in LDS: most of them went
     // through the HBM table after all, on top of the partitioning.  The plan goes back to the
     // streaming kernels.
@@ -1386,7 +1386,7 @@ uint64_t partitioned_group_by(prism_gpu_ctx* ctx, prism_gpu_plan* plan, AggParam
     gt = std::move(list);
     break;
   }
-  plan->part_groups.store(std::max<uint64_t>(1, groups), std::memory_order_relaxed);
+  plan->learnt_groups(merge_input).store(std::max<uint64_t>(1, groups), std::memory_order_relaxed);
   return groups;
 }
 
@@ -2341,7 +2341,7 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
       probe.key_words = 2;
       probe.keys_only = (plan->distinct_plan && layout.words == 2) ? 1 : 0;
       const int words = part_record_words(probe, vals_nullable);
-      uint64_t est = plan->part_groups.load(std::memory_order_relaxed);
+      uint64_t est = plan->learnt_groups(merge_input).load(std::memory_order_relaxed);
       if (!est) est = plan->groups_hint;
       wide_fits = words > 0 && est > 0 && est <= (uint64_t)part_max_buckets(words) * (part_lds_entries(probe) / 2);
     }
@@ -2426,7 +2426,7 @@ void execute_impl(prism_gpu_plan* plan, prism_gpu_table* table, const uint32_t* 
         const AggRule& r = low.rules[(size_t)plan->order_by - keys.size()];
         if ((r.func == PRISM_AGG_COUNT_STAR || r.func == PRISM_AGG_COUNT) && r.count_slot < 0 && r.main_slot == 0) leading = (uint32_t)plan->limit;
       }
-      partitioned_group_by(ctx, plan, ap, selected, ss.rows, key_bytes, value_bytes, vals_nullable, slot_ops, gt, leading, &lead);
+      partitioned_group_by(ctx, plan, ap, selected, ss.rows, key_bytes, value_bytes, vals_nullable, slot_ops, gt, leading, &lead, merge_input);
       dense = false;
     }
     std::shared_ptr<void> flag_landing;  // (see below: the table's flag word, read with the groups)

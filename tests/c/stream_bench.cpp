@@ -146,6 +146,8 @@ int main(int argc, char** argv) {
   uint64_t groups = 0;
   for (int step = 0; step < steps + 1; ++step) {  // step 0 warms the pools up
     CHECK(prism_gpu_reset_stats(ctx));
+    // (the verbose last step is timed kernel by kernel: slower, and not part of the average's best)
+    if (getenv("STREAM_BENCH_VERBOSE")) CHECK(prism_gpu_set_profiling(ctx, step == steps ? 1 : 0));
     std::vector<ArrowArray> states(n_parts);
     auto t_start = std::chrono::steady_clock::now();
     std::vector<std::thread> th;
@@ -188,6 +190,7 @@ int main(int argc, char** argv) {
     std::vector<ArrowArray*> ptrs;
     for (auto& s : states) ptrs.push_back(&s);
     ArrowArray out;
+    if (step == steps && getenv("STREAM_BENCH_VERBOSE") && atoi(getenv("STREAM_BENCH_VERBOSE")) > 1) CHECK(prism_gpu_reset_stats(ctx));  // (2: the merge's own statistics)
     CHECK(prism_gpu_merge(plan, ptrs.data(), ptrs.size(), &out));
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     const int64_t* cnt = (const int64_t*)out.children[c3 ? 1 : 2]->buffers[1];
