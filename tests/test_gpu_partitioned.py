@@ -715,3 +715,34 @@ def test_histogram_free_path_falls_back_when_a_segment_overflows(wc_ctx, oracle)
         assert_tables_match(again, want, 1)
     finally:
         g.close()
+
+
+def test_a_merge_is_sized_by_what_merges_learnt_not_by_a_partition(part_ctx, oracle):
+    """One plan aggregates the partitions (PARTIAL) and then merges their states, the way the
+    query engine uses it: a partition sees a fraction of the groups the merge sees.  The merge's
+    list of groups is sized by what the previous merge found, so from the second round on it is
+    one partitioned pass (sized by a partition's groups, its list was too short every time and
+    the pass ran twice)."""
+    from prism_amd.engine import Plan
+
+    wl = workloads.c3(id_bits=20)
+    rows, parts = 4_000_000, 8
+    q = QueryPlan([count_star()], keys=["UserID"])
+    table = workloads.build_gpu_table(part_ctx, wl, 0, rows, rows, parts)
+    st = oracle.SynthTable(wl.schema, wl.make_cols(), wl.seed, 0, rows, rows, n_parts=parts)
+    plan = Plan(part_ctx, wl.schema, q.with_mode(abi.MODE_PARTIAL))
+    try:
+        want, _ = st.execute(q)
+        for round_ in range(3):
+            states = [plan.execute(table, [p]) for p in range(parts)]
+            assert max(s.num_rows for s in states) * 2 < want.num_rows  # (a partition's groups say little about the merge's)
+            part_ctx.reset_stats()
+            got = plan.merge(states)
+            launches = part_ctx.stats()["kernels"]["group_by"]["launches"]
+            assert_tables_match(got, want, 1)
+            if round_ > 0:
+                assert launches == 1, launches
+    finally:
+        plan.close()
+        st.close()
+        table.close()
