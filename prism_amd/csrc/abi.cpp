@@ -382,6 +382,7 @@ int prism_gpu_set_option(prism_gpu_ctx* ctx, const char* name, int64_t value) {
     else if (n == "part_half_blocks") ctx->part_half_blocks.store(value != 0 ? 1 : 0);
     else if (n == "contains_windows") ctx->contains_windows.store(value != 0 ? 1 : 0);
     else if (n == "dict_expand_device") ctx->dict_expand_device.store(value != 0);
+    else if (n == "dict_lookup_min_rows") ctx->dict_lookup_min_rows.store(value < 0 ? INT64_MAX : value);
     else if (n == "stream_chunk_rows") { require(value >= 1 && value <= (1ll << 28), "stream_chunk_rows must be 1..2^28"); ctx->stream_chunk_rows.store((uint64_t)value); }
     else if (n == "stream_agg_chunks") { require(value >= 1 && value <= 256, "stream_agg_chunks must be 1..256"); ctx->stream_agg_chunks.store((int)value); }
     else if (n == "stream_state") ctx->stream_state.store(value != 0 ? 1 : 0);

@@ -92,6 +92,7 @@ struct prism_gpu_ctx {
   std::atomic<int> part2_compact{1};                 // 0: the second partition level of COUNT(DISTINCT) always keeps two-word records
   std::atomic<int> contains_windows{1};              // 0: substring search always by the byte-wise prefilter
   std::atomic<int> parquet_threads{4};               // threads that decode the column chunks of a Parquet row group
+  std::atomic<int64_t> dict_lookup_min_rows{65536};  // plain strings of a chunk of at least so many rows are coded on the device when the dictionary has them all
   std::atomic<int> dict_expand_device{1};            // 0: dictionary-encoded string input is expanded into offsets + bytes on the host
   std::atomic<uint64_t> stream_chunk_rows{1ull << 20};  // rows a streaming partition gathers before it stages a chunk
   std::atomic<int> stream_agg_chunks{8};             // staged chunks a streaming partition lets gather before it aggregates them in one pass

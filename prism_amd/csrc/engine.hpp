@@ -47,6 +47,9 @@ struct ColumnDict {
   bool device_built = false;
   std::unordered_map<std::string, uint32_t> ids;
   std::vector<std::string> values;
+  static constexpr int kFrontBits = 12;
+  std::vector<uint32_t> front;  // recent answers of id_of: index into `values` + 1, 0 = none
+  int lookup_pause = 0;         // appends for which plain strings are not looked up on the device (after one that missed)
   uint32_t id_of(const char* s, size_t n);
 };
 

@@ -629,6 +629,30 @@ struct ColStats {
   unsigned long long null_count;
 };
 // Folds min/max/null count of `rows` values into *stats (device; initialised by the caller).
+// Plain strings -> the codes of a dictionary they are all expected to be in (a table's later chunks
+// of a low-cardinality column): a row's bytes are hashed, looked up in an open-addressing index of
+// the dictionary (slots hold value number + 1, 0 = free; at most half of them taken) and compared
+// with the value's bytes.  A row whose string is not there gets code 0 and raises report[0]
+// (page-locked host memory), and the caller codes the chunk the long way.  NULL rows get code 0.
+struct DictLookup {
+  const int32_t* offsets;
+  const uint8_t* bytes;
+  const uint64_t* validity;
+  uint64_t rows;
+  const uint32_t* dict_off;   // n_values + 1
+  const uint8_t* dict_bytes;
+  const uint32_t* slots;      // mask + 1
+  uint32_t mask;
+  uint32_t* codes;
+  uint32_t* report;
+};
+inline uint64_t dict_lookup_hash_host(const uint8_t* p, uint32_t len) {
+  uint64_t h = 0xcbf29ce484222325ull ^ len;
+  for (uint32_t i = 0; i < len; ++i) h = (h ^ p[i]) * 0x100000001b3ull;
+  h ^= h >> 32;
+  return h * 0x9E3779B97F4A7C15ull >> 20;
+}
+void launch_dict_lookup(prism_gpu_ctx* ctx, const DictLookup& q, hipStream_t stream);
 // Page-locked host memory -> HBM by a kernel that reads the host's memory where it is: for the
 // loader's small copies, which as copy-engine commands would queue behind the tens of megabytes
 // of column values that the same engine moves.  src and dst must agree modulo 16.

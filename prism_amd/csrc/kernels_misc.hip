@@ -47,6 +47,41 @@ __global__ __launch_bounds__(kBlock) void k_col_stats(const void* values, const 
   }
 }
 
+// (the same function as dict_lookup_hash_host)
+__device__ __forceinline__ uint64_t dict_lookup_hash(const uint8_t* p, uint32_t len) {
+  uint64_t h = 0xcbf29ce484222325ull ^ len;
+  for (uint32_t i = 0; i < len; ++i) h = (h ^ p[i]) * 0x100000001b3ull;
+  h ^= h >> 32;
+  return h * 0x9E3779B97F4A7C15ull >> 20;
+}
+
+__global__ __launch_bounds__(kBlock) void k_dict_lookup(DictLookup q) {
+  for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < q.rows; r += (uint64_t)gridDim.x * kBlock) {
+    uint32_t code = 0;
+    if (valid_at(q.validity, r)) {
+      const uint32_t lo = (uint32_t)q.offsets[r], len = (uint32_t)q.offsets[r + 1] - lo;
+      const uint8_t* p = q.bytes + lo;
+      uint32_t e = (uint32_t)dict_lookup_hash(p, len) & q.mask;
+      bool found = false;
+      for (uint32_t probes = 0; probes <= q.mask; ++probes, e = (e + 1) & q.mask) {
+        const uint32_t v1 = q.slots[e];
+        if (v1 == 0) break;
+        const uint32_t from = q.dict_off[v1 - 1];
+        if (q.dict_off[v1] - from != len) continue;
+        uint32_t i = 0;
+        while (i < len && q.dict_bytes[from + i] == p[i]) ++i;
+        if (i == len) {
+          code = v1 - 1;
+          found = true;
+          break;
+        }
+      }
+      if (!found) q.report[0] = 1u;
+    }
+    q.codes[r] = code;
+  }
+}
+
 // dst and src agree modulo 16: bytes up to the first 16-byte boundary, whole vectors, the tail.
 __global__ __launch_bounds__(kBlock) void k_stage_copy(uint8_t* dst, const uint8_t* src, uint64_t bytes) {
   const uint64_t head = min((uint64_t)((16 - ((uintptr_t)dst & 15)) & 15), bytes), vecs = (bytes - head) >> 4;
@@ -269,6 +304,21 @@ void launch_synth_url(prism_gpu_ctx* ctx, const int32_t* offsets, uint8_t* bytes
   if (n_rows == 0) return;
   uint32_t grid = (uint32_t)std::min<uint64_t>(ceil_div(n_rows, (uint64_t)kBlock), (uint64_t)ctx->n_cus * 16);
   k_synth_url<<<dim3(std::max(1u, grid)), dim3(kBlock), 0, ctx->stream>>>(offsets, bytes, n_rows, first_row, p0, p1, column_key);
+  PRISM_HIP(hipGetLastError());
+}
+
+void launch_dict_lookup(prism_gpu_ctx* ctx, const DictLookup& q, hipStream_t stream) {
+  if (q.rows == 0) return;
+  {  // (counted, not timed: the launch is on the caller's stream, among its copies)
+    std::lock_guard<std::mutex> g(ctx->mu);
+    const int i = stat_index(ctx, "dict_lookup");
+    if (i >= 0) {
+      ctx->stats.kernels[i].launches += 1;
+      ctx->stats.kernels[i].algorithmic_bytes += q.rows * 4;
+    }
+  }
+  uint32_t grid = (uint32_t)std::min<uint64_t>(ceil_div(q.rows, (uint64_t)kBlock * 4), (uint64_t)ctx->n_cus * 8);
+  k_dict_lookup<<<dim3(std::max(1u, grid)), dim3(kBlock), 0, stream>>>(q);
   PRISM_HIP(hipGetLastError());
 }
 

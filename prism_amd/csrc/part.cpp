@@ -32,6 +32,7 @@ void copy_options(prism_gpu_ctx* c, prism_gpu_ctx* parent) {
   c->part2_direct.store(parent->part2_direct.load());
   c->part2_half_blocks.store(parent->part2_half_blocks.load());
   c->part_wc_min_rows.store(parent->part_wc_min_rows.load());
+  c->dict_lookup_min_rows.store(parent->dict_lookup_min_rows.load());
   c->contains_windows.store(parent->contains_windows.load());
   c->dict_expand_device.store(parent->dict_expand_device.load());
 }

@@ -20,12 +20,34 @@
 namespace prism {
 
 uint32_t ColumnDict::id_of(const char* s, size_t n) {
+  // In front of the map, a direct-mapped table of recent answers, indexed by a cheap hash of the
+  // length and the first and last eight bytes and confirmed by comparing the bytes: a plain Utf8
+  // column is looked up row by row (the PARTIAL state of a plan with a string key has one row per
+  // group, or per distinct pair), and a string built and hashed per row was 20 ns of each.
+  uint64_t a = 0, b = 0;
+  if (n >= 8) {
+    std::memcpy(&a, s, 8);
+    std::memcpy(&b, s + n - 8, 8);
+  } else {
+    std::memcpy(&a, s, n);
+  }
+  const size_t slot = (size_t)(((a * 0x9E3779B97F4A7C15ull) ^ ((b + n) * 0xC2B2AE3D27D4EB4Full)) >> (64 - kFrontBits));
+  if (front.empty()) front.assign((size_t)1 << kFrontBits, 0u);
+  if (const uint32_t f = front[slot]) {
+    const std::string& v = values[f - 1];
+    if (v.size() == n && std::memcmp(v.data(), s, n) == 0) return f - 1;
+  }
   std::string key(s, n);
   auto it = ids.find(key);
-  if (it != ids.end()) return it->second;
-  uint32_t id = (uint32_t)values.size();
-  values.push_back(key);
-  ids.emplace(std::move(key), id);
+  uint32_t id;
+  if (it != ids.end()) {
+    id = it->second;
+  } else {
+    id = (uint32_t)values.size();
+    values.push_back(key);
+    ids.emplace(std::move(key), id);
+  }
+  front[slot] = id + 1;
   return id;
 }
 
@@ -507,7 +529,18 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
     std::vector<PackedBatch> packed_batches;
     uint64_t packed_bound = 0;  // no more bytes than this come out of the packed batches
     const ArrowArray* seg_dict = nullptr;  // the dictionary of the last segment: batches that share it extend the segment
-    if (dict.alive && !device_expand && !device_codes) codes.resize((size_t)n);
+    // Plain strings of a column whose dictionary exists already: the codes are looked up on the
+    // device first (a later chunk of a low-cardinality column holds nothing new), and only a chunk
+    // with a string the dictionary lacks is coded here, row by row.  A column that keeps bringing
+    // new strings is left alone for a while after each miss.
+    bool dev_lookup = dict.alive && !codes_only && !device_expand && !dict.values.empty() && dict.values.size() <= 16384 &&
+                      n >= ctx->dict_lookup_min_rows.load(std::memory_order_relaxed);
+    for (size_t b = 0; b < n_batches && dev_lookup; ++b) dev_lookup = views[b][ci].dictionary == nullptr;
+    if (dev_lookup && dict.lookup_pause > 0) {
+      --dict.lookup_pause;
+      dev_lookup = false;
+    }
+    if (dict.alive && !device_expand && !device_codes && !dev_lookup) codes.resize((size_t)n);
     std::vector<int32_t> offs(codes_only || device_expand ? 1 : (size_t)n + 1);
     offs[0] = 0;
     // bytes of the chunk: total first (it sizes the device buffer), then the pieces
@@ -642,7 +675,7 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
         const uint64_t len = (uint64_t)(so[nb] - base);
         if (total + len > 0x7fffffffull) fail(PRISM_GPU_EUNSUPPORTED, "string data of one chunk exceeds 2 GiB");
         for (int64_t i = 1; i <= nb; ++i) offs[(size_t)(row0 + i)] = (int32_t)(total + (uint64_t)(so[i] - base));
-        if (dict.alive) {
+        if (dict.alive && !dev_lookup) {
           for (int64_t i = 0; i < nb; ++i) {
             const bool valid = !vbits || bit_at(vbits, a->offset + i);
             codes[(size_t)(row0 + i)] = valid ? dict.id_of((const char*)sb + so[i], (size_t)(so[i + 1] - so[i])) : 0;
@@ -654,17 +687,20 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
       }
       row0 += nb;
     }
-    if (dict.alive && dict.values.size() > kMaxDictValues) {
+    auto retire_full_dictionary = [&]() {
+      if (!dict.alive || dict.values.size() <= kMaxDictValues) return;
       // too many distinct values: this column keeps only its raw form from now on
       // (the values stay: group tables built so far hold their codes and are still read out through them)
       dict.alive = false;
       dict.device_built = false;
       dict.ids.clear();
+      dict.front.clear();
       for (auto& old : t->chunks) {
         dev_free(t, old.cols[ci].codes);
         old.cols[ci].codes = nullptr;
       }
-    }
+    };
+    retire_full_dictionary();
     if (codes_only && !dict.alive) fail(PRISM_GPU_EUNSUPPORTED, "dictionary-encoded column " + f.name + " has more than " + std::to_string(kMaxDictValues) + " distinct values");
     if (device_codes) {
       // (pieces holds the batches' index buffers)
@@ -789,8 +825,80 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
       w.begin(dc.bytes);
       for (const Piece& pc : pieces) w.write(pc.p, pc.n);
     }
-    if (dict.alive) {
+    bool coded = false;
+    if (dev_lookup) {
+      // the dictionary as the kernel wants it: offsets, bytes, and an index with at most half its slots taken
+      const size_t n_values = dict.values.size();
+      std::vector<uint32_t> d_off(n_values + 1, 0);
+      for (size_t v = 0; v < n_values; ++v) d_off[v + 1] = d_off[v] + (uint32_t)dict.values[v].size();
+      std::vector<uint8_t> d_bytes(d_off.back());
+      for (size_t v = 0; v < n_values; ++v) std::memcpy(d_bytes.data() + d_off[v], dict.values[v].data(), dict.values[v].size());
+      const uint32_t n_slots = (uint32_t)pow2_ceil(std::max<size_t>(64, 2 * n_values));
+      std::vector<uint32_t> slots(n_slots, 0);
+      for (size_t v = 0; v < n_values; ++v) {
+        uint32_t e = (uint32_t)dict_lookup_hash_host((const uint8_t*)dict.values[v].data(), (uint32_t)dict.values[v].size()) & (n_slots - 1);
+        while (slots[e]) e = (e + 1) & (n_slots - 1);
+        slots[e] = (uint32_t)v + 1;
+      }
+      auto pad = [](size_t v) { return (v + 15) & ~(size_t)15; };
+      const size_t off_at = 0, slots_at = pad(d_off.size() * 4), bytes_at = slots_at + pad((size_t)n_slots * 4), need = bytes_at + pad(d_bytes.size()) + 16;
+      uint8_t* tmp = (uint8_t*)load_scratch(ctx, need);
+      w.begin(tmp + off_at);
+      w.write(d_off.data(), d_off.size() * 4);
+      w.begin(tmp + slots_at);
+      w.write(slots.data(), (size_t)n_slots * 4);
+      if (!d_bytes.empty()) {
+        w.begin(tmp + bytes_at);
+        w.write(d_bytes.data(), d_bytes.size());
+      }
+      w.join();
       dc.codes = (uint32_t*)dev_alloc(t, (size_t)n * 4);
+      volatile uint32_t* missed = (volatile uint32_t*)ctx->load_landing;
+      missed[0] = 0;
+      DictLookup q;
+      q.offsets = (const int32_t*)dc.values;
+      q.bytes = dc.bytes;
+      q.validity = dc.validity;
+      q.rows = (uint64_t)n;
+      q.dict_off = (const uint32_t*)(tmp + off_at);
+      q.dict_bytes = tmp + bytes_at;
+      q.slots = (const uint32_t*)(tmp + slots_at);
+      q.mask = n_slots - 1;
+      q.codes = dc.codes;
+      q.report = (uint32_t*)ctx->load_landing;
+      launch_dict_lookup(ctx, q, ctx->copy_stream);
+      PRISM_HIP(hipStreamSynchronize(ctx->copy_stream));
+      coded = missed[0] == 0;
+      if (!coded) {
+        // a string the dictionary lacks: the chunk is coded row by row after all (which adds it)
+        dict.lookup_pause = 8;
+        codes.resize((size_t)n);
+        int64_t r0 = 0;
+        for (size_t b = 0; b < n_batches && dict.values.size() <= kMaxDictValues; ++b) {
+          const ArrowArray* a = &views[b][ci];
+          const int64_t nb = a->length;
+          if (nb == 0) continue;
+          const uint8_t* vbits = (a->null_count != 0 && a->n_buffers > 0) ? (const uint8_t*)a->buffers[0] : nullptr;
+          const int32_t* so = (const int32_t*)a->buffers[1] + a->offset;
+          const uint8_t* sb = (const uint8_t*)a->buffers[2];
+          for (int64_t i = 0; i < nb; ++i) {
+            const bool valid = !vbits || bit_at(vbits, a->offset + i);
+            codes[(size_t)(r0 + i)] = valid ? dict.id_of((const char*)sb + so[i], (size_t)(so[i + 1] - so[i])) : 0;
+            if (dict.values.size() > kMaxDictValues) break;
+          }
+          r0 += nb;
+        }
+        retire_full_dictionary();
+        if (!dict.alive) {
+          dev_free(t, dc.codes);
+          dc.codes = nullptr;
+        }
+      }
+    }
+    if (dict.alive && coded) {
+      launch_col_stats(ctx, dc.codes, dc.validity, 4, true, (uint64_t)n, &ch.d_stats[ci], ctx->copy_stream);
+    } else if (dict.alive) {
+      if (!dc.codes) dc.codes = (uint32_t*)dev_alloc(t, (size_t)n * 4);
       w.begin(dc.codes);
       w.write(codes.data(), (size_t)n * 4);
       w.join();
@@ -973,6 +1081,7 @@ void table_device_dictionary(prism_gpu_table* t, int ci) {
     col_bytes += dc.n_bytes;
   }
   dict.values.clear();
+  dict.front.clear();
   dict.device_built = false;
   if (n_rows >= 0xfffffff0ull) fail(PRISM_GPU_EUNSUPPORTED, "GROUP BY on string column " + t->fields[(size_t)ci].name + ": 2^32 rows or more");
   if (col_bytes >= 0xfffffff0ull) fail(PRISM_GPU_EUNSUPPORTED, "GROUP BY on string column " + t->fields[(size_t)ci].name + ": 4 GiB of string data or more");

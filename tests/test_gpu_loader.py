@@ -352,3 +352,54 @@ def test_column_buffers_of_middling_size_survive_a_refused_append(gpu_ctx):
     finally:
         plan.close()
         g.close()
+
+
+@pytest.mark.gpu
+def test_plain_strings_are_coded_on_the_device_once_the_dictionary_has_them():
+    """Plain Utf8 chunks of a low-cardinality column: the first chunk builds the table's dictionary on
+    the host; a later chunk that brings nothing new gets its codes from a kernel that looks every
+    row up in the dictionary; a chunk with a new string is noticed by the kernel and coded on the
+    host (and the next appends are the host's as well).  Codes are the same whichever way they
+    come about: GROUP BY, = and IN over the column equal the oracle's, NULLs and empty strings
+    included."""
+    import numpy as np
+
+    from oracle import pyoracle
+    from prism_amd.engine import Context, Plan, Table
+
+    rng = np.random.default_rng(31)
+    names = ["", "a", "svc-one", "svc-two", "a-name-longer-than-eight-bytes", "ünï©ode", "svc-onf"]
+
+    def chunk(n, pool, nulls=True):
+        idx = rng.integers(0, len(pool), n)
+        mask = (rng.random(n) < 0.1) if nulls else None
+        return pa.table({"service": pa.array([pool[int(i)] for i in idx], pa.string(), mask=mask),
+                         "value": pa.array(rng.integers(-100, 100, n), pa.int64())})
+
+    ctx = Context(0)
+    ctx.set_option("dict_lookup_min_rows", 0)
+    chunks = [chunk(5000, names), chunk(7000, names), chunk(3000, names, nulls=False), chunk(4000, names + ["brand-new"]),
+              chunk(2000, names)]
+    g = Table(ctx, chunks[0].schema)
+    try:
+        launches = []
+        for k, c in enumerate(chunks):
+            ctx.reset_stats()
+            g.append(k, c.combine_chunks().to_batches()[0])
+            stat = ctx.stats()["kernels"].get("dict_lookup")
+            launches.append(stat["launches"] if stat else 0)
+        # the first chunk has no dictionary to look up in; the fourth misses; the fifth falls in the pause
+        assert launches == [0, 1, 1, 1, 0], launches
+        whole = pa.concat_tables(chunks)
+        for q, n_keys in [(QueryPlan([count_star(), sum_("value")], keys=["service"]), 1),
+                          (QueryPlan([count_star()], predicate=col("service") == "svc-one"), 0),
+                          (QueryPlan([count_star()], predicate=col("service") == "brand-new"), 0),
+                          (QueryPlan([count_star(), max_("value")], keys=["service"], predicate=col("service") != ""), 1)]:
+            plan = Plan(ctx, whole.schema, q)
+            try:
+                assert_tables_match(plan.execute(g), pyoracle.execute(whole, q), n_keys)
+            finally:
+                plan.close()
+    finally:
+        g.close()
+        ctx.close()
