@@ -242,8 +242,9 @@ void prism_gpu_ctx_free(prism_gpu_ctx* ctx);
  *   "dict_lookup_min_rows" a chunk of at least so many rows (default 65536; negative: never) whose
  *                    string column arrives as plain Utf8 and whose table-wide dictionary exists
  *                    already gets its codes from a kernel that looks every row up in the
- *                    dictionary; a chunk with a string the dictionary lacks is coded on the host
- *                    as before, and the column is left to the host for the next 8 appends
+ *                    dictionary (a table's first chunk seeds it from a sample of its rows); a chunk
+ *                    with a string the dictionary lacks is coded on the host as before, and after
+ *                    misses in a row the column is left to the host for 2, 4, then 8 appends
  *   "stream_chunk_rows" rows a streaming partition gathers before it stages them as one chunk
  *                    (default 1048576; 1..2^28)
  *   "stream_agg_chunks" staged chunks a streaming partition that keeps its groups in HBM lets gather

@@ -49,7 +49,8 @@ struct ColumnDict {
   std::vector<std::string> values;
   static constexpr int kFrontBits = 12;
   std::vector<uint32_t> front;  // recent answers of id_of: index into `values` + 1, 0 = none
-  int lookup_pause = 0;         // appends for which plain strings are not looked up on the device (after one that missed)
+  int lookup_pause = 0;         // appends for which plain strings are not looked up on the device (after misses in a row)
+  int lookup_misses = 0;        // such look-ups that missed, in a row
   uint32_t id_of(const char* s, size_t n);
 };
 

@@ -533,12 +533,28 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
     // device first (a later chunk of a low-cardinality column holds nothing new), and only a chunk
     // with a string the dictionary lacks is coded here, row by row.  A column that keeps bringing
     // new strings is left alone for a while after each miss.
-    bool dev_lookup = dict.alive && !codes_only && !device_expand && !dict.values.empty() && dict.values.size() <= 16384 &&
+    bool dev_lookup = dict.alive && !codes_only && !device_expand && dict.values.size() <= 16384 &&
                       n >= ctx->dict_lookup_min_rows.load(std::memory_order_relaxed);
     for (size_t b = 0; b < n_batches && dev_lookup; ++b) dev_lookup = views[b][ci].dictionary == nullptr;
     if (dev_lookup && dict.lookup_pause > 0) {
       --dict.lookup_pause;
       dev_lookup = false;
+    }
+    if (dev_lookup && dict.values.empty()) {
+      // The first chunk of a table: a sample of its rows seeds the dictionary, and the kernel finds
+      // out whether their strings were all there is.
+      const int64_t step = std::max<int64_t>(1, n / 8192);  // (spread over the chunk: rows of one value often lie together)
+      for (size_t b = 0; b < n_batches; ++b) {
+        const ArrowArray* a = &views[b][ci];
+        if (a->length == 0) continue;
+        if (a->n_buffers < 3 || !a->buffers[1]) fail(PRISM_GPU_EINVAL, "string column " + f.name + " has no offsets");
+        const uint8_t* vbits = (a->null_count != 0 && a->n_buffers > 0) ? (const uint8_t*)a->buffers[0] : nullptr;
+        const int32_t* so = (const int32_t*)a->buffers[1] + a->offset;
+        const uint8_t* sb = (const uint8_t*)a->buffers[2];
+        for (int64_t i = 0; i < a->length; i += step)
+          if (!vbits || bit_at(vbits, a->offset + i)) (void)dict.id_of((const char*)sb + so[i], (size_t)(so[i + 1] - so[i]));
+      }
+      dev_lookup = !dict.values.empty();
     }
     if (dict.alive && !device_expand && !device_codes && !dev_lookup) codes.resize((size_t)n);
     std::vector<int32_t> offs(codes_only || device_expand ? 1 : (size_t)n + 1);
@@ -869,9 +885,12 @@ void table_append_batches(prism_gpu_table* t, uint32_t partition_id, ArrowArray*
       launch_dict_lookup(ctx, q, ctx->copy_stream);
       PRISM_HIP(hipStreamSynchronize(ctx->copy_stream));
       coded = missed[0] == 0;
+      if (coded) dict.lookup_misses = 0;
       if (!coded) {
         // a string the dictionary lacks: the chunk is coded row by row after all (which adds it)
-        dict.lookup_pause = 8;
+        // (one miss may be the chunk that completes the dictionary; misses in a row are a column that keeps growing)
+        dict.lookup_pause = dict.lookup_misses == 0 ? 0 : std::min(8, 1 << dict.lookup_misses);
+        dict.lookup_misses = std::min(dict.lookup_misses + 1, 8);
         codes.resize((size_t)n);
         int64_t r0 = 0;
         for (size_t b = 0; b < n_batches && dict.values.size() <= kMaxDictValues; ++b) {

@@ -356,10 +356,10 @@ def test_column_buffers_of_middling_size_survive_a_refused_append(gpu_ctx):
 
 @pytest.mark.gpu
 def test_plain_strings_are_coded_on_the_device_once_the_dictionary_has_them():
-    """Plain Utf8 chunks of a low-cardinality column: the first chunk builds the table's dictionary on
-    the host; a later chunk that brings nothing new gets its codes from a kernel that looks every
-    row up in the dictionary; a chunk with a new string is noticed by the kernel and coded on the
-    host (and the next appends are the host's as well).  Codes are the same whichever way they
+    """Plain Utf8 chunks of a low-cardinality column: a sample of the first chunk's rows seeds the
+    table's dictionary on the host; a chunk that brings nothing new gets its codes from a kernel that
+    looks every row up in the dictionary; a chunk with a new string is noticed by the kernel and coded on the
+    host (after misses in a row the next appends are the host's without a try).  Codes are the same whichever way they
     come about: GROUP BY, = and IN over the column equal the oracle's, NULLs and empty strings
     included."""
     import numpy as np
@@ -379,7 +379,8 @@ def test_plain_strings_are_coded_on_the_device_once_the_dictionary_has_them():
     ctx = Context(0)
     ctx.set_option("dict_lookup_min_rows", 0)
     chunks = [chunk(5000, names), chunk(7000, names), chunk(3000, names, nulls=False), chunk(4000, names + ["brand-new"]),
-              chunk(2000, names)]
+              chunk(2000, names), chunk(2000, names + ["x1"]), chunk(2000, names + ["x2"]), chunk(1000, names), chunk(1000, names),
+              chunk(1000, names)]
     g = Table(ctx, chunks[0].schema)
     try:
         launches = []
@@ -388,8 +389,9 @@ def test_plain_strings_are_coded_on_the_device_once_the_dictionary_has_them():
             g.append(k, c.combine_chunks().to_batches()[0])
             stat = ctx.stats()["kernels"].get("dict_lookup")
             launches.append(stat["launches"] if stat else 0)
-        # the first chunk has no dictionary to look up in; the fourth misses; the fifth falls in the pause
-        assert launches == [0, 1, 1, 1, 0], launches
+        # (a sample of the first chunk's rows seeds the dictionary;) the fourth chunk misses and is coded on the
+        # host; the sixth and the seventh miss in a row, and the next two appends are the host's without a try
+        assert launches == [1, 1, 1, 1, 1, 1, 1, 0, 0, 1], launches
         whole = pa.concat_tables(chunks)
         for q, n_keys in [(QueryPlan([count_star(), sum_("value")], keys=["service"]), 1),
                           (QueryPlan([count_star()], predicate=col("service") == "svc-one"), 0),
