@@ -54,7 +54,8 @@ def stream_feed_line(args) -> dict:
         raise SystemExit(f"{exe} is not built (python -c 'import __graft_entry__ as g; g.build()')")
     c3 = args.workload == "C3"
     rows = args.rows or (100_000_000 if c3 else 1_000_000_000)
-    r = subprocess.run([exe, str(rows), str(args.feed_threads), str(args.steps), "8192", "c3" if c3 else "c2"], capture_output=True, text=True)
+    plain = bool(getattr(args, "plain_strings", False)) and not c3
+    r = subprocess.run([exe, str(rows), str(args.feed_threads), str(args.steps), "8192", "c3" if c3 else "c2plain" if plain else "c2"], capture_output=True, text=True)
     if r.returncode != 0:
         raise SystemExit(f"stream_bench failed ({r.returncode}): {r.stderr.strip()}")
     m = json.loads(r.stdout.strip().splitlines()[-1])
@@ -74,7 +75,8 @@ def stream_feed_line(args) -> dict:
         "config": {"workload": ("C3: GROUP BY UserID -> COUNT(*) as PARTIAL state per partition, merged with ORDER BY COUNT(*) DESC LIMIT 10 (`groups`: rows of the PARTIAL states); ids log-uniform over 2^24 ranks, "
                                 "batches of 8192 rows in pageable host memory") if c3 else
                                ("C2: date_bin(1 minute, timestamp), service -> COUNT(*), SUM(value), MAX(value); "
-                                "service dictionary encoded, batches of 8192 rows in pageable host memory"),
+                                + ("service as plain Utf8 (coded on the device), " if plain else "service dictionary encoded, ")
+                                + "batches of 8192 rows in pageable host memory"),
                    "feed": "stream", "total_rows": rows, "partitions": m["threads"], "batch_rows": m["batch_rows"],
                    "groups": m["groups"]},
         "roofline": None,
@@ -437,6 +439,7 @@ def main() -> int:
                          "bounded by PCIe, reported separately, C2 only)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="prism_gpu_set_option on the context (for A/B runs of a kernel path)")
+    ap.add_argument("--plain-strings", action="store_true", help="--feed stream, C2: the service column arrives as plain Utf8 instead of dictionary encoded")
     ap.add_argument("--feed-threads", type=int, default=16, help="partitions (= feeding threads) of --feed stream")
     ap.add_argument("--check-launch", action="store_true",
                     help="only bring the ranks up (gloo rendezvous + one all-reduce, no GPU) and print what met; "

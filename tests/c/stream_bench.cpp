@@ -39,6 +39,9 @@ static uint64_t mix64(uint64_t z) {
 struct Partition {
   std::vector<int64_t> ts, value;
   std::vector<int32_t> svc;
+  // "c2plain": the service column as plain Utf8 (what an Arrow scan yields unless asked for dictionaries)
+  std::vector<int32_t> svc_off;
+  std::string svc_bytes;
 };
 
 // One batch = rows [lo, hi) of a partition: struct array whose children point into the
@@ -48,7 +51,7 @@ struct Batch {
   ArrowArray* children[3];
   const void* top_buf[1];
   const void* ts_buf[2];
-  const void* svc_buf[2];
+  const void* svc_buf[3];
   const void* val_buf[2];
 };
 
@@ -58,6 +61,7 @@ int main(int argc, char** argv) {
   const int steps = argc > 3 ? atoi(argv[3]) : 3;
   const int64_t batch_rows = argc > 4 ? atoll(argv[4]) : 8192;
   const bool c3 = argc > 5 && strcmp(argv[5], "c3") == 0;
+  const bool plain = argc > 5 && strcmp(argv[5], "c2plain") == 0;
   const int n_services = 64;
   const int64_t t0 = 1700000000000ll, day = 86400000ll;
 
@@ -82,6 +86,7 @@ int main(int argc, char** argv) {
   f[1].format = "i"; f[1].name = "service"; f[1].dictionary = &dict_schema;
   f[2].format = "l"; f[2].name = "value";
   dict_schema.format = "u"; dict_schema.name = ""; dict_schema.release = noop_release_schema;
+  if (plain) { f[1].format = "u"; f[1].dictionary = nullptr; }
   for (auto& x : f) { x.flags = ARROW_FLAG_NULLABLE; x.release = noop_release_schema; }
   top.format = "+s"; top.name = ""; top.n_children = 3; top.children = fp; top.release = noop_release_schema;
 
@@ -137,10 +142,19 @@ int main(int argc, char** argv) {
           P.svc[i] = (int32_t)((h >> 40) % (uint64_t)n_services);
           P.value[i] = (int64_t)((h & 0xffffffffull) * 50000ull >> 32);
         }
+        if (plain) {
+          P.svc_off.resize(n + 1);
+          P.svc_off[0] = 0;
+          P.svc_bytes.reserve(n * 6);
+          for (uint64_t i = 0; i < n; ++i) {
+            P.svc_bytes.append(names, (size_t)name_off[P.svc[i]], (size_t)(name_off[P.svc[i] + 1] - name_off[P.svc[i]]));
+            P.svc_off[i + 1] = (int32_t)P.svc_bytes.size();
+          }
+        }
       });
     for (auto& t : gen) t.join();
   }
-  const uint64_t bytes_per_row = c3 ? 8 : 8 + 4 + 8;
+  const uint64_t bytes_per_row = c3 ? 8 : plain ? 8 + 4 + 6 + 8 : 8 + 4 + 8;
 
   double best = 1e30, total = 0;
   uint64_t groups = 0;
@@ -162,6 +176,7 @@ int main(int argc, char** argv) {
           Batch b;
           memset(&b, 0, sizeof(b));
           b.ts_buf[1] = P.ts.data(); b.svc_buf[1] = P.svc.data(); b.val_buf[1] = P.value.data();
+          if (plain) { b.svc_buf[1] = P.svc_off.data(); b.svc_buf[2] = P.svc_bytes.data(); }
           const void** bufs[3] = {b.ts_buf, b.svc_buf, b.val_buf};
           for (int c = 0; c < n_cols; ++c) {
             b.cols[c].length = len; b.cols[c].offset = lo; b.cols[c].n_buffers = 2;
@@ -169,14 +184,15 @@ int main(int argc, char** argv) {
             b.children[c] = &b.cols[c];
           }
           b.dict.length = n_services; b.dict.n_buffers = 3; b.dict.buffers = dict_buf; b.dict.release = noop_release_array;
-          if (!c3) b.cols[1].dictionary = &b.dict;
+          if (!c3 && !plain) b.cols[1].dictionary = &b.dict;
+          if (plain) b.cols[1].n_buffers = 3;
           b.top.length = len; b.top.n_buffers = 1; b.top.buffers = b.top_buf; b.top.n_children = n_cols;
           b.top.children = b.children; b.top.release = noop_release_array;
           // (the part keeps the ArrowArray struct by value; the children live in `b`... so a
           // batch must outlive the push until it is staged: allocate it)
           Batch* hb = new Batch(b);
           for (int c = 0; c < n_cols; ++c) { hb->cols[c].buffers = c == 0 ? hb->ts_buf : c == 1 ? hb->svc_buf : hb->val_buf; hb->children[c] = &hb->cols[c]; }
-          if (!c3) hb->cols[1].dictionary = &hb->dict;
+          if (!c3 && !plain) hb->cols[1].dictionary = &hb->dict;
           hb->top.buffers = hb->top_buf; hb->top.children = hb->children;
           hb->top.private_data = hb;
           hb->top.release = [](ArrowArray* a) { Batch* x = (Batch*)a->private_data; a->release = nullptr; delete x; };
@@ -225,7 +241,7 @@ int main(int argc, char** argv) {
   printf("{\"workload\": \"%s\", \"rows\": %" PRIu64 ", \"threads\": %d, \"batch_rows\": %lld, \"steps\": %d, \"groups\": %" PRIu64
          ", \"seconds_avg\": %.6f, \"seconds_best\": %.6f, \"rows_per_s\": %.1f, \"host_bytes_per_row\": %" PRIu64
          ", \"host_to_hbm_GBps\": %.3f, \"bytes_staged_last_step\": %" PRIu64 ", \"staging_thread_ms_last_step\": %.1f}\n",
-         c3 ? "c3" : "c2", rows, threads, (long long)batch_rows, steps, groups, avg, best, rows / avg, bytes_per_row,
+         c3 ? "c3" : plain ? "c2plain" : "c2", rows, threads, (long long)batch_rows, steps, groups, avg, best, rows / avg, bytes_per_row,
          rows * bytes_per_row / avg / 1e9, (uint64_t)st.bytes_staged, st.staging_ms);
   prism_gpu_plan_free(plan);
   prism_gpu_ctx_free(ctx);
