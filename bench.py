@@ -389,12 +389,15 @@ def parquet_feed_line(args) -> dict:
 
 def extra_feeds(args) -> dict:
     """The two ways rows reach HBM from outside, a few steps each, for the default run's record:
-    host Arrow batches streamed through the C ABI (C2, 10^9 rows, PCIe-bound) and Parquet files
-    decoded by the library (C2-shaped, 32e6 rows).  A feed that fails is recorded as such."""
+    host Arrow batches streamed through the C ABI (C2 at 10^9 rows, PCIe-bound, with the service
+    column dictionary encoded and as plain Utf8; C3 at 10^8 rows as PARTIAL states merged) and
+    Parquet files decoded by the library (C2-shaped, 32e6 rows).  A feed that fails is recorded as such."""
     import copy
 
     out = {}
     for name, fn, over in (("stream_C2", stream_feed_line, {"feed": "stream", "steps": 3, "rows": 0}),
+                           ("stream_C2_plain_utf8", stream_feed_line, {"feed": "stream", "steps": 2, "rows": 0, "plain_strings": True}),
+                           ("stream_C3", stream_feed_line, {"feed": "stream", "workload": "C3", "steps": 5, "rows": 0}),
                            ("parquet_C2", parquet_feed_line, {"feed": "parquet", "steps": 5, "warmup": 2, "rows": 0, "partitions": 0})):
         a = copy.copy(args)
         for k, v in over.items():
